@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: M ray-samples/s of one full training step of the voxel-NeRF hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 160^3 SDF (1 ch) + feature grid (12 ch), fine-stage
+model (rgbnet 106->256x3->256, refnet 307->256x3->3), 4096 rays per GPU per step drawn from 8 blender-style cameras,
+global_step=1000.  One timed step = forward_fine + the fine-stage losses + backward + RCCL gradient averaging (N > 1)
++ dense SDF TV-add-grad + MaskedAdam step (sdf dense, k0 masked, MLPs dense) -- a complete training iteration
+(model/nerf_training.py:300-373), all in fp32.  Unit of work = one in-bbox sample point emitted by
+sample_pts_on_rays.  Inputs are resident in HBM before the timed region.  Weak scaling: per-GPU rays fixed.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GRID = 160
+RAYS_PER_GPU = 4096
+N_BATCHES = 8          # distinct ray batches cycled through, so consecutive steps touch different voxels
+GLOBAL_STEP = 1000
+
+
+def make_optimizer(model):
+    """Fine-stage param groups (config/shiny_blender.py:184-187,214-216; model/nerf_training.py:9-37)."""
+    from fgs_nerf_amd.adam import MaskedAdam
+    return MaskedAdam([
+        {'params': [model.k0.grid], 'lr': 0.1, 'name': 'k0', 'skip_zero_grad': True},
+        {'params': [model.sdf.grid], 'lr': 0.005, 'name': 'sdf', 'skip_zero_grad': False},
+        {'params': list(model.rgbnet.parameters()), 'lr': 1e-3, 'name': 'rgbnet', 'skip_zero_grad': False},
+        {'params': list(model.refnet.parameters()), 'lr': 1e-3, 'name': 'refnet', 'skip_zero_grad': False}],
+        betas=(0.9, 0.99))
+
+
+def train_step(model, opt, averager, batch, n_rays_global):
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    ro, rd, vd, target = batch
+    res = model(ro, rd, vd, global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
+    loss = render_losses(res, target, synth.FINE_LOSS, model)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    averager.average()
+    # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)
+    model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)
+    opt.step()
+    return loss
+
+
+def cpu_baseline(n_rays=1024, iters=3):
+    """The oracle (CPU port of the reference path: packed sampling -> F.grid_sample -> NeuS alpha -> early-stop scan ->
+    nn.Linear MLPs -> index_add_ -> backward) on a bounded sample of the same workload, host cores of this box."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    from oracle import oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    model = synth.build_model(GRID, synth.FINE_MODEL, fused=False)
+    P = synth.oracle_params(model)
+    leaves = [P['sdf'], P['k0']] + [t for net in (P['rgbnet'], P['refnet']) for wb in net for t in wb]
+    for t in leaves:
+        t.requires_grad_(True)
+    ro, rd, vd = synth.random_rays(n_rays, seed=synth.SEED + 1000)
+    target = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(3))
+    times, n_in = [], 0
+    for it in range(iters + 1):
+        for t in leaves:
+            t.grad = None
+        t0 = time.perf_counter()
+        res = O.forward_fine(P, ro, rd, vd, global_step=GLOBAL_STEP, near=2.0, stepsize=0.5, bg=1)
+        render_losses(res, target, synth.FINE_LOSS).backward()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+        n_in = res['n_inbbox']
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(n_in / med / 1e6, 4), "unit": "M ray-samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n_rays} rays x {iters} fwd+bwd iterations of the same 160^3 workload "
+                                      f"({n_in} in-bbox samples/iter, median {med * 1e3:.0f} ms), torch CPU + C oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--composed", action="store_true", help="operator-at-a-time HIP path instead of the fused kernels")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.dist import GradAverager
+    from fgs_nerf_amd.ops import render_utils_cuda
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    model = synth.build_model(GRID, synth.FINE_MODEL, device=dev, fused=False if args.composed else None)
+    opt = make_optimizer(model)
+    averager = GradAverager(model.parameters())
+    n_global = RAYS_PER_GPU * world
+
+    # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)
+    batches, n_inbbox = [], []
+    for b in range(N_BATCHES):
+        ro, rd, vd = synth.random_rays(RAYS_PER_GPU, seed=synth.SEED + 97 * b + 10007 * rank)
+        target = torch.rand(RAYS_PER_GPU, 3, generator=torch.Generator().manual_seed(b + 1000 * rank))
+        batch = tuple(t.to(dev).contiguous() for t in (ro, rd, vd, target))
+        out = render_utils_cuda.sample_pts_on_rays(batch[0], batch[1], model.xyz_min, model.xyz_max, 2.0, 1e9,
+                                                   float(0.5 * model.voxel_size))
+        n_inbbox.append(int((~out[1]).sum().item()))
+        batches.append(batch)
+    del out
+
+    for i in range(args.warmup):
+        train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = 0
+    for i in range(args.steps):
+        train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+        samples += n_inbbox[i % N_BATCHES]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ssum = stats[1:].clone()
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        elapsed, samples = float(tmax.item()), float(ssum.item())
+    if rank == 0:
+        line = {
+            "metric": "M ray-samples/sec (fwd+bwd), 160^3 grid, 4096-ray batch",
+            "value": round(samples / elapsed / 1e6, 3), "unit": "M ray-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 160^3 sdf(1ch)+k0(12ch) fine-stage training step "
+                                   "(forward_fine + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step",
+                       "grid": GRID, "rays_per_gpu": RAYS_PER_GPU, "inbbox_samples_per_step_per_gpu": int(sum(n_inbbox) / len(n_inbbox)),
+                       "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
+        }
+        from fgs_nerf_amd import fused
+        line["roofline"] = fused.roofline_report() if hasattr(fused, "roofline_report") else None
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

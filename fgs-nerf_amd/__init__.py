@@ -1,0 +1,16 @@
+"""fgs-nerf_amd -- MI355X (gfx950) native voxel-NeRF render / training hot path.
+
+Drop-in surfaces (same names, arguments and results as the reference's modules):
+
+    ops.render_utils_cuda / ops.total_variation_cuda / ops.adam_upd_cuda   model/cuda/*.cpp pybind modules
+    grid.create_grid / grid.DenseGrid / grid.MaskGrid                      model/grid.py
+    adam.MaskedAdam                                                        model/adam.py
+    dvgo_ray.* / nerf_ray.*                                                model/dvgo_ray.py, model/nerf_ray.py
+    render.Alphas2Weights                                                  model/nerf.py:1173, model/dvgo.py:390
+    nerf.nerf / dvgo.dvgo                                                  model/nerf.py, model/dvgo.py
+
+The directory name contains a hyphen, so it is imported through the sibling alias package
+``fgs_nerf_amd`` (``import fgs_nerf_amd``), which points its ``__path__`` here.
+All device work goes through libfgs_hip.so (include/fgs_hip.h); there is no CPU fallback.
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,114 @@
+"""ctypes binding of libfgs_hip.so (the C ABI declared in include/fgs_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this
+module raises, and every operator built on it raises with it.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C fgs-nerf_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfgs_hip.so")
+
+P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
+
+# name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
+_SIGNATURES = {
+    "fgs_infer_t_minmax": [P, P, P, P, F32, F32, I64, P, P, P],
+    "fgs_infer_n_samples": [P, P, P, F32, I64, P, P],
+    "fgs_infer_ray_start_dir": [P, P, P, I64, P, P, P],
+    "fgs_sample_count": [P, P, P, P, F32, F32, F32, I64, P, P, P, P, P],
+    "fgs_sample_emit": [P, P, P, P, F32, I64, P, P, I64, P, P, P, P, P],
+    "fgs_sample_ndc_pts": [P, P, P, P, I64, I64, P, P, P],
+    "fgs_sample_bg_pts": [P, P, P, F32, I64, I64, P, P],
+    "fgs_maskcache_lookup": [P, P, P, P, I32, I32, I32, I64, P, P],
+    "fgs_raw2alpha": [P, F32, F32, P, I64, P, P, P],
+    "fgs_raw2alpha_bwd": [P, P, F32, P, I64, P, P],
+    "fgs_alpha2weight_fwd": [P, P, I64, I64, P, P, P, P, P, P],
+    "fgs_alpha2weight_bwd": [P, P, P, P, P, P, I64, I64, P, P, P, P],
+    "fgs_tv_add_grad": [P, P, P, F32, F32, F32, I32, I64, I64, I64, I64, I64, I64, I64, I64, P],
+    "fgs_adam_upd": [P, P, P, P, P, I64, I32, F32, F32, F32, F32, I32, P],
+    "fgs_trilerp_fwd": [P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I64, P, P],
+    "fgs_trilerp_bwd": [P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I64, P, P],
+    "fgs_sdf_taps_fwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P, P],
+    "fgs_sdf_taps_bwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P],
+}
+
+_lib = None
+
+
+class FgsError(RuntimeError):
+    """A libfgs_hip.so entry point returned a non-zero status."""
+
+
+def exported_symbols():
+    """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info"])
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FgsError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build() or `make -C fgs-nerf_amd/csrc`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI and the header drifted apart
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        handle.fgs_last_error.restype = c_char_p
+        handle.fgs_last_error.argtypes = []
+        handle.fgs_version.restype = c_int
+        handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                           ctypes.POINTER(c_int64)]
+        handle.fgs_device_info.restype = c_int
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point; raise FgsError carrying fgs_last_error() on failure."""
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        msg = handle.fgs_last_error()
+        raise FgsError(f"{name} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """PyTorch-ROCm's current HIP stream as an integer handle."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check_input(x: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    """The reference's CHECK_INPUT (model/cuda/render_utils.cpp:46-48): device + contiguity, RuntimeError."""
+    if not isinstance(x, torch.Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and x.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {x.dtype}")
+    return x
+
+
+def device_info(device: int = 0):
+    name = ctypes.create_string_buffer(256)
+    cu, wave, lds = c_int(0), c_int(0), c_int64(0)
+    rc = lib().fgs_device_info(device, name, 256, ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(lds))
+    if rc != 0:
+        raise FgsError(f"fgs_device_info failed: {lib().fgs_last_error().decode()}")
+    return {"name": name.value.decode(), "cu_count": cu.value, "wave_size": wave.value, "lds_bytes": lds.value}

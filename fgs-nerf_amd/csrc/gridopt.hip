@@ -1,0 +1,166 @@
+// gridopt.hip -- per-step dense grid work outside autograd: total-variation gradient and the
+// (masked) Adam update.  Both are pure HBM streaming kernels.
+// Reference operators: model/cuda/total_variation_kernel.cu:13-133, model/cuda/adam_upd_kernel.cu:8-133.
+#include "fgs_common.h"
+
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+// One thread per element, walked in MEMORY order so neighbouring lanes touch neighbouring addresses
+// in either layout.  CHANNEL_LAST: memory index = ((x*Y + y)*Z + z)*C + c ; else ((c*X + x)*Y + y)*Z + z.
+// Arithmetic follows total_variation_kernel.cu:22-33 (unmasked: wz,wz / wy,wy / wz,wz -- the
+// reference's axis-weight quirk) and :47-58 (masked: wx / wy / wz, times mask[i]*mask[nbr]).
+template <bool CHANNEL_LAST, bool MASKED>
+__global__ __launch_bounds__(FGS_BLOCK) void k_tv_add_grad(const float *__restrict__ param, float *__restrict__ grad,
+                                                           const float *__restrict__ mask, float wx, float wy, float wz,
+                                                           int dense_mode, GridDesc d, int64_t N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N) return;
+  const float g0 = grad[idx];
+  if (!(dense_mode || g0 != 0.f)) return;
+  int64_t z, y, x;
+  int64_t r = CHANNEL_LAST ? idx / d.C : idx;
+  z = r % d.Z; r /= d.Z;
+  y = r % d.Y; r /= d.Y;
+  x = r % d.X;
+  const float p = param[idx];
+  float g = 0.f;
+  if (!MASKED) {
+    g += (z == 0       ? 0.f : wz * clamp1(p - param[idx - d.sZ]));
+    g += (z == d.Z - 1 ? 0.f : wz * clamp1(p - param[idx + d.sZ]));
+    g += (y == 0       ? 0.f : wy * clamp1(p - param[idx - d.sY]));
+    g += (y == d.Y - 1 ? 0.f : wy * clamp1(p - param[idx + d.sY]));
+    g += (x == 0       ? 0.f : wz * clamp1(p - param[idx - d.sX]));
+    g += (x == d.X - 1 ? 0.f : wz * clamp1(p - param[idx + d.sX]));
+  } else {
+    const float m0 = mask[idx];
+    g += (z == 0       ? 0.f : wx * clamp1(p - param[idx - d.sZ]) * m0 * mask[idx - d.sZ]);
+    g += (z == d.Z - 1 ? 0.f : wx * clamp1(p - param[idx + d.sZ]) * m0 * mask[idx + d.sZ]);
+    g += (y == 0       ? 0.f : wy * clamp1(p - param[idx - d.sY]) * m0 * mask[idx - d.sY]);
+    g += (y == d.Y - 1 ? 0.f : wy * clamp1(p - param[idx + d.sY]) * m0 * mask[idx + d.sY]);
+    g += (x == 0       ? 0.f : wz * clamp1(p - param[idx - d.sX]) * m0 * mask[idx - d.sX]);
+    g += (x == d.X - 1 ? 0.f : wz * clamp1(p - param[idx + d.sX]) * m0 * mask[idx + d.sX]);
+  }
+  grad[idx] = g0 + g;
+}
+
+// adam_upd_kernel.cu:8-58.  MODE: 0 dense, 1 masked (skip grad == 0), 2 per-voxel lr.
+// Contraction pinned as in oracle/fgs_oracle.c orc_adam_upd.
+template <int MODE>
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float perlr, float step_size, float beta1,
+                                         float beta2, float eps) {
+  m = fmaf(beta1, m, (1.f - beta1) * g);
+  v = fmaf(beta2, v, (1.f - beta2) * g * g);
+  const float num = (MODE == 2) ? step_size * perlr * m : step_size * m;
+  p -= num / (sqrtf(v) + eps);
+}
+
+// 4 elements per thread through 16-byte accesses; the masked form reads only grad when all four
+// gradients are zero (the common case for a feature grid that rays touch sparsely).
+template <int MODE>
+__global__ __launch_bounds__(FGS_BLOCK) void k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad,
+                                                         float4 *__restrict__ exp_avg, float4 *__restrict__ exp_avg_sq,
+                                                         const float4 *__restrict__ perlr, int64_t n4, float step_size,
+                                                         float beta1, float beta2, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 g = grad[i];
+  if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
+  float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+  float4 l = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (MODE == 2) l = perlr[i];
+  if (MODE != 1 || g.x != 0.f) adam_one<MODE>(p.x, g.x, m.x, v.x, l.x, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.y != 0.f) adam_one<MODE>(p.y, g.y, m.y, v.y, l.y, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.z != 0.f) adam_one<MODE>(p.z, g.z, m.z, v.z, l.z, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.w != 0.f) adam_one<MODE>(p.w, g.w, m.w, v.w, l.w, step_size, beta1, beta2, eps);
+  param[i] = p;
+  exp_avg[i] = m;
+  exp_avg_sq[i] = v;
+}
+
+template <int MODE>
+__global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
+                              float *__restrict__ exp_avg_sq, const float *__restrict__ perlr, int64_t begin, int64_t n,
+                              float step_size, float beta1, float beta2, float eps) {
+  const int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i];
+  if (MODE == 1 && g == 0.f) return;
+  float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+  adam_one<MODE>(p, g, m, v, MODE == 2 ? perlr[i] : 1.f, step_size, beta1, beta2, eps);
+  param[i] = p;
+  exp_avg[i] = m;
+  exp_avg_sq[i] = v;
+}
+
+template <int MODE>
+int launch_adam(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
+                float step_size, float beta1, float beta2, float eps, hipStream_t st) {
+  const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq |
+                         (uintptr_t)(MODE == 2 ? perlr : nullptr)) & 15) == 0;
+  const int64_t n4 = aligned ? n / 4 : 0;
+  if (n4 > 0) {
+    hipLaunchKernelGGL(k_adam_vec4<MODE>, dim3(fgs_blocks(n4)), dim3(FGS_BLOCK), 0, st, (float4 *)param,
+                       (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, (const float4 *)perlr, n4, step_size,
+                       beta1, beta2, eps);
+    FGS_LAUNCH_OK("fgs_adam_upd/vec4");
+  }
+  const int64_t done = n4 * 4;
+  if (done < n) {
+    hipLaunchKernelGGL(k_adam_scalar<MODE>, dim3(fgs_blocks(n - done)), dim3(FGS_BLOCK), 0, st, param, grad, exp_avg,
+                       exp_avg_sq, perlr, done, n, step_size, beta1, beta2, eps);
+    FGS_LAUNCH_OK("fgs_adam_upd/tail");
+  }
+  return 0;
+}
+
+}  // namespace
+
+FGS_API int fgs_tv_add_grad(const float *param, float *grad, const float *mask, float wx, float wy, float wz,
+                            int dense_mode, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC, int64_t sX, int64_t sY,
+                            int64_t sZ, fgs_stream_t stream) {
+  FGS_REQUIRE(C > 0 && X > 0 && Y > 0 && Z > 0, FGS_E_INVALID, "fgs_tv_add_grad: empty grid");
+  const int64_t N = C * X * Y * Z;
+  FGS_REQUIRE(N < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_tv_add_grad: %lld elements", (long long)N);
+  FGS_REQUIRE(param && grad, FGS_E_INVALID, "fgs_tv_add_grad: null pointer");
+  const bool ch_first = (sZ == 1 && sY == Z && sX == Y * Z && (C == 1 || sC == X * Y * Z));
+  const bool ch_last = (sC == 1 && sZ == C && sY == Z * C && sX == Y * Z * C);
+  FGS_REQUIRE(ch_first || ch_last, FGS_E_INVALID,
+              "fgs_tv_add_grad: strides (%lld,%lld,%lld,%lld) are neither channel-first nor channel-last dense",
+              (long long)sC, (long long)sX, (long long)sY, (long long)sZ);
+  // total_variation_kernel.cu:76-78 / :112-114
+  wx /= 6; wy /= 6; wz /= 6;
+  const GridDesc d{C, X, Y, Z, sC, sX, sY, sZ};
+  const dim3 g(fgs_blocks(N)), b(FGS_BLOCK);
+  hipStream_t st = fgs_s(stream);
+  // channel-first with C==1 is also a valid channel-last walk; prefer the cheaper decode
+  if (ch_first) {
+    if (mask) hipLaunchKernelGGL((k_tv_add_grad<false, true>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
+    else      hipLaunchKernelGGL((k_tv_add_grad<false, false>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
+  } else {
+    if (mask) hipLaunchKernelGGL((k_tv_add_grad<true, true>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
+    else      hipLaunchKernelGGL((k_tv_add_grad<true, false>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
+  }
+  FGS_LAUNCH_OK("fgs_tv_add_grad");
+  return 0;
+}
+
+FGS_API int fgs_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
+                         int step, float beta1, float beta2, float lr, float eps, int mode, fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_adam_upd: n=%lld", (long long)n);
+  FGS_REQUIRE(mode >= 0 && mode <= 2, FGS_E_INVALID, "fgs_adam_upd: mode=%d", mode);
+  if (n == 0) return 0;
+  FGS_REQUIRE(param && grad && exp_avg && exp_avg_sq && (mode != FGS_ADAM_PERLR || perlr), FGS_E_INVALID,
+              "fgs_adam_upd: null pointer");
+  // adam_upd_kernel.cu:72 -- all-float host arithmetic
+  const float step_size = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
+  hipStream_t st = fgs_s(stream);
+  switch (mode) {
+    case FGS_ADAM_DENSE:  return launch_adam<0>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, st);
+    case FGS_ADAM_MASKED: return launch_adam<1>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, st);
+    default:              return launch_adam<2>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, st);
+  }
+}

@@ -1,0 +1,161 @@
+/*
+ * fgs_hip.h -- C ABI of libfgs_hip.so, the MI355X (gfx950) implementation of the
+ * FGS-NeRF voxel render / training hot path.
+ *
+ * Every entry point replaces one operator of the reference's native extensions or one
+ * torch op chain on the path (citations: paths under the reference tree).  Conventions:
+ *
+ *   - plain C: raw DEVICE pointers + element counts, no torch types;
+ *   - fp32 values, int64 indices, uint8 (0/1) masks, exactly the reference dtypes;
+ *   - `stream` is a hipStream_t passed as void* (PyTorch-ROCm's current stream);
+ *   - nothing allocates, frees or synchronises unless stated; outputs are caller-owned
+ *     and fully overwritten (the zero/one initialisations of the reference wrappers
+ *     are done inside);
+ *   - return 0 on success, a positive hipError_t for a HIP failure, or a negative
+ *     FGS_E_* validation code; fgs_last_error() returns a thread-local message.
+ *   - xyz_min / xyz_max / scale / shift are DEVICE float[3] (the reference passes them
+ *     as tensors), so no call needs a device->host read.
+ */
+#ifndef FGS_HIP_H
+#define FGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGS_E_INVALID (-1) /* bad argument (null pointer, negative size, ...)            */
+#define FGS_E_RANGE   (-2) /* size beyond what the kernel indexes (see fgs_limits)       */
+#define FGS_E_NODEV   (-3) /* no HIP device / wrong architecture                         */
+
+typedef void *fgs_stream_t;
+
+const char *fgs_last_error(void);
+int fgs_version(void);                       /* ABI version, currently 1 */
+/* Fills name (<=255 chars + NUL), CU count, wavefront size, LDS bytes per CU. */
+int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wave_size, int64_t *lds_bytes);
+
+/* ---------------------------------------------------------------------------------
+ * render_utils_cuda  (model/cuda/render_utils.cpp:170-184)
+ * ------------------------------------------------------------------------------ */
+
+/* infer_t_minmax  -- render_utils_kernel.cu:11-35,82-104 */
+int fgs_infer_t_minmax(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                       float near, float far, int64_t n_rays, float *t_min, float *t_max, fgs_stream_t stream);
+
+/* infer_n_samples -- render_utils_kernel.cu:37-55,106-121 */
+int fgs_infer_n_samples(const float *rays_d, const float *t_min, const float *t_max, float stepdist,
+                        int64_t n_rays, int64_t *n_samples, fgs_stream_t stream);
+
+/* infer_ray_start_dir -- render_utils_kernel.cu:57-79,123-139 */
+int fgs_infer_ray_start_dir(const float *rays_o, const float *rays_d, const float *t_min, int64_t n_rays,
+                            float *rays_start, float *rays_dir, fgs_stream_t stream);
+
+/* sample_pts_on_rays, first half -- render_utils_kernel.cu:203-212.
+ * Writes t_min, t_max, n_steps [n_rays] and the EXCLUSIVE prefix sum of n_steps into
+ * steps_cumsum [n_rays+1] (steps_cumsum[n_rays] = total sample count M, the value the
+ * reference fetches with .item<int>()).  The caller reads steps_cumsum[n_rays] when it
+ * needs exact-size outputs; the fused path never does. */
+int fgs_sample_count(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                     float near, float far, float stepdist, int64_t n_rays,
+                     int64_t *n_steps, float *t_min, float *t_max, int64_t *steps_cumsum, fgs_stream_t stream);
+
+/* sample_pts_on_rays, second half -- render_utils_kernel.cu:144-194,213-241.
+ * `capacity` is the row count of the output buffers; rows >= M are left untouched.
+ * M is read from steps_cumsum[n_rays] on the device. */
+int fgs_sample_emit(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                    float stepdist, int64_t n_rays, const float *t_min, const int64_t *steps_cumsum,
+                    int64_t capacity, float *rays_pts, uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id,
+                    fgs_stream_t stream);
+
+/* sample_ndc_pts_on_rays -- render_utils_kernel.cu:244-293 */
+int fgs_sample_ndc_pts(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
+                       int64_t n_samples, int64_t n_rays, float *rays_pts, uint8_t *mask_outbbox, fgs_stream_t stream);
+
+/* sample_bg_pts_on_rays -- render_utils_kernel.cu:300-360 */
+int fgs_sample_bg_pts(const float *rays_o, const float *rays_d, const float *t_max, float bg_preserve,
+                      int64_t n_samples, int64_t n_rays, float *rays_pts, fgs_stream_t stream);
+
+/* maskcache_lookup -- render_utils_kernel.cu:373-424 (out fully written, 0 outside the volume) */
+int fgs_maskcache_lookup(const uint8_t *world, const float *xyz, const float *xyz2ijk_scale, const float *xyz2ijk_shift,
+                         int sz_i, int sz_j, int sz_k, int64_t n_pts, uint8_t *out, fgs_stream_t stream);
+
+/* raw2alpha / raw2alpha_nonuni -- render_utils_kernel.cu:430-504.  interval_nonuni == NULL selects the
+ * uniform-interval form. */
+int fgs_raw2alpha(const float *density, float shift, float interval, const float *interval_nonuni, int64_t n_pts,
+                  float *exp_d, float *alpha, fgs_stream_t stream);
+/* raw2alpha_backward / _nonuni_backward -- render_utils_kernel.cu:506-574 */
+int fgs_raw2alpha_bwd(const float *exp_d, const float *grad_back, float interval, const float *interval_nonuni,
+                      int64_t n_pts, float *grad, fgs_stream_t stream);
+
+/* alpha2weight -- render_utils_kernel.cu:576-651.  ray_id sorted ascending.  One wavefront per ray;
+ * the sequential double-precision transmittance chain of the reference is kept bit for bit. */
+int fgs_alpha2weight_fwd(const float *alpha, const int64_t *ray_id, int64_t n_pts, int64_t n_rays,
+                         float *weight, float *T, float *alphainv_last, int64_t *i_start, int64_t *i_end,
+                         fgs_stream_t stream);
+/* alpha2weight_backward -- render_utils_kernel.cu:653-707 */
+int fgs_alpha2weight_bwd(const float *alpha, const float *weight, const float *T, const float *alphainv_last,
+                         const int64_t *i_start, const int64_t *i_end, int64_t n_pts, int64_t n_rays,
+                         const float *grad_weights, const float *grad_last, float *grad, fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * total_variation_cuda (model/cuda/total_variation.cpp:29-32)
+ * ------------------------------------------------------------------------------ */
+
+/* total_variation_add_grad (mask == NULL, total_variation_kernel.cu:13-35,69-98) and
+ * total_variation_add_grad_new (mask != NULL, :38-66,101-133).  param/grad/mask are [1,C,X,Y,Z]
+ * tensors sharing the element strides (sC,sX,sY,sZ): (X*Y*Z, Y*Z, Z, 1) for the reference's
+ * channel-first layout, (1, Y*Z*C, Z*C, C) for this build's channel-last DenseGrid storage. */
+int fgs_tv_add_grad(const float *param, float *grad, const float *mask, float wx, float wy, float wz, int dense_mode,
+                    int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                    fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * adam_upd_cuda (model/cuda/adam_upd.cpp:79-86)
+ * ------------------------------------------------------------------------------ */
+
+#define FGS_ADAM_DENSE  0 /* adam_upd            adam_upd_kernel.cu:8-23,60-83    */
+#define FGS_ADAM_MASKED 1 /* masked_adam_upd     adam_upd_kernel.cu:25-40,85-108  */
+#define FGS_ADAM_PERLR  2 /* adam_upd_with_perlr adam_upd_kernel.cu:42-58,110-133 */
+int fgs_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
+                 int step, float beta1, float beta2, float lr, float eps, int mode, fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Trilinear grid lookup -- replaces F.grid_sample(grid[1,C,X,Y,Z], ind_norm, 'bilinear',
+ * align_corners=True, zeros padding) as called by DenseGrid.forward (model/grid.py:49-59),
+ * nerf.grid_sampler (model/nerf.py:654-657) and MaskCache.forward (model/nerf.py:1203-1209).
+ * pts are WORLD coordinates [M,3]; the xyz -> [-1,1] -> index round trip of the reference is
+ * reproduced operation by operation.  out / grad_out are [M,C] row-major.
+ * Element strides as in fgs_tv_add_grad.
+ * ------------------------------------------------------------------------------ */
+int fgs_trilerp_fwd(const float *grid, int64_t C, int64_t X, int64_t Y, int64_t Z,
+                    int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                    const float *xyz_min, const float *xyz_max, const float *pts, int64_t M, float *out,
+                    fgs_stream_t stream);
+/* Scatter-add of grad_out into grad_grid (same strides; NOT zeroed here, accumulates with fp32 atomics). */
+int fgs_trilerp_bwd(float *grad_grid, int64_t C, int64_t X, int64_t Y, int64_t Z,
+                    int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                    const float *xyz_min, const float *xyz_max, const float *pts, int64_t M, const float *grad_out,
+                    fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Axis taps of the 1-channel SDF grid -- nerf.sample_sdfs (model/nerf.py:597-637).
+ * For each of M world points and each of K displacements (HOST float[K], K <= 8, in voxels):
+ * six lookups at ind -/+ displace along z, y, x (index space, clamped to the volume).
+ *   feat [M, 6K] : layout ((axis_zyx*2 + sign) * K + k), the reference's `feat.view(M, 6*K)`
+ *   diff [M, 3K] : clamped index distance of each -/+ pair (layout axis_zyx * K + k), may be NULL;
+ *                  the reference's finite difference is (feat[+] - feat[-]) / diff / voxel_size.
+ * The grid is [1,1,X,Y,Z] contiguous.  Backward scatter-adds grad_feat into grad_grid (not zeroed).
+ * ------------------------------------------------------------------------------ */
+int fgs_sdf_taps_fwd(const float *grid, int64_t X, int64_t Y, int64_t Z, const float *xyz_min, const float *xyz_max,
+                     const float *pts, int64_t M, const float *displace_host, int K, float *feat, float *diff,
+                     fgs_stream_t stream);
+int fgs_sdf_taps_bwd(float *grad_grid, int64_t X, int64_t Y, int64_t Z, const float *xyz_min, const float *xyz_max,
+                     const float *pts, int64_t M, const float *displace_host, int K, const float *grad_feat,
+                     fgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGS_HIP_H */
