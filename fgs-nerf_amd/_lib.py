@@ -37,6 +37,21 @@ _SIGNATURES = {
     "fgs_trilerp_bwd": [P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I64, P, P],
     "fgs_sdf_taps_fwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P, P],
     "fgs_sdf_taps_bwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P],
+    "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P],
+    "fgs_exclusive_scan_i64": [P, I64, P, P],
+    "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
+                           P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_surv_compact": [I64, I64, P, I32, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32,
+                         P, P, P, P, P, P, P, P, P],
+    "fgs_march_fine_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, I32,
+                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_feat_fine_fwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, I64, I64, I64, P, P, P, P],
+    "fgs_feat_fine_bwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64,
+                          P, P, P],
+    "fgs_head_fwd": [P, I64, I32, I64, P, P, P, P],
+    "fgs_head_bwd": [P, I64, I32, I64, P, P, P, P, P, P, P],
+    "fgs_composite_fwd": [I64, P, P, P, P, P, F32, F32, P, P, P, P, P, P, P],
+    "fgs_composite_bwd": [I64, P, P, P, P, P, P, P, P, P, F32, P, P, P],
 }
 
 _lib = None

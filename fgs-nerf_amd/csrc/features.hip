@@ -1,0 +1,587 @@
+// features.hip -- per-survivor feature assembly, the 3-wide output head and the per-ray compositing of
+// nerf.forward_fine (model/nerf.py:835-903), forward and backward.
+//
+// Reference chain being fused (all over the M_s samples that survive both thresholds):
+//   normal / l2_normalize (:835), xyz positional encoding (:837-839), k0 = DenseGrid(ray_pts) (:841, C = 12),
+//   sample_sdfs with 4 displacements = 24 trilinear taps + 12 normalised finite differences (:851),
+//   view-direction encoding gathered by ray_id (:871-873), torch.cat into rgb_feat [M_s,106] (:874),
+//   reflection direction + its encoding (:879-881), cat with the rgbnet output (:883),
+//   last refnet Linear (256 -> 3) + two sigmoids (:884-886), three segment_coo sums + background (:888-903).
+// The kernels write straight into the MLP operand buffers X0 [M_s, ldx0] and Z [M_s, ldz] (Z columns
+// [0, off_ref) are filled by the rgbnet's last GEMM), so no concatenation copy exists.
+#include "fgs_taps.h"
+
+namespace {
+
+constexpr int MAXK = 8;
+
+struct FeatLayout {
+  int k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, center_sdf, use_grad_norm;
+  int K;
+  float disp[MAXK];
+  int off_k0, off_xyz, off_view, off_sdf, off_feat, off_hgrad, off_grad, x0_cols, ldx0;
+  int off_ref, z_cols, ldz;
+};
+
+struct SurvArgs {
+  int64_t M;  // survivors
+  const int64_t *ray_id;
+  const float *pts, *sdf, *gradient, *viewdirs;  // pts/sdf/gradient per survivor, viewdirs per ray
+  SceneGeom geom;
+  FeatLayout L;
+};
+
+// ---------------------------------------------------------------------------------------------- k0 lookup
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const float *__restrict__ k0, GridDesc kd,
+                                                           float *__restrict__ X0) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= S.M * kd.C) return;
+  const int64_t m = tid / kd.C, c = tid - m * kd.C;
+  const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
+  X0[m * S.L.ldx0 + S.L.off_k0 + c] = fgs_tri_sample(k0, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz));
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__restrict__ k0_grad, GridDesc kd,
+                                                           const float *__restrict__ dX0) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= S.M * kd.C) return;
+  const int64_t m = tid / kd.C, c = tid - m * kd.C;
+  const float g = dX0[m * S.L.ldx0 + S.L.off_k0 + c];
+  if (g == 0.f) return;
+  const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
+  fgs_tri_scatter(k0_grad, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz), g);
+}
+
+// ------------------------------------------------------------------------------- hierarchical SDF taps (K <= 5)
+// 32 lanes per survivor (two survivors per wavefront): lane j < 6K evaluates tap j = pair*K + k; lanes j < 3K then
+// form the finite difference of axis a = j / K, displacement k = j % K from the tap lanes with in-group shuffles.
+struct TapLane {
+  float f, clamped;
+};
+
+__device__ __forceinline__ float group_shfl(float v, int src_in_group) { return __shfl(v, src_in_group, 32); }
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_fwd(SurvArgs S, const float *__restrict__ sdf_grid,
+                                                             float *__restrict__ X0) {
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int j = threadIdx.x & 31;
+  const int K = S.L.K;
+  const bool row_ok = m < S.M;
+  const GridDesc gd = fgs_sdf_desc(S.geom);
+  float f = 0.f, cl = 0.f;
+  if (row_ok && j < 6 * K) {
+    const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
+    const TapPoint tp = fgs_tap_point(p, gd, j / K, S.L.disp[j % K]);
+    f = fgs_tap_value(sdf_grid, gd, tp);
+    cl = tp.clamped;
+    X0[m * S.L.ldx0 + S.L.off_feat + j] = f;
+  }
+  // finite differences (model/nerf.py:621-626): lane j < 3K -> axis a, displacement k
+  const int a = (j < 3 * K) ? j / K : 0, k = (j < 3 * K) ? j % K : 0;
+  const float fp = group_shfl(f, (2 * a + 1) * K + k), fm = group_shfl(f, (2 * a) * K + k);
+  const float cp = group_shfl(cl, (2 * a + 1) * K + k), cm = group_shfl(cl, (2 * a) * K + k);
+  float g = ((fp - fm) / (cp - cm)) / S.geom.voxel_size;
+  if (S.L.use_grad_norm) {  // grad / (grad.norm(dim=axis) + 1e-5), model/nerf.py:631-632
+    const float g0 = group_shfl(g, k), g1 = group_shfl(g, K + k), g2 = group_shfl(g, 2 * K + k);
+    const float nrm = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+    g = g / (nrm + 1e-5f);
+  }
+  if (row_ok && j < 3 * K) X0[m * S.L.ldx0 + S.L.off_hgrad + j] = g;
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const float *__restrict__ X0,
+                                                             const float *__restrict__ dX0,
+                                                             float *__restrict__ sdf_grad_grid) {
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int j = threadIdx.x & 31;
+  const int K = S.L.K;
+  const bool row_ok = m < S.M;
+  const GridDesc gd = fgs_sdf_desc(S.geom);
+  const bool tap_lane = row_ok && j < 6 * K;
+  float f = 0.f, cl = 0.f, d_f = 0.f;
+  TapPoint tp = {0.f, 0.f, 0.f, 0.f};
+  if (tap_lane) {
+    const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
+    tp = fgs_tap_point(p, gd, j / K, S.L.disp[j % K]);
+    f = X0[m * S.L.ldx0 + S.L.off_feat + j];  // saved forward value
+    cl = tp.clamped;
+    d_f = dX0[m * S.L.ldx0 + S.L.off_feat + j];
+  }
+  // lanes j < 3K: gradient of the (optionally normalised) finite difference w.r.t. the raw difference
+  const int a = (j < 3 * K) ? j / K : 0, k = (j < 3 * K) ? j % K : 0;
+  const float fp = group_shfl(f, (2 * a + 1) * K + k), fm = group_shfl(f, (2 * a) * K + k);
+  const float cp = group_shfl(cl, (2 * a + 1) * K + k), cm = group_shfl(cl, (2 * a) * K + k);
+  const float diff = cp - cm;
+  const float g_raw = ((fp - fm) / diff) / S.geom.voxel_size;
+  float dy = (row_ok && j < 3 * K) ? dX0[m * S.L.ldx0 + S.L.off_hgrad + j] : 0.f;
+  float dg = dy;
+  if (S.L.use_grad_norm) {
+    const float g0 = group_shfl(g_raw, k), g1 = group_shfl(g_raw, K + k), g2 = group_shfl(g_raw, 2 * K + k);
+    const float y0 = group_shfl(dy, k), y1 = group_shfl(dy, K + k), y2 = group_shfl(dy, 2 * K + k);
+    const float r = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+    const float dot = (y0 * g0 + y1 * g1) + y2 * g2;
+    dg = dy / (r + 1e-5f);
+    if (r > 0.f) dg -= dot / (r * (r + 1e-5f) * (r + 1e-5f)) * g_raw;
+  }
+  const float coef = (j < 3 * K) ? (dg / S.geom.voxel_size) / diff : 0.f;
+  // back to the tap lanes: tap (pair, k) takes +/- coef of axis pair>>1
+  const int pair = (j < 6 * K) ? j / K : 0, kk = (j < 6 * K) ? j % K : 0;
+  const float c_axis = group_shfl(coef, (pair >> 1) * K + kk);
+  if (tap_lane) {
+    const float total = d_f + ((pair & 1) ? c_axis : -c_axis);
+    if (total != 0.f) fgs_tri_scatter(sdf_grad_grid, gd, 0, fgs_tri_setup(tp.fx, tp.fy, tp.fz), total);
+  }
+}
+
+// --------------------------------------------------------- encodings, normal, reflection (16 lanes per survivor)
+struct Normal3 {
+  float n[3];
+};
+
+// normal = l2_normalize(g / (|g| + 1e-7)), model/nerf.py:835,480-483
+__device__ __forceinline__ Normal3 normal_of(float gx, float gy, float gz) {
+  const float r = sqrtf((gx * gx + gy * gy) + gz * gz);
+  const float x0 = gx / (r + 1e-7f), x1 = gy / (r + 1e-7f), x2 = gz / (r + 1e-7f);
+  const float q = (x0 * x0 + x1 * x1) + x2 * x2;
+  const float nr = sqrtf(fmaxf(q, 1.1920928955078125e-07f));
+  Normal3 o;
+  o.n[0] = x0 / nr; o.n[1] = x1 / nr; o.n[2] = x2 / nr;
+  return o;
+}
+
+// [x, sin(x f_i), cos(x f_i)] block of one component: row[3 + c*F + f], row[3 + 3F + c*F + f]
+__device__ __forceinline__ void write_pe_component(float *__restrict__ row, int c, float x, int F) {
+  row[c] = x;
+  float freq = 1.f;
+  for (int f = 0; f < F; ++f) {
+    const float arg = x * freq;
+    row[3 + c * F + f] = sinf(arg);
+    row[3 + 3 * F + c * F + f] = cosf(arg);
+    freq *= 2.f;
+  }
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *__restrict__ X0, float *__restrict__ Z,
+                                                            float *__restrict__ normal_out) {
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int slot = threadIdx.x & 15;
+  if (m >= S.M || slot > 9) return;
+  const FeatLayout &L = S.L;
+  float *x0 = X0 + m * L.ldx0;
+  if (slot < 3) {  // rays_xyz = (p - lo) / (hi - lo), model/nerf.py:837
+    const float u = (S.pts[3 * m + slot] - S.geom.lo[slot]) / (S.geom.hi[slot] - S.geom.lo[slot]);
+    write_pe_component(x0 + L.off_xyz, slot, u, L.n_posfreq);
+  } else if (slot < 6) {
+    if (L.use_viewdir) write_pe_component(x0 + L.off_view, slot - 3, S.viewdirs[3 * S.ray_id[m] + (slot - 3)], L.n_viewfreq);
+  } else if (slot < 9) {
+    const int c = slot - 6;
+    const int64_t r = S.ray_id[m];
+    const float v0 = S.viewdirs[3 * r], v1 = S.viewdirs[3 * r + 1], v2 = S.viewdirs[3 * r + 2];
+    const Normal3 nn = normal_of(S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]);
+    const float dot = (v0 * nn.n[0] + v1 * nn.n[1]) + v2 * nn.n[2];
+    const float vc = (c == 0) ? v0 : (c == 1 ? v1 : v2);
+    const float refl = vc - (2.f * dot) * nn.n[c];  // model/nerf.py:879
+    write_pe_component(Z + m * L.ldz + L.off_ref, c, refl, L.n_reffreq);
+    normal_out[3 * m + c] = nn.n[c];
+  } else {  // slot 9: scalar features and zero padding
+    if (L.center_sdf) x0[L.off_sdf] = S.sdf[m];
+    x0[L.off_grad + 0] = S.gradient[3 * m + 0];
+    x0[L.off_grad + 1] = S.gradient[3 * m + 1];
+    x0[L.off_grad + 2] = S.gradient[3 * m + 2];
+    for (int c = L.x0_cols; c < L.ldx0; ++c) x0[c] = 0.f;
+    for (int c = L.z_cols; c < L.ldz; ++c) Z[m * L.ldz + c] = 0.f;
+  }
+}
+
+// One thread per survivor: gradients reaching sdf and the raw gradient vector through the feature columns,
+// the normal (orientation loss, reflection) and the reflection encoding.
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const float *__restrict__ Z,
+                                                            const float *__restrict__ dX0, const float *__restrict__ dZ,
+                                                            const float *__restrict__ g_normal, float *__restrict__ g_sdf,
+                                                            float *__restrict__ g_gradient) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= S.M) return;
+  const FeatLayout &L = S.L;
+  const int F = L.n_reffreq;
+  const float *z = Z + m * L.ldz + L.off_ref;
+  const float *dz = dZ + m * L.ldz + L.off_ref;
+  // d reflect_c = dE[c] + sum_f f (cos * dE_sin - sin * dE_cos)
+  float dr[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float acc = dz[c], freq = 1.f;
+    for (int f = 0; f < F; ++f) {
+      const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
+      acc += freq * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
+      freq *= 2.f;
+    }
+    dr[c] = acc;
+  }
+  const int64_t r = S.ray_id[m];
+  const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
+  const float g[3] = {S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]};
+  // recompute the two-stage normalisation
+  const float rn = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+  const float x[3] = {g[0] / (rn + 1e-7f), g[1] / (rn + 1e-7f), g[2] / (rn + 1e-7f)};
+  const float q = (x[0] * x[0] + x[1] * x[1]) + x[2] * x[2];
+  const float eps = 1.1920928955078125e-07f;
+  const float nr = sqrtf(fmaxf(q, eps));
+  const float n[3] = {x[0] / nr, x[1] / nr, x[2] / nr};
+  // reflect = v - 2 (v.n) n
+  const float s = (v[0] * n[0] + v[1] * n[1]) + v[2] * n[2];
+  const float drn = (dr[0] * n[0] + dr[1] * n[1]) + dr[2] * n[2];
+  float dn[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dn[c] = -2.f * (v[c] * drn + s * dr[c]) + (g_normal ? g_normal[3 * m + c] : 0.f);
+  // normal = x / sqrt(max(sum x^2, eps))
+  const float dnx = (dn[0] * x[0] + dn[1] * x[1]) + dn[2] * x[2];
+  float dx[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dx[c] = dn[c] / nr - ((q > eps) ? dnx / (nr * nr * nr) * x[c] : 0.f);
+  // x = g / (|g| + 1e-7)
+  const float dxg = (dx[0] * g[0] + dx[1] * g[1]) + dx[2] * g[2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float dg = dx[c] / (rn + 1e-7f);
+    if (rn > 0.f) dg -= dxg / ((rn + 1e-7f) * (rn + 1e-7f)) * (g[c] / rn);
+    g_gradient[3 * m + c] = dg + dX0[m * L.ldx0 + L.off_grad + c];
+  }
+  g_sdf[m] = L.center_sdf ? dX0[m * L.ldx0 + L.off_sdf] : 0.f;
+}
+
+// ------------------------------------------------------------------------- 3-wide output head (refnet last Linear)
+// out = R3 . V4^T + c4 ; rgb = sigmoid(out).  One wavefront per row, lane l owns columns 4l..4l+3 (W <= 256).
+__global__ __launch_bounds__(FGS_BLOCK) void k_head_fwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
+                                                        const float *__restrict__ V, const float *__restrict__ bias,
+                                                        float *__restrict__ rgb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
+  const bool col_ok = 4 * lane < W;
+  float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
+  if (col_ok) {
+    w0 = *reinterpret_cast<const float4 *>(V + 0 * W + 4 * lane);
+    w1 = *reinterpret_cast<const float4 *>(V + 1 * W + 4 * lane);
+    w2 = *reinterpret_cast<const float4 *>(V + 2 * W + 4 * lane);
+  }
+  for (int64_t m = wave; m < M; m += n_waves) {
+    float4 x = make_float4(0, 0, 0, 0);
+    if (col_ok) x = *reinterpret_cast<const float4 *>(R + m * ldr + 4 * lane);
+    float a0 = ((x.x * w0.x + x.y * w0.y) + x.z * w0.z) + x.w * w0.w;
+    float a1 = ((x.x * w1.x + x.y * w1.y) + x.z * w1.z) + x.w * w1.w;
+    float a2 = ((x.x * w2.x + x.y * w2.y) + x.z * w2.z) + x.w * w2.w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 64);
+      a1 += __shfl_xor(a1, off, 64);
+      a2 += __shfl_xor(a2, off, 64);
+    }
+    if (lane == 0) {
+      rgb[3 * m + 0] = 1.f / (1.f + expf(-(a0 + bias[0])));
+      rgb[3 * m + 1] = 1.f / (1.f + expf(-(a1 + bias[1])));
+      rgb[3 * m + 2] = 1.f / (1.f + expf(-(a2 + bias[2])));
+    }
+  }
+}
+
+// d_out [M,3] -> dR = (d_out . V4) * (R > 0) ; dV4 += d_out^T R ; dc4 += colsum(d_out) ; dR_colsum += colsum(dR)
+__global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
+                                                        const float *__restrict__ V, const float *__restrict__ d_out,
+                                                        float *__restrict__ dR, float *__restrict__ dV,
+                                                        float *__restrict__ dbias, float *__restrict__ dR_colsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
+  const bool col_ok = 4 * lane < W;
+  float4 w[3], acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    w[c] = col_ok ? *reinterpret_cast<const float4 *>(V + c * W + 4 * lane) : make_float4(0, 0, 0, 0);
+    acc[c] = make_float4(0, 0, 0, 0);
+  }
+  float bsum[3] = {0.f, 0.f, 0.f};
+  float4 osum = make_float4(0, 0, 0, 0);
+  for (int64_t m = wave; m < M; m += n_waves) {
+    const float d0 = d_out[3 * m], d1 = d_out[3 * m + 1], d2 = d_out[3 * m + 2];
+    bsum[0] += d0; bsum[1] += d1; bsum[2] += d2;
+    if (!col_ok) continue;
+    const float4 x = *reinterpret_cast<const float4 *>(R + m * ldr + 4 * lane);
+    float4 o;
+    o.x = (x.x > 0.f) ? (d0 * w[0].x + d1 * w[1].x) + d2 * w[2].x : 0.f;
+    o.y = (x.y > 0.f) ? (d0 * w[0].y + d1 * w[1].y) + d2 * w[2].y : 0.f;
+    o.z = (x.z > 0.f) ? (d0 * w[0].z + d1 * w[1].z) + d2 * w[2].z : 0.f;
+    o.w = (x.w > 0.f) ? (d0 * w[0].w + d1 * w[1].w) + d2 * w[2].w : 0.f;
+    *reinterpret_cast<float4 *>(dR + m * ldr + 4 * lane) = o;
+    osum.x += o.x; osum.y += o.y; osum.z += o.z; osum.w += o.w;
+    const float dd[3] = {d0, d1, d2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc[c].x = fmaf(dd[c], x.x, acc[c].x);
+      acc[c].y = fmaf(dd[c], x.y, acc[c].y);
+      acc[c].z = fmaf(dd[c], x.z, acc[c].z);
+      acc[c].w = fmaf(dd[c], x.w, acc[c].w);
+    }
+  }
+  if (col_ok) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicAdd(dV + c * W + 4 * lane + 0, acc[c].x);
+      atomicAdd(dV + c * W + 4 * lane + 1, acc[c].y);
+      atomicAdd(dV + c * W + 4 * lane + 2, acc[c].z);
+      atomicAdd(dV + c * W + 4 * lane + 3, acc[c].w);
+    }
+    if (dR_colsum) {
+      atomicAdd(dR_colsum + 4 * lane + 0, osum.x);
+      atomicAdd(dR_colsum + 4 * lane + 1, osum.y);
+      atomicAdd(dR_colsum + 4 * lane + 2, osum.z);
+      atomicAdd(dR_colsum + 4 * lane + 3, osum.w);
+    }
+  }
+  if (lane < 3) atomicAdd(dbias + lane, bsum[lane]);  // every lane walked the same rows
+}
+
+// -------------------------------------------------------------------------------------------- per-ray compositing
+struct CompositeArgs {
+  int64_t n_rays;
+  const int64_t *surv_off;  // [n_rays + 1]
+  const float *weights, *rgb, *normal;  // per survivor
+  const int64_t *step_id;
+  float bg, dist;
+  float *rgb_marched, *sigmoid_rgb, *pre_rgb, *pre_sig;  // [n_rays,3]
+  float *normal_marched;  // [n_rays,3] or null (render_grad)
+  float *depth;           // [n_rays] or null (render_depth)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_composite_fwd(CompositeArgs C) {
+  const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (ray >= C.n_rays) return;
+  const int64_t s0 = fgs_uniform(C.surv_off[ray]), s1 = fgs_uniform(C.surv_off[ray + 1]);
+  float acc[3] = {0, 0, 0}, sig[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, wsum = 0.f, dep = 0.f;
+  for (int64_t i = s0 + lane; i < s1; i += FGS_WAVE) {
+    const float w = C.weights[i];
+    wsum += w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = C.rgb[3 * i + c];
+      acc[c] += w * v;
+      sig[c] += w * (1.f / (1.f + expf(-v)));  // sigmoid_rgb = sigmoid(rgb): the reference's second sigmoid (:886)
+      if (C.normal_marched) nrm[c] += w * C.normal[3 * i + c];
+    }
+    if (C.depth) dep += (w * (float)C.step_id[i]) * C.dist;
+  }
+  wsum = wave_sum(wsum);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    acc[c] = wave_sum(acc[c]);
+    sig[c] = wave_sum(sig[c]);
+    if (C.normal_marched) nrm[c] = wave_sum(nrm[c]);
+  }
+  if (C.depth) dep = wave_sum(dep);
+  if (lane == 0) {
+    const float bgterm = (1.f - wsum) * C.bg;  // model/nerf.py:899,902
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = acc[c] + bgterm, b = sig[c] + bgterm;
+      C.pre_rgb[3 * ray + c] = a;
+      C.pre_sig[3 * ray + c] = b;
+      C.rgb_marched[3 * ray + c] = fminf(fmaxf(a, 0.f), 1.f);
+      C.sigmoid_rgb[3 * ray + c] = fminf(fmaxf(b, 0.f), 1.f);
+      if (C.normal_marched) C.normal_marched[3 * ray + c] = nrm[c];
+    }
+    if (C.depth) C.depth[ray] = dep;
+  }
+}
+
+struct CompositeBwdArgs {
+  int64_t M;
+  const int64_t *ray_id;
+  const float *weights, *rgb;
+  const float *pre_rgb, *pre_sig;                   // [n_rays,3]
+  const float *g_rgb_marched, *g_sigmoid_rgb;       // [n_rays,3] or null
+  const float *g_raw_rgb;                           // [M,3] or null
+  const float *g_weights_direct;                    // [M] or null
+  float bg;
+  float *d_out;  // [M,3] gradient w.r.t. the pre-sigmoid head output
+  float *d_w;    // [M]
+};
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_composite_bwd(CompositeBwdArgs C) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= C.M) return;
+  const int64_t r = C.ray_id[m];
+  const float w = C.weights[m];
+  float dw = C.g_weights_direct ? C.g_weights_direct[m] : 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = C.rgb[3 * m + c];
+    const float sg = 1.f / (1.f + expf(-v));
+    float g1 = 0.f, g2 = 0.f;  // clamp(0,1) passes the gradient on the closed interval
+    if (C.g_rgb_marched) {
+      const float pre = C.pre_rgb[3 * r + c];
+      g1 = (pre >= 0.f && pre <= 1.f) ? C.g_rgb_marched[3 * r + c] : 0.f;
+    }
+    if (C.g_sigmoid_rgb) {
+      const float pre = C.pre_sig[3 * r + c];
+      g2 = (pre >= 0.f && pre <= 1.f) ? C.g_sigmoid_rgb[3 * r + c] : 0.f;
+    }
+    dw += v * g1 + sg * g2 - C.bg * (g1 + g2);
+    float d_rgb = w * g1 + (w * g2) * (sg * (1.f - sg));
+    if (C.g_raw_rgb) d_rgb += C.g_raw_rgb[3 * m + c];
+    C.d_out[3 * m + c] = d_rgb * (v * (1.f - v));  // rgb = sigmoid(out)
+  }
+  C.d_w[m] = dw;
+}
+
+SceneGeom geom_of(const float *lo, const float *hi, int X, int Y, int Z, float voxel_size) {
+  SceneGeom g;
+  for (int c = 0; c < 3; ++c) { g.lo[c] = lo[c]; g.hi[c] = hi[c]; }
+  g.X = X; g.Y = Y; g.Z = Z; g.voxel_size = voxel_size;
+  return g;
+}
+
+int fill_layout(const int *li, const float *disp, FeatLayout *L) {
+  // li: k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, center_sdf, use_grad_norm, K, ldx0, off_ref, ldz
+  L->k0_dim = li[0]; L->n_posfreq = li[1]; L->n_viewfreq = li[2]; L->n_reffreq = li[3];
+  L->use_viewdir = li[4]; L->center_sdf = li[5]; L->use_grad_norm = li[6]; L->K = li[7];
+  L->ldx0 = li[8]; L->off_ref = li[9]; L->ldz = li[10];
+  if (L->K < 0 || L->K > 5) return fgs_set_error(FGS_E_RANGE, "feature layout: K=%d displacements (0..5 supported)", L->K);
+  for (int i = 0; i < MAXK; ++i) L->disp[i] = (i < L->K && disp) ? disp[i] : 0.f;
+  // column order of torch.cat([k0, xyz_emb, viewdirs_emb, sdf, all_feat, all_grad, gradient]) (model/nerf.py:874)
+  int c = 0;
+  L->off_k0 = c; c += L->k0_dim;
+  L->off_xyz = c; c += 3 + 6 * L->n_posfreq;
+  L->off_view = c; c += L->use_viewdir ? 3 + 6 * L->n_viewfreq : 0;
+  L->off_sdf = c; c += L->center_sdf ? 1 : 0;
+  L->off_feat = c; c += 6 * L->K;
+  L->off_hgrad = c; c += 3 * L->K;
+  L->off_grad = c; c += 3;
+  L->x0_cols = c;
+  L->z_cols = L->off_ref + 3 + 6 * L->n_reffreq;
+  if (L->ldx0 < L->x0_cols || L->ldz < L->z_cols || (L->ldx0 & 3) || (L->ldz & 3))
+    return fgs_set_error(FGS_E_INVALID, "feature layout: ldx0=%d (need >= %d), ldz=%d (need >= %d), multiples of 4",
+                         L->ldx0, L->x0_cols, L->ldz, L->z_cols);
+  return 0;
+}
+
+}  // namespace
+
+// layout_i: 11 ints (see fill_layout); displace_host: K floats.  Returns x0_cols through *x0_cols_out when non-null.
+FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,
+                              const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                              int Z, float voxel_size, const int *layout_i, const float *displace_host,
+                              const float *sdf_grid, const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY,
+                              int64_t ksZ, float *X0, float *Zbuf, float *normal_out, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_fine_fwd: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && sdf_grid &&
+                  k0_grid && X0 && Zbuf && normal_out, FGS_E_INVALID, "fgs_feat_fine_fwd: null pointer");
+  SurvArgs S;
+  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
+  if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  hipStream_t st = fgs_s(stream);
+  const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
+  hipLaunchKernelGGL(k_feat_k0_fwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grid, kd, X0);
+  FGS_LAUNCH_OK("fgs_feat_fine_fwd/k0");
+  if (S.L.K > 0) {
+    hipLaunchKernelGGL(k_feat_taps_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, sdf_grid, X0);
+    FGS_LAUNCH_OK("fgs_feat_fine_fwd/taps");
+  }
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 16)), dim3(FGS_BLOCK), 0, st, S, X0, Zbuf, normal_out);
+  FGS_LAUNCH_OK("fgs_feat_fine_fwd/enc");
+  return 0;
+}
+
+FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,
+                              const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                              int Z, float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
+                              const float *Zbuf, const float *dX0, const float *dZ, const float *g_normal,
+                              float *sdf_grad_grid, float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ,
+                              float *g_sdf, float *g_gradient, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_fine_bwd: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && Zbuf && dX0 &&
+                  dZ && sdf_grad_grid && k0_grad_grid && g_sdf && g_gradient, FGS_E_INVALID, "fgs_feat_fine_bwd: null pointer");
+  SurvArgs S;
+  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
+  if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  hipStream_t st = fgs_s(stream);
+  const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
+  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+  FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
+  if (S.L.K > 0) {
+    hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, sdf_grad_grid);
+    FGS_LAUNCH_OK("fgs_feat_fine_bwd/taps");
+  }
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
+                     g_gradient);
+  FGS_LAUNCH_OK("fgs_feat_fine_bwd/enc");
+  return 0;
+}
+
+FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *bias, float *rgb,
+                         fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && W > 0 && W <= 256 && (W & 3) == 0 && (ldr & 3) == 0, FGS_E_RANGE,
+              "fgs_head_fwd: M=%lld W=%d ldr=%lld (W <= 256, multiples of 4)", (long long)M, W, (long long)ldr);
+  if (M == 0) return 0;
+  FGS_REQUIRE(R && V && bias && rgb, FGS_E_INVALID, "fgs_head_fwd: null pointer");
+  const int64_t want = (M + 3) / 4;
+  const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb);
+  FGS_LAUNCH_OK("fgs_head_fwd");
+  return 0;
+}
+
+FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR,
+                         float *dV, float *dbias, float *dR_colsum, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && W > 0 && W <= 256 && (W & 3) == 0 && (ldr & 3) == 0, FGS_E_RANGE,
+              "fgs_head_bwd: M=%lld W=%d ldr=%lld", (long long)M, W, (long long)ldr);
+  if (M == 0) return 0;
+  FGS_REQUIRE(R && V && d_out && dR && dV && dbias, FGS_E_INVALID, "fgs_head_bwd: null pointer");
+  const int64_t want = (M + 3) / 4;
+  const unsigned blocks = (unsigned)(want < 512 ? want : 512);
+  hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
+                     dR_colsum);
+  FGS_LAUNCH_OK("fgs_head_bwd");
+  return 0;
+}
+
+FGS_API int fgs_composite_fwd(int64_t n_rays, const int64_t *surv_off, const float *weights, const float *rgb,
+                              const float *normal, const int64_t *step_id, float bg, float dist, float *rgb_marched,
+                              float *sigmoid_rgb, float *pre_rgb, float *pre_sig, float *normal_marched, float *depth,
+                              fgs_stream_t stream) {
+  FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_composite_fwd: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return 0;
+  FGS_REQUIRE(surv_off && rgb_marched && sigmoid_rgb && pre_rgb && pre_sig, FGS_E_INVALID, "fgs_composite_fwd: null pointer");
+  CompositeArgs C;
+  C.n_rays = n_rays; C.surv_off = surv_off; C.weights = weights; C.rgb = rgb; C.normal = normal; C.step_id = step_id;
+  C.bg = bg; C.dist = dist; C.rgb_marched = rgb_marched; C.sigmoid_rgb = sigmoid_rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
+  C.normal_marched = normal_marched; C.depth = depth;
+  hipLaunchKernelGGL(k_composite_fwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), C);
+  FGS_LAUNCH_OK("fgs_composite_fwd");
+  return 0;
+}
+
+FGS_API int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, const float *rgb, const float *pre_rgb,
+                              const float *pre_sig, const float *g_rgb_marched, const float *g_sigmoid_rgb,
+                              const float *g_raw_rgb, const float *g_weights_direct, float bg, float *d_out, float *d_w,
+                              fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_composite_bwd: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(ray_id && weights && rgb && pre_rgb && pre_sig && d_out && d_w, FGS_E_INVALID, "fgs_composite_bwd: null pointer");
+  CompositeBwdArgs C;
+  C.M = M; C.ray_id = ray_id; C.weights = weights; C.rgb = rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
+  C.g_rgb_marched = g_rgb_marched; C.g_sigmoid_rgb = g_sigmoid_rgb; C.g_raw_rgb = g_raw_rgb;
+  C.g_weights_direct = g_weights_direct; C.bg = bg; C.d_out = d_out; C.d_w = d_w;
+  hipLaunchKernelGGL(k_composite_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), C);
+  FGS_LAUNCH_OK("fgs_composite_bwd");
+  return 0;
+}

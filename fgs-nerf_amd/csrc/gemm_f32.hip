@@ -1,0 +1,260 @@
+// gemm_f32.hip -- exact-fp32 matrix-core GEMM for the tiny MLPs (model/nerf.py:125-142: rgbnet / refnet).
+//
+// The reference runs these layers as cuBLAS SGEMMs via nn.Linear.  Here they are v_mfma_f32_32x32x2_f32
+// (f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain, so the 1e-5 rel-L2 bar holds; gfx950 has
+// no reduced-precision f32 path) in one kernel template serving the three products of a Linear layer:
+//
+//   FGS_GEMM_NT  forward        C[m,n]  = sum_k A[m,k] * B[n,k]   (+ bias[n]) (ReLU)        A = X, B = W[N,K]
+//   FGS_GEMM_NN  data gradient  C[m,n]  = sum_k A[m,k] * B[k,n]   (* (mask[m,n] > 0))       A = dY, B = W[K,N]
+//   FGS_GEMM_TN  weight grad    C[m,n] += sum_k A[k,m] * B[k,n]   (split-K, fp32 atomics)   A = dY, B = X
+//
+// Tiling for CDNA4: 256-thread workgroup = 4 wavefronts (one per SIMD), 128x128 output tile, each wave a
+// 64x64 quadrant = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs), K consumed in chunks of 32 through a
+// double-buffered LDS image (<= 73.7 KB, two workgroups per CU).  Operands that are contiguous along K are
+// staged as [row][36] (144-byte rows: the four ds_read_b128 of a lane's 16-value K run are conflict-free);
+// operands contiguous along the output index are staged as [k][128] and read with conflict-free
+// ds_read_b32.  Lane half h owns k = 16h..16h+15 of a chunk for both operands, so one staged chunk feeds
+// 16 MFMAs per tile with no cross-lane movement.  Workgroup ids are dealt so that the column tiles of one
+// row tile land on the same XCD (ids b, b+8, ...) and share its L2.
+#include "fgs_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = 36;   // floats per staged row of a K-contiguous operand
+constexpr int LDI = 128;  // floats per staged k-row of an index-contiguous operand
+constexpr int TILE_FLOATS = 128 * LDK;  // >= 32 * LDI
+
+struct GemmArgs {
+  int64_t M, N, K;
+  const float *A; int64_t lda;
+  const float *B; int64_t ldb;
+  float *C; int64_t ldc;
+  const float *bias;          // NT: [N] or null
+  int relu;                   // NT: apply max(.,0)
+  const float *mask; int64_t ldm;   // NN: zero C where mask <= 0 (saved activation), or null
+  float *colsum;              // NT/NN: if non-null, colsum[n] += sum_m C[m,n] (after the epilogue) -> bias gradients
+  int64_t k_per_split;        // TN: reduction rows handled by one workgroup (multiple of BK)
+  int tiles_m, tiles_n;
+};
+
+enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
+
+// ---- global -> registers -> LDS staging ----------------------------------------------------------------
+// K-contiguous operand: tile = 128 rows x 32 k.  Thread t: k4 = t & 7 (float4 along k), rows t>>3 + 32*p.
+template <bool KC>
+struct Stage {
+  float4 v[4];
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float *p, bool ok) {
+  return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_load(Stage<KC> &s, const float *__restrict__ base, int64_t ld, int64_t row0,
+                                           int64_t n_rows, int64_t k0, int64_t k_end, int tid) {
+  if (KC) {
+    // element (row0 + r, k0 + 4*k4 ..)
+    const int k4 = tid & 7;
+    const int64_t k = k0 + 4 * k4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t r = row0 + (tid >> 3) + 32 * p;
+      s.v[p] = ld4_guard(base + r * ld + k, r < n_rows && k < k_end);
+    }
+  } else {
+    // operand stored [k][index]: element (k0 + kk, row0 + 4*i4 ..)
+    const int i4 = tid & 31;
+    const int64_t i = row0 + 4 * i4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t k = k0 + (tid >> 5) + 8 * p;
+      s.v[p] = ld4_guard(base + k * ld + i, k < k_end && i < n_rows);
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_store(const Stage<KC> &s, float *__restrict__ lds, int tid) {
+  if (KC) {
+    const int k4 = tid & 7;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      *reinterpret_cast<float4 *>(lds + ((tid >> 3) + 32 * p) * LDK + 4 * k4) = s.v[p];
+  } else {
+    const int i4 = tid & 31;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      *reinterpret_cast<float4 *>(lds + ((tid >> 5) + 8 * p) * LDI + 4 * i4) = s.v[p];
+  }
+}
+
+// 16 operand values (k = 16h .. 16h+15 of the chunk) of tile row/col `idx` (0..127) for this lane.
+template <bool KC>
+__device__ __forceinline__ void frag_load(float (&f)[16], const float *__restrict__ lds, int idx, int h) {
+  if (KC) {
+    const float4 *p = reinterpret_cast<const float4 *>(lds + idx * LDK + 16 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = p[q];
+      f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) f[s] = lds[(16 * h + s) * LDI + idx];
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];  // [buffer][A|B]
+
+  // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
+  const int b = blockIdx.x;
+  const int grp = b / (8 * g.tiles_n);
+  const int within = b - grp * 8 * g.tiles_n;
+  const int tile_m = grp * 8 + (within & 7);
+  const int tile_n = within >> 3;
+  if (tile_m >= g.tiles_m) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+
+  int64_t k_begin = 0, k_end = g.K;
+  if (EPI == EPI_ATOMIC) {
+    k_begin = (int64_t)blockIdx.y * g.k_per_split;
+    k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
+    if (k_begin >= k_end) return;
+  }
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stage<A_KC> sa;
+  Stage<B_KC> sb;
+  stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin, k_end, tid);
+  stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin, k_end, tid);
+  stage_store<A_KC>(sa, lds[0][0], tid);
+  stage_store<B_KC>(sb, lds[0][1], tid);
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = k0 + BK < k_end;
+    if (more) {
+      stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k0 + BK, k_end, tid);
+      stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, tid);
+    }
+    float fa[2][16], fb[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      frag_load<A_KC>(fa[t], lds[cur][0], wave_m * 64 + t * 32 + l31, h);
+      frag_load<B_KC>(fb[t], lds[cur][1], wave_n * 64 + t * 32 + l31, h);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    if (more) {
+      stage_store<A_KC>(sa, lds[cur ^ 1][0], tid);
+      stage_store<B_KC>(sb, lds[cur ^ 1][1], tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + wave_n * 64 + j * 32 + l31;
+    const bool col_ok = col < g.N;
+    float csum = 0.f;
+    const float bv = (EPI == EPI_STORE && g.bias && col_ok) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!(col_ok && row < g.M)) continue;
+        float v = acc[i][j][r];
+        if (EPI == EPI_ATOMIC) {
+          atomicAdd(g.C + row * g.ldc + col, v);
+        } else {
+          v += bv;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask && !(g.mask[row * g.ldm + col] > 0.f)) v = 0.f;
+          g.C[row * g.ldc + col] = v;
+          csum += v;
+        }
+      }
+    }
+    if (EPI == EPI_STORE && g.colsum) {
+      csum += __shfl_xor(csum, 32, 64);  // the two lane halves hold different rows of the same column
+      if (h == 0 && col_ok) atomicAdd(g.colsum + col, csum);
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
+  const unsigned groups = (unsigned)((g.tiles_m + 7) / 8);
+  dim3 grid(groups * 8 * (unsigned)g.tiles_n, splits, 1);
+  hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI>), grid, dim3(256), 0, st, g);
+  FGS_LAUNCH_OK("fgs_gemm_f32");
+  return 0;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
+                         int64_t ldb, float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm,
+                         float *colsum, fgs_stream_t stream) {
+  FGS_REQUIRE(op >= 0 && op <= 2, FGS_E_INVALID, "fgs_gemm_f32: op=%d", op);
+  FGS_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31),
+              FGS_E_RANGE, "fgs_gemm_f32: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  if (M == 0 || N == 0) return 0;
+  if (K == 0 && op == FGS_GEMM_TN) return 0;
+  FGS_REQUIRE(A && B && C, FGS_E_INVALID, "fgs_gemm_f32: null pointer");
+  FGS_REQUIRE(aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0, FGS_E_INVALID,
+              "fgs_gemm_f32: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  // vector loads walk K (K-contiguous operands) or the output index (index-contiguous operands) 4 at a time
+  if (op == FGS_GEMM_NT) FGS_REQUIRE(K % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NT): K must be a multiple of 4");
+  if (op == FGS_GEMM_NN) FGS_REQUIRE(K % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NN): K and N must be multiples of 4");
+  if (op == FGS_GEMM_TN) FGS_REQUIRE(M % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(TN): M and N must be multiples of 4");
+
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.colsum = colsum; g.k_per_split = 0;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  hipStream_t st = fgs_s(stream);
+  switch (op) {
+    case FGS_GEMM_NT: return launch<true, true, EPI_STORE>(g, 1, st);
+    case FGS_GEMM_NN: return launch<true, false, EPI_STORE>(g, 1, st);
+    default: {
+      // split the long reduction so that ~4 workgroups per CU are in flight (256 CUs)
+      const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
+      int64_t want = (1024 + tiles - 1) / tiles;
+      const int64_t chunks = (K + BK - 1) / BK;
+      if (want > chunks) want = chunks;
+      if (want < 1) want = 1;
+      g.k_per_split = ((chunks + want - 1) / want) * BK;
+      const unsigned splits = (unsigned)((K + g.k_per_split - 1) / g.k_per_split);
+      return launch<false, false, EPI_ATOMIC>(g, splits, st);
+    }
+  }
+}

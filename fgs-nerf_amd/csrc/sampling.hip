@@ -315,3 +315,13 @@ FGS_API int fgs_maskcache_lookup(const uint8_t *world, const float *xyz, const f
   FGS_LAUNCH_OK("fgs_maskcache_lookup");
   return 0;
 }
+
+// Exclusive prefix sum of int64 counts: out[0..n] (out[n] = total).  Used between the fused march kernel and the
+// survivor kernels (per-ray survivor counts -> segment offsets), the same scan sample_count uses.
+FGS_API int fgs_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_exclusive_scan_i64: n=%lld", (long long)n);
+  FGS_REQUIRE(out && (n == 0 || in), FGS_E_INVALID, "fgs_exclusive_scan_i64: null pointer");
+  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), in, n, out);
+  FGS_LAUNCH_OK("fgs_exclusive_scan_i64");
+  return 0;
+}

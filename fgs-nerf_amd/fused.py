@@ -1,9 +1,421 @@
-"""Fused MI355X render path (wave-per-ray march, survivor features, fp32-MFMA MLP, compositing).
+"""Fused MI355X path for ``nerf.forward_fine`` (model/nerf.py:776-941): one autograd node, ~25 HIP launches.
 
-Placeholder until the fused kernels land: ``supports`` answers False so every model uses the
-operator-at-a-time HIP path of render.py.
+Forward:   march (1 wave / ray: sampling + SDF + 6-tap gradient + NeuS alpha + exact early-terminating scan)
+           -> scan of per-ray survivor counts -> ONE device->host read (M_s, needed to size the result tensors the
+           reference API returns) -> survivor compaction -> feature kernels (k0 trilerp, 24 SDF taps, encodings,
+           reflection) writing straight into the MLP operand buffers -> fp32-MFMA GEMM chain (rgbnet, refnet) ->
+           3-wide head + sigmoid -> per-ray compositing.
+Backward:  compositing -> head -> GEMM chain (data + split-K weight gradients, bias gradients in the epilogues)
+           -> feature scatter (k0.grad, sdf.grad) -> march backward (alpha2weight + NeuS alpha, sdf.grad scatter).
+
+The reference touches the host ~10 times per forward (`.item()`, seven boolean-mask compactions, `unique`); this
+path does it once.  Configurations outside ``supports`` run the operator-at-a-time kernels of render.py.
 """
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import fused_ops as fo
+from ._lib import call, ptr, stream
+from .ops import grid_strides
+
+F32, I64, I32 = torch.float32, torch.int64, torch.int32
+
+# event pairs recorded around the dominant kernel family (the MLP GEMMs) when profiling is switched on by bench.py
+PROFILE = {"enabled": False, "gemm_events": [], "gemm_flops": 0.0}
 
 
 def supports(model) -> bool:
-    return False
+    """Configurations the fused kernels cover (everything the shipped fine-stage configs use)."""
+    from .nerf import mlp_layers
+    if model.stage != 'fine' or model.rgbnet is None or model.smooth_sdf or model.s_learn:
+        return False
+    if not (model.fast_color_thres > 0) or not model.use_viewdir:
+        return False
+    if model.k_grad_feat != (1.0,) or len(model.k_sdf_feat) != 0:
+        return False
+    disp = sorted(set(model.grad_feat + model.k_grad_feat))
+    if disp != sorted(set(model.sdf_feat + model.k_sdf_feat)) or len(disp) > 5:
+        return False
+    rl, fl = mlp_layers(model.rgbnet), mlp_layers(model.refnet)
+    x0_cols = (model.k0_dim + (3 + 6 * len(model.posfreq)) + (3 + 6 * len(model.viewfreq)) + int(model.center_sdf)
+               + 9 * len(disp) + 3)
+    if x0_cols != rl[0].in_features or rl[-1].out_features + 3 + 6 * len(model.reffreq) != fl[0].in_features:
+        return False
+    rw, fw = rl[0].out_features, fl[0].out_features
+    if rw % 4 or fw % 4 or fw > 256 or len(rl) < 2 or len(fl) < 2 or fl[-1].out_features != 3:
+        return False
+    if any(l.out_features != rw for l in rl) or any(l.out_features != fw for l in fl[:-1]):
+        return False
+    g = model.sdf.grid
+    return g.is_cuda and g.is_contiguous() and model.k0.grid.is_cuda
+
+
+def _f32(x) -> float:
+    """The fp32 value of a python / tensor scalar, as a python float."""
+    return float(torch.as_tensor(x, dtype=F32))
+
+
+class _Geom:
+    """Host copies of the model geometry (cached on the model; refreshed when the grid is rescaled)."""
+
+    def __init__(self, model):
+        self.lo = model.xyz_min.detach().cpu().float().numpy().copy()
+        self.hi = model.xyz_max.detach().cpu().float().numpy().copy()
+        self.lo_c = (ctypes.c_float * 3)(*self.lo.tolist())
+        self.hi_c = (ctypes.c_float * 3)(*self.hi.tolist())
+        self.X, self.Y, self.Z = (int(s) for s in model.sdf.grid.shape[2:])
+        self.voxel_size = _f32(model.voxel_size)
+        self.diag = float(np.linalg.norm(self.hi.astype(np.float64) - self.lo.astype(np.float64)))
+        self.mask = None
+        if model.mask_cache is not None:
+            mc = model.mask_cache
+            mlo = mc.xyz_min.detach().cpu().float().numpy()
+            mhi = mc.xyz_max.detach().cpu().float().numpy()
+            self.mask = ((ctypes.c_float * 3)(*mlo.tolist()), (ctypes.c_float * 3)(*mhi.tolist()),
+                         tuple(int(s) for s in mc.sdf_mask.shape[2:]), float(mc.mask_cache_thres))
+
+
+def _geom(model) -> _Geom:
+    key = (tuple(model.sdf.grid.shape), id(model.mask_cache))
+    g = getattr(model, '_fused_geom', None)
+    if g is None or getattr(model, '_fused_geom_key', None) != key:
+        g = _Geom(model)
+        model._fused_geom, model._fused_geom_key = g, key
+    return g
+
+
+def _layout(model, geom):
+    """(layout_i ctypes int[11], displace ctypes float[K], ldx0, ldz, x0_cols) for csrc/features.hip fill_layout."""
+    from .nerf import mlp_layers
+    disp = sorted(set(model.grad_feat + model.k_grad_feat))   # model/nerf.py:843-851
+    K = len(disp)
+    rw = mlp_layers(model.rgbnet)[0].out_features
+    x0_cols = mlp_layers(model.rgbnet)[0].in_features
+    ldx0 = (x0_cols + 3) // 4 * 4
+    z_cols = mlp_layers(model.refnet)[0].in_features
+    ldz = (z_cols + 3) // 4 * 4
+    li = [model.k0_dim, len(model.posfreq), len(model.viewfreq), len(model.reffreq), int(model.use_viewdir),
+          int(model.center_sdf), int(model.use_grad_norm), K, ldx0, rw, ldz]
+    expect = model.k0_dim + (3 + 6 * li[1]) + (3 + 6 * li[2]) + int(model.center_sdf) + 9 * K + 3
+    assert expect == x0_cols and rw + 3 + 6 * li[3] == z_cols, (expect, x0_cols, z_cols)
+    return (ctypes.c_int * 11)(*li), (ctypes.c_float * max(K, 1))(*(disp or [0.0])), ldx0, ldz, x0_cols
+
+
+class _Run:
+    """Everything one forward produced that the backward needs (plain attribute bag)."""
+
+
+def _gemm(op, A, B, C, M, N, K, **kw):
+    if PROFILE["enabled"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fo.gemm(op, A, B, C, M, N, K, **kw)
+        e1.record()
+        PROFILE["gemm_events"].append((e0, e1))
+        PROFILE["gemm_flops"] += 2.0 * M * N * K
+    else:
+        fo.gemm(op, A, B, C, M, N, K, **kw)
+
+
+class _FusedFine(torch.autograd.Function):
+    """inputs: sdf grid, k0 grid, then (weight, bias) of every rgbnet and refnet Linear; `run` carries the rest."""
+
+    @staticmethod
+    def forward(ctx, run, sdf_grid, k0_grid, *mlp):
+        dev = sdf_grid.device
+        g, N, st = run.geom, run.n_rays, stream()
+        ms = run.max_steps
+        rec = N * ms
+        ws = run.workspace
+        # 1. march
+        call("fgs_march_fine_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+             g.voxel_size, run.near, 1e9, run.stepdist, ptr(sdf_grid), run.dist, run.inv_s, run.thres,
+             ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
+             g.mask[3] if g.mask else 0.0, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']),
+             ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']), ptr(ws['n_alive']),
+             ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
+        call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        M = int(ws['surv_off'][N].item())          # the one host read of the step
+        run.M = M
+        # 2. survivors
+        ray_id = torch.empty(M, dtype=I64, device=dev)
+        step_id = torch.empty(M, dtype=I64, device=dev)
+        rec_idx = torch.empty(M, dtype=I32, device=dev)
+        weights = torch.empty(M, dtype=F32, device=dev)
+        alpha = torch.empty(M, dtype=F32, device=dev)
+        sdf = torch.empty(M, dtype=F32, device=dev)
+        gradient = torch.empty(M, 3, dtype=F32, device=dev)
+        pts = torch.empty(M, 3, dtype=F32, device=dev)
+        call("fgs_surv_compact", N, M, ptr(ws['surv_off']), ms, ptr(ws['surv_slot']), ptr(ws['a_step']), ptr(ws['a_alpha']),
+             ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(run.rays_o), ptr(run.rays_d), g.lo_c, g.hi_c,
+             g.X, g.Y, g.Z, run.near, 1e9, run.stepdist, ptr(ray_id), ptr(step_id), ptr(rec_idx), ptr(weights), ptr(alpha),
+             ptr(sdf), ptr(gradient), ptr(pts), st)
+        # 3. features
+        ldx0, ldz = run.ldx0, run.ldz
+        X0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+        Z = torch.empty(M, ldz, dtype=F32, device=dev)
+        normal = torch.empty(M, 3, dtype=F32, device=dev)
+        kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
+        call("fgs_feat_fine_fwd", M, ptr(ray_id), ptr(pts), ptr(sdf), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c,
+             g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
+             ptr(X0), ptr(Z), ptr(normal), st)
+        # 4. MLPs.  First-layer weights are copied into K-padded operands (their row length is not a multiple of 4).
+        n_rgb, n_ref = run.n_rgb, run.n_ref
+        rgb_w = [mlp[2 * i] for i in range(n_rgb)]
+        rgb_b = [mlp[2 * i + 1] for i in range(n_rgb)]
+        ref_w = [mlp[2 * (n_rgb + i)] for i in range(n_ref)]
+        ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
+        rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
+        W0p = torch.zeros(rw, ldx0, dtype=F32, device=dev)
+        W0p[:, :rgb_w[0].shape[1]].copy_(rgb_w[0].detach())
+        V0p = torch.zeros(fw, ldz, dtype=F32, device=dev)
+        V0p[:, :ref_w[0].shape[1]].copy_(ref_w[0].detach())
+        acts_rgb = [X0]                                    # input of each rgbnet layer
+        a = X0
+        for i in range(n_rgb):
+            last = i == n_rgb - 1
+            out = Z if last else torch.empty(M, rw, dtype=F32, device=dev)   # last layer writes Z[:, :rw] (no ReLU)
+            B = W0p if i == 0 else rgb_w[i].detach()
+            _gemm(fo.GEMM_NT, a, B, out, M, rw, a.shape[1] if i else ldx0, bias=rgb_b[i].detach(), relu=not last)
+            a = out
+            if not last:
+                acts_rgb.append(out)
+        acts_ref = [Z]                                     # input of each refnet layer
+        a = Z
+        for i in range(n_ref - 1):
+            out = torch.empty(M, fw, dtype=F32, device=dev)
+            B = V0p if i == 0 else ref_w[i].detach()
+            _gemm(fo.GEMM_NT, a, B, out, M, fw, ldz if i == 0 else fw, bias=ref_b[i].detach(), relu=True)
+            a = out
+            acts_ref.append(out)
+        rgb = torch.empty(M, 3, dtype=F32, device=dev)
+        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
+        # 5. compositing
+        rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
+        sigmoid_rgb = torch.empty(N, 3, dtype=F32, device=dev)
+        pre_rgb = torch.empty(N, 3, dtype=F32, device=dev)
+        pre_sig = torch.empty(N, 3, dtype=F32, device=dev)
+        normal_marched = torch.empty(N, 3, dtype=F32, device=dev) if run.render_grad else None
+        depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
+        call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
+             ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+        alphainv_last = ws['alphainv_last'].clone()
+
+        run.saved = dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
+                         acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig,
+                         alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ))
+        run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
+                          n_inbbox=ws['n_inbbox'])
+        ctx.run = run
+        ctx.save_for_backward(sdf_grid, k0_grid, *mlp)
+        ctx.mark_non_differentiable(ray_id, alpha, gradient)
+        return rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
+        run = ctx.run
+        sdf_grid, k0_grid, *mlp = ctx.saved_tensors
+        S, g, N, M, st = run.saved, run.geom, run.n_rays, run.M, stream()
+        ws = run.workspace
+        dev = sdf_grid.device
+        n_rgb, n_ref = run.n_rgb, run.n_ref
+        rgb_w = [mlp[2 * i] for i in range(n_rgb)]
+        ref_w = [mlp[2 * (n_rgb + i)] for i in range(n_ref)]
+        rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
+        ldx0, ldz = run.ldx0, run.ldz
+
+        def c(t):
+            return None if t is None else t.contiguous()
+        g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
+            c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
+
+        # 1. compositing
+        d_out = torch.empty(M, 3, dtype=F32, device=dev)
+        d_w = torch.empty(M, dtype=F32, device=dev)
+        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
+             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
+
+        # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised)
+        gw_rgb = [torch.zeros_like(w) for w in rgb_w]
+        gw_ref = [torch.zeros_like(w) for w in ref_w]
+        gb_rgb = [torch.zeros(w.shape[0], dtype=F32, device=dev) for w in rgb_w]
+        gb_ref = [torch.zeros(w.shape[0], dtype=F32, device=dev) for w in ref_w]
+        gW0p = torch.zeros(rw, ldx0, dtype=F32, device=dev)
+        gV0p = torch.zeros(fw, ldz, dtype=F32, device=dev)
+
+        # 2. head: d_out -> dY of refnet layer n_ref-2 (masked), dV_last, dc_last, bias grad of layer n_ref-2
+        acts_ref, acts_rgb = S['acts_ref'], S['acts_rgb']
+        a_last = acts_ref[n_ref - 1]
+        dY = torch.empty(M, fw, dtype=F32, device=dev)
+        call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_ref[-1]),
+             ptr(gb_ref[-1]), ptr(gb_ref[n_ref - 2]), st)
+        # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
+        for i in range(n_ref - 2, -1, -1):
+            a_in = acts_ref[i]                      # input of layer i: Z for i == 0
+            if i == 0:
+                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldz, M)
+                dZ = torch.empty(M, ldz, dtype=F32, device=dev)
+                # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
+                # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
+                cs = torch.zeros(ldz, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, S['V0p'], dZ, M, ldz, fw, colsum=cs)
+                gb_rgb[-1] = cs[:rw]
+            else:
+                _gemm(fo.GEMM_TN, dY, a_in, gw_ref[i], fw, fw, M)
+                d_in = torch.empty(M, fw, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, ref_w[i], d_in, M, fw, fw, mask=a_in, colsum=gb_ref[i - 1])
+                dY = d_in
+        gw_ref[0] = gV0p[:, :ref_w[0].shape[1]]
+        # 4. rgbnet layers n_rgb-1 .. 0 ; dY of the last layer is dZ[:, :rw] (a strided view, ld = ldz)
+        dY = dZ[:, :rw]
+        for i in range(n_rgb - 1, -1, -1):
+            a_in = acts_rgb[i]                      # X0 for i == 0
+            if i == 0:
+                _gemm(fo.GEMM_TN, dY, a_in, gW0p, rw, ldx0, M)
+                dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, S['W0p'], dX0, M, ldx0, rw)
+            else:
+                _gemm(fo.GEMM_TN, dY, a_in, gw_rgb[i], rw, rw, M)
+                d_in = torch.empty(M, rw, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, rgb_w[i], d_in, M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
+                dY = d_in
+        gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
+
+        # 5. features -> grids
+        grad_sdf = torch.zeros_like(sdf_grid)
+        grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+        g_sdf_s = torch.empty(M, dtype=F32, device=dev)
+        g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
+        ksC, ksX, ksY, ksZ = S['k0_strides']
+        call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
+             g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
+             ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
+        # 6. march backward
+        call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+             g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
+             ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
+             ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
+             ptr(g_grad_s), ptr(grad_sdf), st)
+
+        grads: List[Optional[torch.Tensor]] = [None, grad_sdf, grad_k0]
+        for i in range(n_rgb):
+            grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
+        for i in range(n_ref):
+            grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
+        return tuple(grads)
+
+
+def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tensor]:
+    """Per-(n_rays, max_steps) record arrays, cached on the model: no allocator traffic in the steady state."""
+    key = (n_rays, max_steps, str(dev))
+    cache = model.__dict__.setdefault('_fused_ws', {})
+    ws = cache.get(key)
+    if ws is None:
+        rec = n_rays * max_steps
+        ws = dict(a_step=torch.empty(rec, dtype=I32, device=dev), a_alpha=torch.empty(rec, dtype=F32, device=dev),
+                  a_T=torch.empty(rec, dtype=F32, device=dev), a_weight=torch.empty(rec, dtype=F32, device=dev),
+                  a_sdf=torch.empty(rec, dtype=F32, device=dev), a_grad=torch.empty(rec * 3, dtype=F32, device=dev),
+                  a_surv=torch.empty(rec, dtype=I32, device=dev), surv_slot=torch.empty(rec, dtype=I32, device=dev),
+                  n_alive=torch.empty(n_rays, dtype=I64, device=dev), n_surv=torch.empty(n_rays, dtype=I64, device=dev),
+                  n_inbbox=torch.empty(n_rays, dtype=I64, device=dev),
+                  surv_off=torch.empty(n_rays + 1, dtype=I64, device=dev),
+                  alphainv_last=torch.empty(n_rays, dtype=F32, device=dev))
+        cache.clear()            # keep one shape resident
+        cache[key] = ws
+    return ws
+
+
+class LazyResult(dict):
+    """ret_dict of forward_fine whose rarely used, expensive entries ('mask', 'mask_outbbox': per-sample masks over ALL
+    emitted samples, which the fused kernels never materialise) are computed on first access."""
+
+    def __init__(self, eager, lazy_fns):
+        super().__init__(eager)
+        self._lazy = dict(lazy_fns)
+        for k in self._lazy:
+            super().__setitem__(k, None)
+
+    def __getitem__(self, k):
+        if k in self._lazy:
+            super().__setitem__(k, self._lazy.pop(k)())
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
+def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
+    from .nerf import mlp_layers
+    dev = rays_o.device
+    run = _Run()
+    run.geom = _geom(model)
+    run.n_rays = N = len(rays_o)
+    run.rays_o, run.rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()
+    run.viewdirs = viewdirs.contiguous().float()
+    run.near = float(render_kwargs['near'])
+    stepsize = render_kwargs['stepsize']
+    # dist = stepsize * voxel_size in fp32 (model/nerf.py:795); stepdist (model/nerf.py:689) is the same value as a C float
+    run.dist = float(np.float32(stepsize) * np.float32(run.geom.voxel_size))
+    run.stepdist = run.dist
+    run.bg = float(render_kwargs['bg'])
+    run.thres = float(model.fast_color_thres)
+    is_train = global_step is not None
+    s_val = model._s_val_for(global_step, is_train)
+    # inv_s = torch.ones(1) / self.s_val: one fp32 division (model/nerf.py:522); done on the host, no device read
+    s32 = np.float32(s_val) if is_train else np.float32(getattr(model, '_s_val_host', model.s_start))
+    model._s_val_host = float(s32)
+    run.inv_s = float(np.float32(1.0) / s32)
+    run.max_steps = int(math.ceil(run.geom.diag / run.stepdist)) + 2
+    run.workspace = _workspace(model, N, run.max_steps, dev)
+    run.layout_i, run.displace, run.ldx0, run.ldz, _ = _layout(model, run.geom)
+    run.mask_grid = model.mask_cache.sdf_mask if model.mask_cache is not None else None
+    run.render_grad = bool(render_kwargs.get('render_grad', False))
+    run.render_depth = bool(render_kwargs.get('render_depth', False))
+    rl, fl = mlp_layers(model.rgbnet), mlp_layers(model.refnet)
+    run.n_rgb, run.n_ref = len(rl), len(fl)
+    mlp = []
+    for layer in rl + fl:
+        mlp += [layer.weight, layer.bias]
+    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
+        run, model.sdf.grid, model.k0.grid, *mlp)
+    ex = run.extras
+    depth = ex['depth']
+
+    def lazy_masks():
+        """The reference's per-sample masks, recomputed with the operator-at-a-time kernels only when asked for."""
+        with torch.no_grad():
+            _, _, _, mask_outbbox, _ = model.sample_ray(rays_o=rays_o, rays_d=rays_d, **render_kwargs)
+        return mask_outbbox
+
+    def lazy_mask():
+        with torch.no_grad():
+            res = model._forward_fine_composed(rays_o, rays_d, viewdirs, global_step, **render_kwargs)
+        return res['mask']
+
+    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id, 'viewdirs': run.viewdirs[ray_id],
+             'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
+             'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
+             'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
+             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox']}
+    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks})
+
+
+def roofline_report():
+    """Filled in by bench.py after a profiled run: achieved fp32 FLOP/s of the MLP GEMM family vs the gfx950 peak."""
+    ev = PROFILE["gemm_events"]
+    if not ev:
+        return None
+    ms = sum(e0.elapsed_time(e1) for e0, e1 in ev)
+    n = len(ev)
+    achieved = PROFILE["gemm_flops"] / (ms * 1e-3) / 1e12
+    peak = 157.3
+    return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32: rgbnet/refnet forward, data and weight gradients)",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "traffic": None}

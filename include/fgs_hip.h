@@ -155,6 +155,106 @@ int fgs_sdf_taps_bwd(float *grad_grid, int64_t X, int64_t Y, int64_t Z, const fl
                      const float *pts, int64_t M, const float *displace_host, int K, const float *grad_feat,
                      fgs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * Tiny-MLP products -- replace the nn.Linear / autograd SGEMMs of rgbnet and refnet
+ * (model/nerf.py:125-142,877,884,1009).  Exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32).
+ *   FGS_GEMM_NT  C[m,n]  = sum_k A[m,k] B[n,k] (+ bias[n]) (ReLU if relu)     forward:  A = X[M,K], B = W[N,K]
+ *   FGS_GEMM_NN  C[m,n]  = sum_k A[m,k] B[k,n], zeroed where mask[m,n] <= 0   dX:       A = dY[M,K], B = W[K,N]
+ *   FGS_GEMM_TN  C[m,n] += sum_k A[k,m] B[k,n]  (split-K, fp32 atomic adds)   dW:       A = dY[K,M], B = X[K,N]
+ * colsum (NT/NN, may be NULL): colsum[n] += sum_m C[m,n] after the epilogue (bias gradients).
+ * Operands 16-byte aligned, leading dimensions multiples of 4 floats; NT: K % 4 == 0; NN: K, N % 4 == 0;
+ * TN: M, N % 4 == 0.  M (NT/NN) and K (TN) -- the sample count -- are arbitrary.
+ * ------------------------------------------------------------------------------ */
+#define FGS_GEMM_NT 0
+#define FGS_GEMM_NN 1
+#define FGS_GEMM_TN 2
+int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
+                 float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,
+                 fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused fine-stage render path -- nerf.forward_fine (model/nerf.py:776-941) as a short kernel chain.
+ * Scene geometry is passed BY VALUE from the host (xyz_min/xyz_max HOST float[3], grid dims, voxel_size); device
+ * arrays are caller-allocated.  Record arrays are laid out [n_rays * max_steps] with
+ * max_steps >= ceil(|xyz_max - xyz_min| / stepdist) + 2 (no ray can emit more samples).
+ * ------------------------------------------------------------------------------ */
+
+/* out[0..n] = exclusive prefix sum of in[0..n) (out[n] = total); one workgroup, any n. */
+int fgs_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, fgs_stream_t stream);
+
+/* One wavefront per ray: sample_pts_on_rays + in-bbox / mask-cache tests + SDF trilerp + 6-tap gradient +
+ * NeuS alpha + `alpha > thres` + alpha2weight (exact sequential chain, early termination at T < 1e-3) +
+ * `weights > thres`  (model/nerf.py:780-833; render_utils_kernel.cu:11-242,576-605).
+ * Writes the "alive" records of each ray (alpha > thres, up to and including the terminating sample -- the
+ * [i_start, i_end) segment of the reference): a_step, a_alpha, a_T, a_weight, a_sdf, a_grad[3], a_surv (rank among the
+ * ray's survivors or -1), surv_slot (k-th survivor -> local alive index); per ray n_alive, n_surv, n_inbbox (in-bbox
+ * samples visited before termination) and alphainv_last.  mask_grid == NULL disables the mask cache. */
+int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                       const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float voxel_size,
+                       float near, float far, float stepdist, const float *sdf, float dist, float inv_s, float thres,
+                       const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
+                       int mZ, float mask_thres, int max_steps, int *a_step, float *a_alpha, float *a_T, float *a_weight,
+                       float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive, int64_t *n_surv,
+                       int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream);
+
+/* Survivor position t in [0, M_s) -> ray (binary search in surv_off) and the per-survivor arrays of the result
+ * dict: ray_id, step_id, weights, raw alpha, sdf, gradient[3], ray_pts[3]; rec_idx = local alive index. */
+int fgs_surv_compact(int64_t n_rays, int64_t n_surv_total, const int64_t *surv_off, int max_steps, const int *surv_slot,
+                     const int *a_step, const float *a_alpha, const float *a_weight, const float *a_sdf,
+                     const float *a_grad, const float *rays_o, const float *rays_d, const float *xyz_min_host,
+                     const float *xyz_max_host, int X, int Y, int Z, float near, float far, float stepdist,
+                     int64_t *ray_id, int64_t *step_id, int *rec_idx, float *weights, float *alpha, float *sdf,
+                     float *gradient, float *pts, fgs_stream_t stream);
+
+/* Backward of fgs_march_fine_fwd: alpha2weight backward (render_utils_kernel.cu:653-677) over the alive records,
+ * NeuS-alpha backward, plus the per-survivor gradients arriving through the feature path (g_sdf [M_s], g_gradient
+ * [M_s,3], may be NULL); scatter-adds into grad_sdf_grid [X,Y,Z] (not zeroed here). */
+int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                       const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float voxel_size,
+                       float near, float far, float stepdist, float dist, float inv_s, int max_steps, const int *a_step,
+                       const int *a_surv, const float *a_alpha, const float *a_T, const float *a_weight,
+                       const float *a_sdf, const float *a_grad, const int64_t *n_alive, const int64_t *surv_off,
+                       const float *alphainv_last, const float *g_weights, const float *g_last, const float *g_sdf,
+                       const float *g_gradient, float *grad_sdf_grid, fgs_stream_t stream);
+
+/* Per-survivor MLP inputs (model/nerf.py:835-883).  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq,
+ * use_viewdir, center_sdf, use_grad_norm, K, ldx0, off_ref, ldz}; displace_host = K sorted displacements (K <= 5).
+ * X0 [M, ldx0] receives torch.cat([k0, xyz_emb, viewdirs_emb, sdf, all_feat, all_grad, gradient]) (zero padded);
+ * Zbuf [M, ldz] receives the reflection encoding at columns [off_ref, off_ref + 3 + 6 n_reffreq) (zero padded above);
+ * normal_out [M,3].  k0 grid strides (ksC,ksX,ksY,ksZ) as in fgs_trilerp_fwd. */
+int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,
+                      const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z,
+                      float voxel_size, const int *layout_i, const float *displace_host, const float *sdf_grid,
+                      const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *X0, float *Zbuf,
+                      float *normal_out, fgs_stream_t stream);
+/* Backward: scatter-adds into sdf_grad_grid and k0_grad_grid, writes g_sdf [M] and g_gradient [M,3] for
+ * fgs_march_fine_bwd.  g_normal [M,3] (direct gradient on the `normal` output) may be NULL. */
+int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,
+                      const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z,
+                      float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
+                      const float *Zbuf, const float *dX0, const float *dZ, const float *g_normal, float *sdf_grad_grid,
+                      float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *g_sdf,
+                      float *g_gradient, fgs_stream_t stream);
+
+/* Last refnet Linear (W -> 3) + sigmoid (model/nerf.py:884): rgb[m,:] = sigmoid(R[m,:W] . V[3,W]^T + bias). */
+int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *bias, float *rgb,
+                 fgs_stream_t stream);
+/* d_out [M,3] (w.r.t. the pre-sigmoid output) -> dR = (d_out . V) * (R > 0), dV += d_out^T R, dbias += colsum(d_out),
+ * dR_colsum[W] += colsum(dR) (the bias gradient of the layer that produced R; may be NULL). */
+int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR, float *dV,
+                 float *dbias, float *dR_colsum, fgs_stream_t stream);
+
+/* The three segment_coo sums + background + clamp (model/nerf.py:888-903), optional normal_marched / depth
+ * (:905-920).  pre_rgb / pre_sig keep the un-clamped values for the backward pass. */
+int fgs_composite_fwd(int64_t n_rays, const int64_t *surv_off, const float *weights, const float *rgb, const float *normal,
+                      const int64_t *step_id, float bg, float dist, float *rgb_marched, float *sigmoid_rgb, float *pre_rgb,
+                      float *pre_sig, float *normal_marched, float *depth, fgs_stream_t stream);
+/* Gradients of the loss w.r.t. rgb_marched / sigmoid_rgb [n_rays,3], raw_rgb [M,3], weights [M] (each may be
+ * NULL) -> d_out [M,3] (pre-sigmoid head output) and d_w [M]. */
+int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, const float *rgb, const float *pre_rgb,
+                      const float *pre_sig, const float *g_rgb_marched, const float *g_sigmoid_rgb, const float *g_raw_rgb,
+                      const float *g_weights_direct, float bg, float *d_out, float *d_w, fgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
