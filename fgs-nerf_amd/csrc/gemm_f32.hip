@@ -17,6 +17,7 @@
 // 16 MFMAs per tile with no cross-lane movement.  Workgroup ids are dealt so that the column tiles of one
 // row tile land on the same XCD (ids b, b+8, ...) and share its L2.
 #include "fgs_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -114,22 +115,29 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 
   // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
   const int b = blockIdx.x;
-  const int grp = b / (8 * g.tiles_n);
-  const int within = b - grp * 8 * g.tiles_n;
-  const int tile_m = grp * 8 + (within & 7);
-  const int tile_n = within >> 3;
-  if (tile_m >= g.tiles_m) return;
+  int tile_m, tile_n;
+  int64_t k_begin = 0, k_end = g.K;
+  if (EPI == EPI_ATOMIC) {
+    // split-K: few output tiles, many K slices.  Consecutive ids (dealt round-robin over the 8 XCDs) take the
+    // tiles of one slice, so every XCD works and the 2-4 tiles sharing a slice of A / B run at the same time.
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int split = b / tiles, tile = b - split * tiles;
+    tile_m = tile % g.tiles_m;
+    tile_n = tile / g.tiles_m;
+    k_begin = (int64_t)split * g.k_per_split;
+    k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
+    if (k_begin >= k_end) return;
+  } else {
+    const int grp = b / (8 * g.tiles_n);
+    const int within = b - grp * 8 * g.tiles_n;
+    tile_m = grp * 8 + (within & 7);
+    tile_n = within >> 3;
+    if (tile_m >= g.tiles_m) return;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-
-  int64_t k_begin = 0, k_end = g.K;
-  if (EPI == EPI_ATOMIC) {
-    k_begin = (int64_t)blockIdx.y * g.k_per_split;
-    k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
-    if (k_begin >= k_end) return;
-  }
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -176,33 +184,74 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   }
 
   // ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
+  if (EPI == EPI_ATOMIC) {
+    // one atomic wave-instruction = two 128-byte row segments (the full-rate shape for global_atomic_add_f32)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t col = n0 + wave_n * 64 + j * 32 + l31;
-    const bool col_ok = col < g.N;
-    float csum = 0.f;
-    const float bv = (EPI == EPI_STORE && g.bias && col_ok) ? g.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wave_n * 64 + j * 32 + l31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!(col_ok && row < g.M)) continue;
-        float v = acc[i][j][r];
-        if (EPI == EPI_ATOMIC) {
-          atomicAdd(g.C + row * g.ldc + col, v);
-        } else {
-          v += bv;
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (g.mask && !(g.mask[row * g.ldm + col] > 0.f)) v = 0.f;
-          g.C[row * g.ldc + col] = v;
-          csum += v;
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (col < g.N && row < g.M) atomicAdd(g.C + row * g.ldc + col, acc[i][j][r]);
         }
-      }
     }
-    if (EPI == EPI_STORE && g.colsum) {
-      csum += __shfl_xor(csum, 32, 64);  // the two lane halves hold different rows of the same column
-      if (h == 0 && col_ok) atomicAdd(g.colsum + col, csum);
+    return;
+  }
+  // Stage the 128x128 tile through LDS (the K loop is done with it) so that bias / mask reads and the stores are
+  // 16-byte accesses over whole 512-byte row segments instead of 64 scalar stores per lane.
+  constexpr int LDC = 132;
+  float *ct = &lds[0][0][0];  // 128 * 132 floats = 67.6 KB <= the 73.7 KB image
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ct[(wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wave_n * 64 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  const int c4 = tid & 31;
+  const int64_t col = n0 + 4 * c4;
+  const bool col_ok = col < g.N;  // N % 4 == 0 on every path that reaches here
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && col_ok) bv = *reinterpret_cast<const float4 *>(g.bias + col);
+  float4 mk[16];
+  if (g.mask) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int64_t row = m0 + (tid >> 5) + 8 * p;
+      mk[p] = (col_ok && row < g.M) ? *reinterpret_cast<const float4 *>(g.mask + row * g.ldm + col) : make_float4(0, 0, 0, 0);
+    }
+  }
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int rl = (tid >> 5) + 8 * p;
+    const int64_t row = m0 + rl;
+    if (!(col_ok && row < g.M)) continue;
+    float4 v = *reinterpret_cast<const float4 *>(ct + rl * LDC + 4 * c4);
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (g.mask) {
+      if (!(mk[p].x > 0.f)) v.x = 0.f;
+      if (!(mk[p].y > 0.f)) v.y = 0.f;
+      if (!(mk[p].z > 0.f)) v.z = 0.f;
+      if (!(mk[p].w > 0.f)) v.w = 0.f;
+    }
+    *reinterpret_cast<float4 *>(g.C + row * g.ldc + col) = v;
+    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+  }
+  if (g.colsum) {  // 8 threads (tid >> 5) share a column quad: reduce through LDS, one atomic per column
+    __syncthreads();
+    float *red = ct;  // [8][128]
+    *reinterpret_cast<float4 *>(red + (tid >> 5) * 128 + 4 * c4) = cs;
+    __syncthreads();
+    if (tid < 128 && n0 + tid < g.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += red[q * 128 + tid];
+      atomicAdd(g.colsum + n0 + tid, s);
     }
   }
 }
@@ -210,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
   const unsigned groups = (unsigned)((g.tiles_m + 7) / 8);
-  dim3 grid(groups * 8 * (unsigned)g.tiles_n, splits, 1);
+  dim3 grid(EPI == EPI_ATOMIC ? (unsigned)(g.tiles_m * g.tiles_n) * splits : groups * 8 * (unsigned)g.tiles_n, 1, 1);
   hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI>), grid, dim3(256), 0, st, g);
   FGS_LAUNCH_OK("fgs_gemm_f32");
   return 0;
@@ -232,7 +281,10 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
   FGS_REQUIRE(aligned16(A) && aligned16(B) && (lda % 4) == 0 && (ldb % 4) == 0, FGS_E_INVALID,
               "fgs_gemm_f32: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
   // vector loads walk K (K-contiguous operands) or the output index (index-contiguous operands) 4 at a time
-  if (op == FGS_GEMM_NT) FGS_REQUIRE(K % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NT): K must be a multiple of 4");
+  if (op == FGS_GEMM_NT) FGS_REQUIRE(K % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NT): K and N must be multiples of 4");
+  if (op != FGS_GEMM_TN)
+    FGS_REQUIRE(aligned16(C) && (ldc % 4) == 0 && (!bias || aligned16(bias)) && (!mask || (aligned16(mask) && (ldm % 4) == 0)),
+                FGS_E_INVALID, "fgs_gemm_f32: C / bias / mask must be 16-byte aligned with leading dimensions multiple of 4");
   if (op == FGS_GEMM_NN) FGS_REQUIRE(K % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NN): K and N must be multiples of 4");
   if (op == FGS_GEMM_TN) FGS_REQUIRE(M % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(TN): M and N must be multiples of 4");
 
@@ -248,7 +300,9 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
     default: {
       // split the long reduction so that ~4 workgroups per CU are in flight (256 CUs)
       const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
-      int64_t want = (1024 + tiles - 1) / tiles;
+      // measured on MI355X at M_s = 64 K, 256x256 outputs: 256-512 workgroups 96 us, 128: 159 us, 2048: 147 us
+      static const int target_wgs = getenv("FGS_TN_WGS") ? atoi(getenv("FGS_TN_WGS")) : 512;
+      int64_t want = (target_wgs + tiles - 1) / tiles;
       const int64_t chunks = (K + BK - 1) / BK;
       if (want > chunks) want = chunks;
       if (want < 1) want = 1;
