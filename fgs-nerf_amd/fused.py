@@ -111,14 +111,15 @@ class _Run:
     """Everything one forward produced that the backward needs (plain attribute bag)."""
 
 
-def _gemm(op, A, B, C, M, N, K, **kw):
+def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
+    """`logical` = un-padded (M, N, K) of the product, for the algorithmic FLOP count of the roofline report."""
     if PROFILE["enabled"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fo.gemm(op, A, B, C, M, N, K, **kw)
         e1.record()
-        PROFILE["gemm_events"].append((e0, e1))
-        PROFILE["gemm_flops"] += 2.0 * M * N * K
+        lm, ln, lk = logical or (M, N, K)
+        PROFILE["gemm_events"].append((e0, e1, op, 2.0 * lm * ln * lk))
     else:
         fo.gemm(op, A, B, C, M, N, K, **kw)
 
@@ -182,7 +183,8 @@ class _FusedFine(torch.autograd.Function):
             last = i == n_rgb - 1
             out = Z if last else torch.empty(M, rw, dtype=F32, device=dev)   # last layer writes Z[:, :rw] (no ReLU)
             B = W0p if i == 0 else rgb_w[i].detach()
-            _gemm(fo.GEMM_NT, a, B, out, M, rw, a.shape[1] if i else ldx0, bias=rgb_b[i].detach(), relu=not last)
+            _gemm(fo.GEMM_NT, a, B, out, M, rw, a.shape[1] if i else ldx0, bias=rgb_b[i].detach(), relu=not last,
+                  logical=(M, rw, rgb_w[i].shape[1]))
             a = out
             if not last:
                 acts_rgb.append(out)
@@ -191,7 +193,8 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_ref - 1):
             out = torch.empty(M, fw, dtype=F32, device=dev)
             B = V0p if i == 0 else ref_w[i].detach()
-            _gemm(fo.GEMM_NT, a, B, out, M, fw, ldz if i == 0 else fw, bias=ref_b[i].detach(), relu=True)
+            _gemm(fo.GEMM_NT, a, B, out, M, fw, ldz if i == 0 else fw, bias=ref_b[i].detach(), relu=True,
+                  logical=(M, fw, ref_w[i].shape[1]))
             a = out
             acts_ref.append(out)
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
@@ -260,12 +263,12 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_ref - 2, -1, -1):
             a_in = acts_ref[i]                      # input of layer i: Z for i == 0
             if i == 0:
-                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldz, M)
+                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldz, M, logical=(fw, ref_w[0].shape[1], M))
                 dZ = torch.empty(M, ldz, dtype=F32, device=dev)
                 # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
                 # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
                 cs = torch.zeros(ldz, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, S['V0p'], dZ, M, ldz, fw, colsum=cs)
+                _gemm(fo.GEMM_NN, dY, S['V0p'], dZ, M, ldz, fw, colsum=cs, logical=(M, ref_w[0].shape[1], fw))
                 gb_rgb[-1] = cs[:rw]
             else:
                 _gemm(fo.GEMM_TN, dY, a_in, gw_ref[i], fw, fw, M)
@@ -278,9 +281,9 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_rgb - 1, -1, -1):
             a_in = acts_rgb[i]                      # X0 for i == 0
             if i == 0:
-                _gemm(fo.GEMM_TN, dY, a_in, gW0p, rw, ldx0, M)
+                _gemm(fo.GEMM_TN, dY, a_in, gW0p, rw, ldx0, M, logical=(rw, rgb_w[0].shape[1], M))
                 dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, S['W0p'], dX0, M, ldx0, rw)
+                _gemm(fo.GEMM_NN, dY, S['W0p'], dX0, M, ldx0, rw, logical=(M, rgb_w[0].shape[1], rw))
             else:
                 _gemm(fo.GEMM_TN, dY, a_in, gw_rgb[i], rw, rw, M)
                 d_in = torch.empty(M, rw, dtype=F32, device=dev)
@@ -408,14 +411,29 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
 
 
 def roofline_report():
-    """Filled in by bench.py after a profiled run: achieved fp32 FLOP/s of the MLP GEMM family vs the gfx950 peak."""
+    """Achieved fp32 FLOP/s of the dominant kernel (the k_gemm template: MLP forward, data- and weight-gradient products)
+    from the HIP events bench.py had recorded around every launch in its timed region, against the gfx950 fp32
+    matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD)."""
     ev = PROFILE["gemm_events"]
     if not ev:
         return None
-    ms = sum(e0.elapsed_time(e1) for e0, e1 in ev)
-    n = len(ev)
-    achieved = PROFILE["gemm_flops"] / (ms * 1e-3) / 1e12
+    names = {fo.GEMM_NT: "k_gemm<true,true,0> (forward)", fo.GEMM_NN: "k_gemm<true,false,0> (data grad)",
+             fo.GEMM_TN: "k_gemm<false,false,1> (weight grad)"}
+    per = {}
+    tot_ms, tot_fl = 0.0, 0.0
+    for e0, e1, op, fl in ev:
+        ms = e0.elapsed_time(e1)
+        d = per.setdefault(names[op], [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += ms
+        d[2] += fl
+        tot_ms += ms
+        tot_fl += fl
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = 157.3
-    return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32: rgbnet/refnet forward, data and weight gradients)",
+    return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32; rgbnet/refnet forward, data-grad, weight-grad)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "traffic": None}
+            "traffic": None, "launches": len(ev), "avg_launch_us": round(tot_ms * 1e3 / len(ev), 2),
+            "algorithmic_gflop_per_launch": round(tot_fl / len(ev) / 1e9, 3),
+            "variants": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
+                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()}}
