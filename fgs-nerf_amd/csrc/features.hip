@@ -89,8 +89,30 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_fwd(SurvArgs S, const f
   if (row_ok && j < 3 * K) X0[m * S.L.ldx0 + S.L.off_hgrad + j] = g;
 }
 
+constexpr int BRICK = 8;  // voxels per side of the per-survivor accumulation brick: floor(centre) - 3 .. + 4
+
+// trilinear scatter of `go` into the LDS brick (origin bx0,by0,bz0); a corner outside the brick (cannot happen for
+// displacements <= 2 voxels, kept for safety) goes straight to global memory
+__device__ __forceinline__ void brick_scatter(float *brick, int bx0, int by0, int bz0, float *__restrict__ grid,
+                                              const GridDesc &d, const TriCorners &t, float go) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = t.x0 + (k >> 2), y = t.y0 + ((k >> 1) & 1), z = t.z0 + (k & 1);
+    if (!(fgs_in(x, (int)d.X) && fgs_in(y, (int)d.Y) && fgs_in(z, (int)d.Z))) continue;
+    const int rx = x - bx0, ry = y - by0, rz = z - bz0;
+    if (fgs_in(rx, BRICK) && fgs_in(ry, BRICK) && fgs_in(rz, BRICK))
+      atomicAdd(brick + (rx * BRICK + ry) * BRICK + rz, t.w[k] * go);
+    else
+      atomicAdd(grid + x * d.sX + y * d.sY + z * d.sZ, t.w[k] * go);
+  }
+}
+
+// Scatter of every sdf.grad contribution of the survivors: hierarchical taps (dX0 columns) plus, when tot_sdf /
+// tot_grad are given, the centre lookup and +/-1 taps whose gradients k_march_fine_bwd accumulated per survivor.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const float *__restrict__ X0,
                                                              const float *__restrict__ dX0,
+                                                             const float *__restrict__ tot_sdf,
+                                                             const float *__restrict__ tot_grad,
                                                              float *__restrict__ sdf_grad_grid) {
   const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
@@ -123,13 +145,55 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
     dg = dy / (r + 1e-5f);
     if (r > 0.f) dg -= dot / (r * (r + 1e-5f) * (r + 1e-5f)) * g_raw;
   }
-  const float coef = (j < 3 * K) ? (dg / S.geom.voxel_size) / diff : 0.f;
+  const float coef = (j < 3 * K && K > 0) ? (dg / S.geom.voxel_size) / diff : 0.f;
   // back to the tap lanes: tap (pair, k) takes +/- coef of axis pair>>1
   const int pair = (j < 6 * K) ? j / K : 0, kk = (j < 6 * K) ? j % K : 0;
   const float c_axis = group_shfl(coef, (pair >> 1) * K + kk);
+
+  // ---- combine everything this survivor adds to sdf.grad in an 8x8x8 LDS brick, then flush row-wise ----------------
+  // Memory-side float atomics are priced per 64-byte line per wave-instruction (MI355X_MICROARCH.md, global float
+  // atomics): the ~30 trilinear footprints of one survivor (24 hierarchical taps, the centre lookup and its six
+  // +/-1 taps) overlap heavily, so they are summed on chip and leave as ~30 line requests instead of ~250.
+  __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
+  float *brick = brick_all[threadIdx.x >> 5];
+  int bx0 = 0, by0 = 0, bz0 = 0;
+  PointIdx pc = {0.f, 0.f, 0.f};
+  if (row_ok) {
+    pc = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
+    bx0 = (int)fgs_safe_floor(pc.fx) - 3;
+    by0 = (int)fgs_safe_floor(pc.fy) - 3;
+    bz0 = (int)fgs_safe_floor(pc.fz) - 3;
+  }
+  for (int e = j; e < BRICK * BRICK * BRICK; e += 32) brick[e] = 0.f;
+  __syncthreads();
   if (tap_lane) {
     const float total = d_f + ((pair & 1) ? c_axis : -c_axis);
-    if (total != 0.f) fgs_tri_scatter(sdf_grad_grid, gd, 0, fgs_tri_setup(tp.fx, tp.fy, tp.fz), total);
+    if (total != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tp.fx, tp.fy, tp.fz), total);
+  }
+  if (row_ok && tot_sdf && j >= 24 && j < 31) {
+    // lane 24: centre lookup (d sdf); lanes 25..30: the six +/-1 voxel taps of the finite-difference gradient
+    if (j == 24) {
+      const float g = tot_sdf[m];
+      if (g != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(pc.fx, pc.fy, pc.fz), g);
+    } else {
+      const int pr = j - 25, ax = pr >> 1;                       // ax: 0 -> z, 1 -> y, 2 -> x
+      const float dgax = tot_grad[3 * m + (2 - ax)];
+      if (dgax != 0.f) {
+        const TapPoint tm = fgs_tap_point(pc, gd, 2 * ax, 1.0f), tq = fgs_tap_point(pc, gd, 2 * ax + 1, 1.0f);
+        const float cf = (dgax / S.geom.voxel_size) / (tq.clamped - tm.clamped);
+        const TapPoint &tt = (pr & 1) ? tq : tm;
+        brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tt.fx, tt.fy, tt.fz), (pr & 1) ? cf : -cf);
+      }
+    }
+  }
+  __syncthreads();
+  if (row_ok) {
+    for (int e = j; e < BRICK * BRICK * BRICK; e += 32) {  // 8 consecutive lanes = 8 consecutive z of one (x,y) row
+      const float v = brick[e];
+      if (v == 0.f) continue;
+      const int x = bx0 + (e >> 6), y = by0 + ((e >> 3) & 7), z = bz0 + (e & 7);
+      atomicAdd(sdf_grad_grid + (int64_t)x * gd.sX + (int64_t)y * gd.sY + z, v);  // nonzero entries are in-volume
+    }
   }
 }
 
@@ -284,6 +348,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_head_fwd(const float *__restrict_
   }
 }
 
+constexpr int HEAD_ILP = 4;
 // d_out [M,3] -> dR = (d_out . V4) * (R > 0) ; dV4 += d_out^T R ; dc4 += colsum(d_out) ; dR_colsum += colsum(dR)
 __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
                                                         const float *__restrict__ V, const float *__restrict__ d_out,
@@ -301,43 +366,64 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict_
   }
   float bsum[3] = {0.f, 0.f, 0.f};
   float4 osum = make_float4(0, 0, 0, 0);
-  for (int64_t m = wave; m < M; m += n_waves) {
-    const float d0 = d_out[3 * m], d1 = d_out[3 * m + 1], d2 = d_out[3 * m + 2];
-    bsum[0] += d0; bsum[1] += d1; bsum[2] += d2;
-    if (!col_ok) continue;
-    const float4 x = *reinterpret_cast<const float4 *>(R + m * ldr + 4 * lane);
-    float4 o;
-    o.x = (x.x > 0.f) ? (d0 * w[0].x + d1 * w[1].x) + d2 * w[2].x : 0.f;
-    o.y = (x.y > 0.f) ? (d0 * w[0].y + d1 * w[1].y) + d2 * w[2].y : 0.f;
-    o.z = (x.z > 0.f) ? (d0 * w[0].z + d1 * w[1].z) + d2 * w[2].z : 0.f;
-    o.w = (x.w > 0.f) ? (d0 * w[0].w + d1 * w[1].w) + d2 * w[2].w : 0.f;
-    *reinterpret_cast<float4 *>(dR + m * ldr + 4 * lane) = o;
-    osum.x += o.x; osum.y += o.y; osum.z += o.z; osum.w += o.w;
-    const float dd[3] = {d0, d1, d2};
+  // each wave owns a contiguous run of rows and keeps HEAD_ILP row loads in flight
+  const int64_t per = (M + n_waves - 1) / n_waves;
+  const int64_t m_lo = wave * per, m_hi = (m_lo + per < M) ? m_lo + per : M;
+  for (int64_t mb = m_lo; mb < m_hi; mb += HEAD_ILP) {
+    float4 x[HEAD_ILP];
+    float dd[HEAD_ILP][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      acc[c].x = fmaf(dd[c], x.x, acc[c].x);
-      acc[c].y = fmaf(dd[c], x.y, acc[c].y);
-      acc[c].z = fmaf(dd[c], x.z, acc[c].z);
-      acc[c].w = fmaf(dd[c], x.w, acc[c].w);
+    for (int u = 0; u < HEAD_ILP; ++u) {
+      const int64_t m = mb + u;
+      const bool ok = m < m_hi;
+      x[u] = (ok && col_ok) ? *reinterpret_cast<const float4 *>(R + m * ldr + 4 * lane) : make_float4(0, 0, 0, 0);
+      dd[u][0] = ok ? d_out[3 * m] : 0.f;
+      dd[u][1] = ok ? d_out[3 * m + 1] : 0.f;
+      dd[u][2] = ok ? d_out[3 * m + 2] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < HEAD_ILP; ++u) {
+      const int64_t m = mb + u;
+      if (m >= m_hi) continue;
+      const float d0 = dd[u][0], d1 = dd[u][1], d2 = dd[u][2];
+      bsum[0] += d0; bsum[1] += d1; bsum[2] += d2;
+      if (!col_ok) continue;
+      float4 o;
+      o.x = (x[u].x > 0.f) ? (d0 * w[0].x + d1 * w[1].x) + d2 * w[2].x : 0.f;
+      o.y = (x[u].y > 0.f) ? (d0 * w[0].y + d1 * w[1].y) + d2 * w[2].y : 0.f;
+      o.z = (x[u].z > 0.f) ? (d0 * w[0].z + d1 * w[1].z) + d2 * w[2].z : 0.f;
+      o.w = (x[u].w > 0.f) ? (d0 * w[0].w + d1 * w[1].w) + d2 * w[2].w : 0.f;
+      *reinterpret_cast<float4 *>(dR + m * ldr + 4 * lane) = o;
+      osum.x += o.x; osum.y += o.y; osum.z += o.z; osum.w += o.w;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc[c].x = fmaf(dd[u][c], x[u].x, acc[c].x);
+        acc[c].y = fmaf(dd[u][c], x[u].y, acc[c].y);
+        acc[c].z = fmaf(dd[u][c], x[u].z, acc[c].z);
+        acc[c].w = fmaf(dd[u][c], x[u].w, acc[c].w);
+      }
     }
   }
+  // block reduction of the 16 per-lane partial sums (3x4 dV + 4 colsum) over the 4 waves, then one atomic each
+  __shared__ float red[FGS_BLOCK / FGS_WAVE][16][FGS_WAVE];
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    red[wv][4 * c + 0][lane] = acc[c].x; red[wv][4 * c + 1][lane] = acc[c].y;
+    red[wv][4 * c + 2][lane] = acc[c].z; red[wv][4 * c + 3][lane] = acc[c].w;
+  }
+  red[wv][12][lane] = osum.x; red[wv][13][lane] = osum.y; red[wv][14][lane] = osum.z; red[wv][15][lane] = osum.w;
+  __syncthreads();
   if (col_ok) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      atomicAdd(dV + c * W + 4 * lane + 0, acc[c].x);
-      atomicAdd(dV + c * W + 4 * lane + 1, acc[c].y);
-      atomicAdd(dV + c * W + 4 * lane + 2, acc[c].z);
-      atomicAdd(dV + c * W + 4 * lane + 3, acc[c].w);
-    }
-    if (dR_colsum) {
-      atomicAdd(dR_colsum + 4 * lane + 0, osum.x);
-      atomicAdd(dR_colsum + 4 * lane + 1, osum.y);
-      atomicAdd(dR_colsum + 4 * lane + 2, osum.z);
-      atomicAdd(dR_colsum + 4 * lane + 3, osum.w);
+    for (int q = 0; q < 4; ++q) {
+      const int v = wv * 4 + q;  // this wave finishes values 4*wv .. 4*wv+3 for column quad `lane`
+      const float s = (red[0][v][lane] + red[1][v][lane]) + (red[2][v][lane] + red[3][v][lane]);
+      if (v < 12) atomicAdd(dV + (v >> 2) * W + 4 * lane + (v & 3), s);
+      else if (dR_colsum) atomicAdd(dR_colsum + 4 * lane + (v - 12), s);
     }
   }
-  if (lane < 3) atomicAdd(dbias + lane, bsum[lane]);  // every lane walked the same rows
+  if (lane < 3) atomicAdd(dbias + lane, bsum[lane]);  // every lane of the wave walked the same rows
 }
 
 // -------------------------------------------------------------------------------------------- per-ray compositing
@@ -517,13 +603,28 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
-  if (S.L.K > 0) {
-    hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, sdf_grad_grid);
-    FGS_LAUNCH_OK("fgs_feat_fine_bwd/taps");
-  }
   hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
                      g_gradient);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/enc");
+  (void)sdf_grad_grid;  // the sdf.grad scatter of the survivors is fgs_sdf_scatter_surv (after fgs_march_fine_bwd)
+  return 0;
+}
+
+FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_min_host, const float *xyz_max_host, int X,
+                                 int Y, int Z, float voxel_size, const int *layout_i, const float *displace_host,
+                                 const float *X0, const float *dX0, const float *tot_sdf, const float *tot_grad,
+                                 float *sdf_grad_grid, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_sdf_scatter_surv: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(pts && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && sdf_grad_grid && (!tot_sdf == !tot_grad),
+              FGS_E_INVALID, "fgs_sdf_scatter_surv: null pointer");
+  SurvArgs S;
+  S.M = M; S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
+  S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
+  if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
+                     tot_grad, sdf_grad_grid);
+  FGS_LAUNCH_OK("fgs_sdf_scatter_surv");
   return 0;
 }
 
@@ -546,8 +647,8 @@ FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const fl
               "fgs_head_bwd: M=%lld W=%d ldr=%lld", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
   FGS_REQUIRE(R && V && d_out && dR && dV && dbias, FGS_E_INVALID, "fgs_head_bwd: null pointer");
-  const int64_t want = (M + 3) / 4;
-  const unsigned blocks = (unsigned)(want < 512 ? want : 512);
+  const int64_t want = (M + 63) / 64;  // ~16 rows per wave
+  const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
   hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
                      dR_colsum);
   FGS_LAUNCH_OK("fgs_head_bwd");

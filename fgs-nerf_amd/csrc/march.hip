@@ -236,6 +236,7 @@ struct MarchBwdArgs {
   const float *g_sdf;       // [M_s] from the feature path (center sdf), or null
   const float *g_gradient;  // [M_s,3] from the feature path (normal, reflection, gradient feature), or null
   float *grad_sdf_grid;     // [X,Y,Z] accumulated with atomics
+  float *tot_sdf, *tot_grad;  // [M_s], [M_s,3]: if non-null, survivors' totals are written here instead of scattered
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
@@ -303,6 +304,13 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
         dgx += A.g_gradient[3 * (s_off + rank) + 0];
         dgy += A.g_gradient[3 * (s_off + rank) + 1];
         dgz += A.g_gradient[3 * (s_off + rank) + 2];
+      }
+      if (A.tot_sdf) {  // survivors: hand the totals to fgs_sdf_scatter_surv, which combines them with the 24 taps on chip
+        A.tot_sdf[s_off + rank] = d_sdf;
+        A.tot_grad[3 * (s_off + rank) + 0] = dgx;
+        A.tot_grad[3 * (s_off + rank) + 1] = dgy;
+        A.tot_grad[3 * (s_off + rank) + 2] = dgz;
+        continue;
       }
     }
     // scatter: sdf trilerp corners, then the six +/-1 voxel taps of the finite-difference gradient
@@ -398,7 +406,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
                                const float *a_weight, const float *a_sdf, const float *a_grad, const int64_t *n_alive,
                                const int64_t *surv_off, const float *alphainv_last, const float *g_weights,
                                const float *g_last, const float *g_sdf, const float *g_gradient, float *grad_sdf_grid,
-                               fgs_stream_t stream) {
+                               float *tot_sdf, float *tot_grad, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_fine_bwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_surv && a_alpha && a_T && a_weight &&
@@ -411,6 +419,8 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
   A.a_step = a_step; A.a_surv = a_surv; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf;
   A.a_grad = a_grad; A.n_alive = n_alive; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_sdf = g_sdf; A.g_gradient = g_gradient; A.grad_sdf_grid = grad_sdf_grid;
+  FGS_REQUIRE(!tot_sdf == !tot_grad, FGS_E_INVALID, "fgs_march_fine_bwd: tot_sdf and tot_grad go together");
+  A.tot_sdf = tot_sdf; A.tot_grad = tot_grad;
   hipLaunchKernelGGL(k_march_fine_bwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
   FGS_LAUNCH_OK("fgs_march_fine_bwd");
   return 0;

@@ -296,6 +296,8 @@ class _FusedFine(torch.autograd.Function):
         grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
         g_sdf_s = torch.empty(M, dtype=F32, device=dev)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
+        tot_sdf = torch.empty(M, dtype=F32, device=dev)
+        tot_grad = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
         call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
              g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
@@ -305,7 +307,10 @@ class _FusedFine(torch.autograd.Function):
              g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
              ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
              ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
-             ptr(g_grad_s), ptr(grad_sdf), st)
+             ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), st)
+        # 7. every sdf.grad contribution of the survivors (24 taps + centre + six +/-1 taps), combined on chip
+        call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
+             run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
 
         grads: List[Optional[torch.Tensor]] = [None, grad_sdf, grad_k0]
         for i in range(n_rgb):

@@ -215,7 +215,16 @@ int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const float *vi
                        const int *a_surv, const float *a_alpha, const float *a_T, const float *a_weight,
                        const float *a_sdf, const float *a_grad, const int64_t *n_alive, const int64_t *surv_off,
                        const float *alphainv_last, const float *g_weights, const float *g_last, const float *g_sdf,
-                       const float *g_gradient, float *grad_sdf_grid, fgs_stream_t stream);
+                       const float *g_gradient, float *grad_sdf_grid, float *tot_sdf, float *tot_grad,
+                       fgs_stream_t stream);
+/* tot_sdf [M_s] / tot_grad [M_s,3] (both or neither): when given, the survivors' total gradients w.r.t. their sdf value
+ * and sdf gradient vector are written there instead of being scattered, and fgs_sdf_scatter_surv combines them on chip
+ * with the hierarchical-tap gradients (8x8x8 LDS brick per survivor, row-wise flush: ~30 atomic line requests per
+ * survivor instead of ~250).  dX0 is the gradient w.r.t. the rgbnet input buffer; X0 the saved forward buffer. */
+int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                         int Z, float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
+                         const float *dX0, const float *tot_sdf, const float *tot_grad, float *sdf_grad_grid,
+                         fgs_stream_t stream);
 
 /* Per-survivor MLP inputs (model/nerf.py:835-883).  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq,
  * use_viewdir, center_sdf, use_grad_norm, K, ldx0, off_ref, ldz}; displace_host = K sorted displacements (K <= 5).
