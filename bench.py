@@ -45,10 +45,11 @@ def make_optimizer(model):
 
 def train_step(model, opt, averager, batch, n_rays_global):
     from fgs_nerf_amd import synth
-    from fgs_nerf_amd.losses import render_losses
+    from fgs_nerf_amd.losses import fused_render_losses
     ro, rd, vd, target = batch
     res = model(ro, rd, vd, global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
-    loss = render_losses(res, target, synth.FINE_LOSS, model)
+    # nerf_training.py:308-327; two HIP launches each way on the fused path, plain torch on the composed path
+    loss = fused_render_losses(res, target, synth.FINE_LOSS, model)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     averager.average()

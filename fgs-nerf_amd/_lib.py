@@ -46,6 +46,9 @@ _SIGNATURES = {
     "fgs_march_fine_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, I32,
                            P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_sdf_scatter_surv": [I64, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P],
+    "fgs_adam_upd_multi": [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P],
+    "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_fine_loss_bwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_feat_fine_fwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, I64, I64, I64, P, P, P, P],
     "fgs_feat_fine_bwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64,
                           P, P, P],

@@ -5,13 +5,20 @@ Contract kept: constructor ``MaskedAdam(params, lr, betas=(0.9, 0.99), eps)``, p
 ``set_pervoxel_lr(count)``, and the rule that picks one of three fused update kernels per tensor
 (per-voxel lr if a same-shape table is set, else masked if the group says ``skip_zero_grad``, else
 dense).  The kernels are csrc/gridopt.hip (``fgs_adam_upd``), not the JIT-built ``adam_upd_cuda``.
+Small tensors (the 16 MLP weights / biases) are updated by ONE ``fgs_adam_upd_multi`` launch per
+(betas, eps) instead of one launch each; the arithmetic per element is identical.
 The reference's unused ``Adam`` class (model/adam.py:16-161) is outside the hot path.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
+from ._lib import call, stream
 from .ops import adam_upd_cuda
+
+_SMALL = 1 << 20  # tensors below this many elements go through the multi-tensor launch
 
 
 def _as_layout_of(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
@@ -44,12 +51,26 @@ class MaskedAdam(torch.optim.Optimizer):
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    @staticmethod
+    def _flush_small(batch, b1, b2, eps):
+        n = len(batch)
+        if n == 0:
+            return
+        P = ctypes.c_void_p
+        tables = [(P * n)(*[row[k].data_ptr() for row in batch]) for k in range(4)]
+        sizes = (ctypes.c_int64 * n)(*[row[0].numel() for row in batch])
+        steps = (ctypes.c_int * n)(*[row[4] for row in batch])
+        lrs = (ctypes.c_float * n)(*[row[5] for row in batch])
+        masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
+        call("fgs_adam_upd_multi", n, *tables, sizes, steps, lrs, masked, float(b1), float(b2), float(eps), stream())
+
     @torch.no_grad()
     def step(self):
         for group in self.param_groups:
             b1, b2 = group['betas']
             hyper = (b1, b2, group['lr'], group['eps'])
             masked = group['skip_zero_grad']
+            small = []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -59,7 +80,10 @@ class MaskedAdam(torch.optim.Optimizer):
                 m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
                 if self.per_lr is not None and p.shape == self.per_lr.shape:
                     adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
+                elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
+                    small.append((p, g, m, v, t, group['lr'], masked))
                 elif masked:
                     adam_upd_cuda.masked_adam_upd(p, g, m, v, t, *hyper)
                 else:
                     adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
+            self._flush_small(small, b1, b2, group['eps'])

@@ -164,3 +164,63 @@ FGS_API int fgs_adam_upd(float *param, const float *grad, float *exp_avg, float 
     default:              return launch_adam<2>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, st);
   }
 }
+
+// ---- many small tensors in one launch (the 16 Linear weights / biases of the two MLPs) -----------------------------
+namespace {
+constexpr int MULTI_MAX = 32;
+struct MultiAdam {
+  int n_tensors;
+  float *param[MULTI_MAX];
+  const float *grad[MULTI_MAX];
+  float *m[MULTI_MAX], *v[MULTI_MAX];
+  int64_t size[MULTI_MAX];
+  unsigned blk_start[MULTI_MAX + 1];
+  float step_size[MULTI_MAX];
+  int masked[MULTI_MAX];
+};
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_adam_multi(MultiAdam A, float beta1, float beta2, float eps) {
+  int t = 0;
+  while (t + 1 < A.n_tensors && blockIdx.x >= A.blk_start[t + 1]) ++t;  // uniform per block
+  const int64_t i = (int64_t)(blockIdx.x - A.blk_start[t]) * blockDim.x + threadIdx.x;
+  if (i >= A.size[t]) return;
+  const float g = A.grad[t][i];
+  if (A.masked[t] && g == 0.f) return;
+  float p = A.param[t][i], m = A.m[t][i], v = A.v[t][i];
+  adam_one<0>(p, g, m, v, 1.f, A.step_size[t], beta1, beta2, eps);
+  A.param[t][i] = p;
+  A.m[t][i] = m;
+  A.v[t][i] = v;
+}
+}  // namespace
+
+FGS_API int fgs_adam_upd_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                               float *const *exp_avg_sqs, const int64_t *sizes, const int *steps, const float *lrs,
+                               const int *masked, float beta1, float beta2, float eps, fgs_stream_t stream) {
+  FGS_REQUIRE(n_tensors >= 0, FGS_E_INVALID, "fgs_adam_upd_multi: n_tensors=%d", n_tensors);
+  if (n_tensors == 0) return 0;
+  FGS_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && sizes && steps && lrs && masked, FGS_E_INVALID,
+              "fgs_adam_upd_multi: null table");
+  for (int base = 0; base < n_tensors; base += MULTI_MAX) {
+    MultiAdam A;
+    A.n_tensors = (n_tensors - base < MULTI_MAX) ? n_tensors - base : MULTI_MAX;
+    unsigned blocks = 0;
+    for (int t = 0; t < A.n_tensors; ++t) {
+      const int s = base + t;
+      FGS_REQUIRE(params[s] && grads[s] && exp_avgs[s] && exp_avg_sqs[s] && sizes[s] >= 0 && sizes[s] < ((int64_t)1 << 31),
+                  FGS_E_INVALID, "fgs_adam_upd_multi: bad tensor %d", s);
+      A.param[t] = params[s]; A.grad[t] = grads[s]; A.m[t] = exp_avgs[s]; A.v[t] = exp_avg_sqs[s];
+      A.size[t] = sizes[s];
+      A.masked[t] = masked[s];
+      // adam_upd_kernel.cu:72, per tensor (each keeps its own step count)
+      A.step_size[t] = lrs[s] * sqrtf(1.f - powf(beta2, (float)steps[s])) / (1.f - powf(beta1, (float)steps[s]));
+      A.blk_start[t] = blocks;
+      blocks += fgs_blocks(sizes[s]);
+    }
+    A.blk_start[A.n_tensors] = blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), A, beta1, beta2, eps);
+    FGS_LAUNCH_OK("fgs_adam_upd_multi");
+  }
+  return 0;
+}

@@ -1,9 +1,18 @@
-"""Ray-dependent loss terms of one training iteration, as model/nerf_training.py:308-327 computes them from the
-render result dict.  Plain torch on whatever device the results live on (host-side training-loop code, not a kernel)."""
+"""Ray-dependent loss terms of one training iteration (model/nerf_training.py:308-327).
+
+``render_losses``        plain torch, exactly the reference statements, on whatever device the results live on.
+``fused_render_losses``  the same value and gradients from two small HIP kernels each way (csrc/losses.hip) instead
+                         of ~40 autograd launches -- SURVEY.md 8f row f1 (training-loop host overhead).  Needs the
+                         result dict of the fused render path (per-ray view directions, survivor ray ids).
+"""
 from __future__ import annotations
+
+import ctypes
 
 import torch
 import torch.nn.functional as F
+
+from ._lib import call, ptr, stream
 
 
 def render_losses(res, target, cfg, model=None):
@@ -23,3 +32,47 @@ def render_losses(res, target, cfg, model=None):
     if cfg.get('sigmoid_rgb_loss', 0) > 0:
         loss = loss + cfg['sigmoid_rgb_loss'] * F.mse_loss(res['sigmoid_rgb'], target)
     return loss
+
+
+def _w5(cfg):
+    return (ctypes.c_float * 5)(float(cfg.get('weight_main', 1.0)), float(cfg.get('weight_rgbper', 0)),
+                                float(cfg.get('weight_entropy_last', 0)), float(cfg.get('weight_orientation', 0)),
+                                float(cfg.get('sigmoid_rgb_loss', 0)))
+
+
+class _FineLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_marched, sigmoid_rgb, alphainv_cum, normal, raw_rgb, weights, ray_id, ray_viewdirs, target, w5):
+        N, M = rgb_marched.shape[0], weights.shape[0]
+        loss = torch.empty((), dtype=torch.float32, device=rgb_marched.device)
+        args = (rgb_marched.contiguous(), sigmoid_rgb.contiguous(), target.contiguous(), alphainv_cum.contiguous(),
+                weights.contiguous(), normal.contiguous(), raw_rgb.contiguous(), ray_id.contiguous(),
+                ray_viewdirs.contiguous())
+        call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), stream())
+        ctx.save_for_backward(*args)
+        ctx.w5 = w5
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        args = ctx.saved_tensors
+        rgb_marched, weights = args[0], args[4]
+        N, M, dev = rgb_marched.shape[0], weights.shape[0], rgb_marched.device
+        g_rm = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        g_sr = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        g_last = torch.empty(N, dtype=torch.float32, device=dev)
+        g_normal = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        g_raw = torch.empty(M, 3, dtype=torch.float32, device=dev) if ctx.w5[1] > 0 else None
+        call("fgs_fine_loss_bwd", N, M, *(ptr(a) for a in args), ctx.w5, ptr(grad_out.contiguous()), ptr(g_rm), ptr(g_sr),
+             ptr(g_last), ptr(g_normal), ptr(g_raw), stream())
+        return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None
+
+
+def fused_render_losses(res, target, cfg, model=None):
+    """Same scalar and gradients as ``render_losses`` for a fused-path result dict (``res['ray_viewdirs']`` [N,3])."""
+    rv = res.get('ray_viewdirs') if hasattr(res, 'get') else None
+    if rv is None or not res['rgb_marched'].is_cuda:
+        return render_losses(res, target, cfg, model)
+    return _FineLoss.apply(res['rgb_marched'], res['sigmoid_rgb'], res['alphainv_cum'], res['normal'], res['raw_rgb'],
+                           res['weights'], res['ray_id'], rv, target, _w5(cfg))

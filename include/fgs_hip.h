@@ -121,6 +121,29 @@ int fgs_tv_add_grad(const float *param, float *grad, const float *mask, float wx
 int fgs_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
                  int step, float beta1, float beta2, float lr, float eps, int mode, fgs_stream_t stream);
 
+/* The same update for many small tensors in ONE launch (MaskedAdam.step over the 16 MLP weights / biases:
+ * model/adam.py:195-221 loops one kernel per tensor).  HOST tables of n_tensors entries; per-tensor step count, lr and
+ * masked flag (skip_zero_grad); arithmetic identical to fgs_adam_upd modes 0 / 1. */
+int fgs_adam_upd_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                       float *const *exp_avg_sqs, const int64_t *sizes, const int *steps, const float *lrs,
+                       const int *masked, float beta1, float beta2, float eps, fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Ray-dependent loss terms of one iteration -- model/nerf_training.py:308-327 (+ nerf.orientation_loss,
+ * model/nerf.py:469-478) and their gradients, two launches each instead of the ~40 of the autograd graph.
+ * weights5_host = {weight_main, weight_rgbper, weight_entropy_last, weight_orientation, sigmoid_rgb_loss}.
+ * viewdirs are per RAY [N,3] (the per-sample view direction is viewdirs[ray_id]).  loss_out / grad_out: device floats.
+ * ------------------------------------------------------------------------------ */
+int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
+                      const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
+                      const int64_t *ray_id, const float *viewdirs, const float *weights5_host, float *loss_out,
+                      fgs_stream_t stream);
+int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
+                      const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
+                      const int64_t *ray_id, const float *viewdirs, const float *weights5_host, const float *grad_out,
+                      float *g_rgb_marched, float *g_sigmoid_rgb, float *g_last, float *g_normal, float *g_raw_rgb,
+                      fgs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Trilinear grid lookup -- replaces F.grid_sample(grid[1,C,X,Y,Z], ind_norm, 'bilinear',
  * align_corners=True, zeros padding) as called by DenseGrid.forward (model/grid.py:49-59),
