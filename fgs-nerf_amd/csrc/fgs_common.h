@@ -114,14 +114,23 @@ __device__ __forceinline__ bool fgs_in(int i, int n) { return (unsigned)i < (uns
 // Trilinear value of channel `c` with zeros padding (corners outside the volume contribute 0).
 __device__ __forceinline__ float fgs_tri_sample(const float *__restrict__ g, const GridDesc &d, int64_t c,
                                                 const TriCorners &t) {
+  // All eight loads are issued unconditionally on clamped (always valid) addresses and an out-of-volume corner gets a
+  // zero weight: fmaf(v, 0, acc) == acc for the finite grid values, so the result equals skipping the corner, but
+  // the loads carry no branch and the compiler can keep all of them (and those of neighbouring lookups) in flight
+  // behind ONE s_waitcnt instead of one wait per load.
   const float *base = g + c * d.sC;
-  float acc = 0.f;
+  float v[8], w[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int x = t.x0 + (k >> 2), y = t.y0 + ((k >> 1) & 1), z = t.z0 + (k & 1);
-    if (fgs_in(x, (int)d.X) && fgs_in(y, (int)d.Y) && fgs_in(z, (int)d.Z))
-      acc = fmaf(base[x * d.sX + y * d.sY + z * d.sZ], t.w[k], acc);
+    const bool ok = fgs_in(x, (int)d.X) && fgs_in(y, (int)d.Y) && fgs_in(z, (int)d.Z);
+    const int xc = min(max(x, 0), (int)d.X - 1), yc = min(max(y, 0), (int)d.Y - 1), zc = min(max(z, 0), (int)d.Z - 1);
+    v[k] = base[xc * d.sX + yc * d.sY + zc * d.sZ];
+    w[k] = ok ? t.w[k] : 0.f;
   }
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc = fmaf(v[k], w[k], acc);
   return acc;
 }
 

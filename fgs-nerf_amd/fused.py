@@ -173,10 +173,8 @@ class _FusedFine(torch.autograd.Function):
         ref_w = [mlp[2 * (n_rgb + i)] for i in range(n_ref)]
         ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
         rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
-        W0p = torch.zeros(rw, ldx0, dtype=F32, device=dev)
-        W0p[:, :rgb_w[0].shape[1]].copy_(rgb_w[0].detach())
-        V0p = torch.zeros(fw, ldz, dtype=F32, device=dev)
-        V0p[:, :ref_w[0].shape[1]].copy_(ref_w[0].detach())
+        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
+        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
         acts_rgb = [X0]                                    # input of each rgbnet layer
         a = X0
         for i in range(n_rgb):
@@ -246,12 +244,19 @@ class _FusedFine(torch.autograd.Function):
              ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
 
         # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised)
-        gw_rgb = [torch.zeros_like(w) for w in rgb_w]
-        gw_ref = [torch.zeros_like(w) for w in ref_w]
-        gb_rgb = [torch.zeros(w.shape[0], dtype=F32, device=dev) for w in rgb_w]
-        gb_ref = [torch.zeros(w.shape[0], dtype=F32, device=dev) for w in ref_w]
-        gW0p = torch.zeros(rw, ldx0, dtype=F32, device=dev)
-        gV0p = torch.zeros(fw, ldz, dtype=F32, device=dev)
+        # one zero fill for all of them: views of a flat buffer, each 16-byte aligned
+        shapes = ([tuple(w.shape) for w in rgb_w] + [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in rgb_w] +
+                  [(w.shape[0],) for w in ref_w] + [(rw, ldx0), (fw, ldz), (ldz,)])
+        sizes = [(int(np.prod(s)) + 3) // 4 * 4 for s in shapes]
+        flat = torch.zeros(sum(sizes), dtype=F32, device=dev)
+        views, off = [], 0
+        for s, n in zip(shapes, sizes):
+            views.append(flat[off:off + int(np.prod(s))].view(*s))
+            off += n
+        gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
+        gb_rgb = views[n_rgb + n_ref:2 * n_rgb + n_ref]
+        gb_ref = views[2 * n_rgb + n_ref:2 * (n_rgb + n_ref)]
+        gW0p, gV0p, cs = views[-3], views[-2], views[-1]
 
         # 2. head: d_out -> dY of refnet layer n_ref-2 (masked), dV_last, dc_last, bias grad of layer n_ref-2
         acts_ref, acts_rgb = S['acts_ref'], S['acts_rgb']
@@ -267,7 +272,6 @@ class _FusedFine(torch.autograd.Function):
                 dZ = torch.empty(M, ldz, dtype=F32, device=dev)
                 # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
                 # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
-                cs = torch.zeros(ldz, dtype=F32, device=dev)
                 _gemm(fo.GEMM_NN, dY, S['V0p'], dZ, M, ldz, fw, colsum=cs, logical=(M, ref_w[0].shape[1], fw))
                 gb_rgb[-1] = cs[:rw]
             else:
