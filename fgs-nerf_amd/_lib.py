@@ -41,6 +41,8 @@ _SIGNATURES = {
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_march_count": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
+                        P, P, P, I32, I32, I32, F32, I32, P, P, P],
     "fgs_surv_compact": [I64, I64, P, I32, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32,
                          P, P, P, P, P, P, P, P, P],
     "fgs_march_fine_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, I32,

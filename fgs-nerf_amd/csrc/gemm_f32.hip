@@ -109,6 +109,20 @@ __device__ __forceinline__ void frag_load(float (&f)[16], const float *__restric
   }
 }
 
+// Half of that run: the 8 values k = 16h + 8*half .. + 7 (one pipeline stage of the K loop).
+template <bool KC>
+__device__ __forceinline__ void half_load(float (&f)[8], const float *__restrict__ lds, int idx, int h, int half) {
+  if (KC) {
+    const float4 *p = reinterpret_cast<const float4 *>(lds + idx * LDK + 16 * h + 8 * half);
+    const float4 u = p[0], v = p[1];
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
+    f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+  } else {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = lds[(16 * h + 8 * half + s) * LDI + idx];
+  }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];  // [buffer][A|B]
@@ -147,41 +161,75 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Software pipeline, three stages deep, one raw barrier per K chunk:
+  //   global -> staging registers : chunk c+2 (issued at the top of iteration c, a full iteration to land)
+  //   staging registers -> LDS    : chunk c+1 (top of iteration c, into the buffer chunk c-1 has vacated)
+  //   LDS -> fragment registers   : the next HALF chunk (8 k-steps) is fetched while the current half's 32 MFMAs issue,
+  //                                 so a wave's MFMA stream is not interrupted by LDS latency.
+  // The barrier is s_waitcnt lgkmcnt(0) + s_barrier (no vmcnt wait: __syncthreads() would drain the prefetch).
   Stage<A_KC> sa;
   Stage<B_KC> sb;
+  const int ia0 = wave_m * 64 + l31, ib0 = wave_n * 64 + l31;
+  const int64_t n_chunks = (k_end - k_begin + BK - 1) / BK;
   stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin, k_end, tid);
   stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin, k_end, tid);
   stage_store<A_KC>(sa, lds[0][0], tid);
   stage_store<B_KC>(sb, lds[0][1], tid);
-  __syncthreads();
+  if (n_chunks > 1) {
+    stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin + BK, k_end, tid);
+    stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin + BK, k_end, tid);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  int cur = 0;
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
-    const bool more = k0 + BK < k_end;
-    if (more) {
-      stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k0 + BK, k_end, tid);
-      stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k0 + BK, k_end, tid);
+  float f0a[2][8], f0b[2][8], f1a[2][8], f1b[2][8];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    half_load<A_KC>(f0a[t], lds[0][0], ia0 + t * 32, h, 0);
+    half_load<B_KC>(f0b[t], lds[0][1], ib0 + t * 32, h, 0);
+  }
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int cur = (int)(c & 1);
+    if (c + 1 < n_chunks) {
+      stage_store<A_KC>(sa, lds[cur ^ 1][0], tid);
+      stage_store<B_KC>(sb, lds[cur ^ 1][1], tid);
+      if (c + 2 < n_chunks) {
+        stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin + (c + 2) * BK, k_end, tid);
+        stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin + (c + 2) * BK, k_end, tid);
+      }
     }
-    float fa[2][16], fb[2][16];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      frag_load<A_KC>(fa[t], lds[cur][0], wave_m * 64 + t * 32 + l31, h);
-      frag_load<B_KC>(fb[t], lds[cur][1], wave_n * 64 + t * 32 + l31, h);
+      half_load<A_KC>(f1a[t], lds[cur][0], ia0 + t * 32, h, 1);
+      half_load<B_KC>(f1b[t], lds[cur][1], ib0 + t * 32, h, 1);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-    if (more) {
-      stage_store<A_KC>(sa, lds[cur ^ 1][0], tid);
-      stage_store<B_KC>(sb, lds[cur ^ 1][1], tid);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[i][s], f0b[j][s], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (c + 1 < n_chunks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        half_load<A_KC>(f0a[t], lds[cur ^ 1][0], ia0 + t * 32, h, 0);
+        half_load<B_KC>(f0b[t], lds[cur ^ 1][1], ib0 + t * 32, h, 0);
+      }
     }
-    __syncthreads();
-    cur ^= 1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[i][s], f1b[j][s], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  __syncthreads();  // every wave is past its last LDS fragment read before the epilogue reuses the image
 
   // ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
   if (EPI == EPI_ATOMIC) {

@@ -86,6 +86,7 @@ __device__ __forceinline__ float neus_alpha(float sdf, float gx, float gy, float
   return fminf(fmaxf(a, 0.f), 1.f);
 }
 
+template <bool COUNT_ONLY>
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
       alpha = neus_alpha(sv.sdf, sv.gx, sv.gy, sv.gz, vx, vy, vz, A.dist, A.inv_s);
     }
     const bool m1 = in && (A.thres > 0.f ? alpha > A.thres : true);
+    if (COUNT_ONLY) {  // length of the reference's `alpha > thres` list for this ray (no termination): see fgs_march_count
+      alive_base += __popcll(__ballot(m1));
+      continue;
+    }
     unsigned long long bal = __ballot(m1);
     // exact sequential transmittance chain over the m1 lanes (render_utils_kernel.cu:591-601)
     float my_T = 1.f;
@@ -168,9 +173,11 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
   }
   if (lane == 0) {
     A.n_alive[ray] = alive_base;
-    A.n_surv[ray] = surv_base;
     A.n_inbbox[ray] = inb_count;
-    A.alphainv_last[ray] = T_cum;
+    if (!COUNT_ONLY) {
+      A.n_surv[ray] = surv_base;
+      A.alphainv_last[ray] = T_cum;
+    }
   }
 }
 
@@ -370,8 +377,40 @@ FGS_API int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const f
   A.a_step = a_step; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf; A.a_grad = a_grad;
   A.a_surv = a_surv; A.surv_slot = surv_slot; A.n_alive = n_alive; A.n_surv = n_surv; A.n_inbbox = n_inbbox;
   A.alphainv_last = alphainv_last;
-  hipLaunchKernelGGL(k_march_fine_fwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
+  hipLaunchKernelGGL(k_march_fine_fwd<false>, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
   FGS_LAUNCH_OK("fgs_march_fine_fwd");
+  return 0;
+}
+
+// Per-ray length of the reference's `alpha > fast_color_thres` list (model/nerf.py:802-810) WITHOUT early termination,
+// and the in-bbox sample count: what the result-dict entry 'mask' (a bool per such sample) is sized by.  The fused
+// forward never visits the samples behind the terminating one; this runs only when a caller asks for 'mask'.
+FGS_API int fgs_march_count(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                            const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float voxel_size,
+                            float near, float far, float stepdist, const float *sdf, float dist, float inv_s, float thres,
+                            const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
+                            int mZ, float mask_thres, int max_steps, int64_t *n_m1, int64_t *n_inbbox,
+                            fgs_stream_t stream) {
+  FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_count: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return 0;
+  FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && sdf && n_m1 && n_inbbox, FGS_E_INVALID,
+              "fgs_march_count: null pointer");
+  FGS_REQUIRE(X > 1 && Y > 1 && Z > 1 && max_steps > 0 && stepdist > 0.f, FGS_E_INVALID, "fgs_march_count: bad geometry");
+  MarchArgs A = {};
+  A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
+  A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.thres = thres;
+  A.mask_grid = mask_grid;
+  A.mask_geom = A.geom;
+  A.mask_thres = mask_thres;
+  if (mask_grid) {
+    FGS_REQUIRE(mask_min_host && mask_max_host && mX > 1 && mY > 1 && mZ > 1, FGS_E_INVALID, "fgs_march_count: bad mask cache");
+    A.mask_geom = make_geom(mask_min_host, mask_max_host, mX, mY, mZ, 0.f);
+  }
+  A.max_steps = max_steps;
+  A.n_alive = n_m1; A.n_inbbox = n_inbbox;
+  hipLaunchKernelGGL(k_march_fine_fwd<true>, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
+  FGS_LAUNCH_OK("fgs_march_count");
   return 0;
 }
 

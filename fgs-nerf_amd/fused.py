@@ -407,9 +407,22 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
         return mask_outbbox
 
     def lazy_mask():
-        with torch.no_grad():
-            res = model._forward_fine_composed(rays_o, rays_d, viewdirs, global_step, **render_kwargs)
-        return res['mask']
+        """`weights > thres` over the reference's alpha-compacted list (model/nerf.py:825): per ray the alive records come
+        first (survivors flagged), the samples behind the terminating one follow (all False)."""
+        g, ws = run.geom, run.workspace
+        n_m1 = torch.empty(N, dtype=I64, device=dev)
+        n_in = torch.empty(N, dtype=I64, device=dev)
+        call("fgs_march_count", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+             g.voxel_size, run.near, 1e9, run.stepdist, ptr(model.sdf.grid), run.dist, run.inv_s, run.thres,
+             ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
+             g.mask[3] if g.mask else 0.0, run.max_steps, ptr(n_m1), ptr(n_in), stream())
+        # the training loop reads 'mask' after optimizer.step() (nerf_training.py:373-381), i.e. on an updated sdf grid:
+        # never let a ray's list be shorter than its alive segment of this forward (valid until the next forward)
+        n_m1 = torch.maximum(n_m1, ws['n_alive'])
+        off = torch.cumsum(n_m1, 0) - n_m1
+        mask = torch.zeros(int(n_m1.sum().item()), dtype=torch.bool, device=dev)
+        mask[off[ray_id] + ex['rec_idx'].long()] = True
+        return mask
 
     eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id, 'viewdirs': run.viewdirs[ray_id],
              'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
@@ -440,9 +453,29 @@ def roofline_report():
         tot_fl += fl
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = 157.3
+    traffic = _pmc_traffic()
+    return _roofline_dict(achieved, peak, traffic, ev, tot_ms, tot_fl, per)
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    collected and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_gemm.json), averaged over the three
+    template instances.  PMC collection needs the profiler, so bench.py reports the committed measurement."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_gemm.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks))
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def _roofline_dict(achieved, peak, traffic, ev, tot_ms, tot_fl, per):
     return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32; rgbnet/refnet forward, data-grad, weight-grad)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "launches": len(ev), "avg_launch_us": round(tot_ms * 1e3 / len(ev), 2),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_gemm.json)",
+            "launches": len(ev), "avg_launch_us": round(tot_ms * 1e3 / len(ev), 2),
             "algorithmic_gflop_per_launch": round(tot_fl / len(ev) / 1e9, 3),
             "variants": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
                              "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()}}

@@ -197,7 +197,15 @@ class nerf(torch.nn.Module):
     @torch.no_grad()
     def _set_nonempty_mask(self):
         """model/nerf.py:338-353."""
-        nonempty = self.mask_cache(self._grid_points()).contiguous().reshape(*self.sdf.grid.shape)
+        pts = self._grid_points()
+        if not pts.is_cuda:
+            # model built on the host and moved later (the reference builds under set_default_device('cuda')): the
+            # lookup itself only exists as a HIP kernel, so it runs on the accelerator and the mask comes back
+            if not torch.cuda.is_available():
+                raise RuntimeError("the mask-cache lookup needs the GPU (no CPU fallback)")
+            self.mask_cache.to('cuda')
+            pts = pts.cuda()
+        nonempty = self.mask_cache(pts).contiguous().reshape(*self.sdf.grid.shape).to(self.sdf.grid.device)
         self.nonempty_mask = nonempty
         if self.stage == 'coarse':
             self.sdf.grid[~nonempty] = 1
@@ -554,6 +562,58 @@ class nerf(torch.nn.Module):
                 'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': normal_marched,
                 'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': disp, 'mask': mask,
                 'mask_outbbox': mask_outbbox, 'gradient': gradient, 's_val': s_val}
+
+
+def _nerf_extract_geometry(self, bound_min, bound_max, resolution=128, threshold=0.0, **kwargs):
+    """model/nerf.py:1157-1170: field = trilinear lookup of -sdf (smoothed in the coarse stages) on a dense lattice."""
+    from .extract_geometry import extract_geometry
+    sdf_grid = self.smooth_conv(self.sdf.grid) if self.smooth_sdf else self.sdf.grid
+    neg = (-sdf_grid).detach().contiguous()
+    if resolution is None:
+        resolution = int(self.world_size[0])
+    return extract_geometry(bound_min, bound_max, resolution=resolution, threshold=threshold,
+                            query_func=lambda pts: grid_sampler(pts.to(neg.device), neg, self.xyz_min, self.xyz_max))
+
+
+def _nerf_extract_fields(self, bound_min, bound_max, resolution=128):
+    """The field half of extract_geometry (no PyMCubes needed): float32 ndarray [res,res,res] of -sdf."""
+    from .extract_geometry import extract_fields
+    sdf_grid = self.smooth_conv(self.sdf.grid) if self.smooth_sdf else self.sdf.grid
+    neg = (-sdf_grid).detach().contiguous()
+    return extract_fields(bound_min, bound_max, resolution,
+                          lambda pts: grid_sampler(pts.to(neg.device), neg, self.xyz_min, self.xyz_max))
+
+
+def _nerf_voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
+    """model/nerf.py:398-428: per-voxel count of training views whose rays touch it (for the per-voxel lr option),
+    through autograd of the trilinear lookup on a grid of ones."""
+    n_samples = int(np.linalg.norm(np.array(self.sdf.grid.shape[2:]) + 1) / stepsize) + 1
+    dev = self.sdf.grid.device
+    rng = torch.arange(n_samples, device=dev)[None].float()
+    count = torch.zeros_like(self.sdf.grid.detach())
+    for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+        ones = torch.ones_like(self.sdf.grid).requires_grad_()
+        if irregular_shape:
+            chunks_o, chunks_d = rays_o_.split(10000), rays_d_.split(10000)
+        else:
+            chunks_o = rays_o_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+            chunks_d = rays_d_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+        for rays_o, rays_d in zip(chunks_o, chunks_d):
+            vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+            rate_a, rate_b = (self.xyz_max - rays_o) / vec, (self.xyz_min - rays_o) / vec
+            t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+            step = stepsize * self.voxel_size.to(dev) * rng
+            interpx = t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True)
+            rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+            grid_sampler(rays_pts, ones, self.xyz_min, self.xyz_max).sum().backward()
+        with torch.no_grad():
+            count += (ones.grad > 1)
+    return count
+
+
+nerf.extract_geometry = _nerf_extract_geometry
+nerf.extract_fields = _nerf_extract_fields
+nerf.voxel_count_views = _nerf_voxel_count_views
 
 
 def total_variation(v, mask=None):

@@ -220,6 +220,15 @@ int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const float *vi
                        float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive, int64_t *n_surv,
                        int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream);
 
+/* Same walk without early termination and without writing records: n_m1[r] = number of samples of ray r with
+ * alpha > thres (the length of the reference's first compacted list, model/nerf.py:802-810), n_inbbox[r] = in-bbox
+ * samples.  Used only to materialise the result-dict entry 'mask' on demand. */
+int fgs_march_count(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                    const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float voxel_size, float near,
+                    float far, float stepdist, const float *sdf, float dist, float inv_s, float thres,
+                    const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY, int mZ,
+                    float mask_thres, int max_steps, int64_t *n_m1, int64_t *n_inbbox, fgs_stream_t stream);
+
 /* Survivor position t in [0, M_s) -> ray (binary search in surv_off) and the per-survivor arrays of the result
  * dict: ray_id, step_id, weights, raw alpha, sdf, gradient[3], ray_pts[3]; rec_idx = local alive index. */
 int fgs_surv_compact(int64_t n_rays, int64_t n_surv_total, const int64_t *surv_off, int max_steps, const int *surv_slot,

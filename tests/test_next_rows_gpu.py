@@ -1,0 +1,73 @@
+"""GPU tests of the SURVEY 8(f) "next" rows built so far: lazily materialised result-dict masks (f1), SDF field
+extraction for mesh export (f3), stage hand-off checkpoint -> MaskCache (f4), per-voxel view counts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lazy_mask_entries_match_reference_semantics(dev):
+    from fgs_nerf_amd import synth
+    rays = tuple(r.to(dev) for r in synth.random_rays(400, seed=17))
+    a = synth.build_model(40, synth.FINE_MODEL, device=dev, fused=True)
+    b = synth.build_model(40, synth.FINE_MODEL, device=dev, fused=False)
+    with torch.no_grad():
+        ra = a(*rays, global_step=1000, **synth.RENDER_KWARGS)
+        rb = b(*rays, global_step=1000, **synth.RENDER_KWARGS)
+    assert 'mask' in ra and 'mask_outbbox' in ra                     # present as keys before being computed
+    assert torch.equal(ra['mask'], rb['mask'])                        # weights > thres over the alpha-compacted list
+    assert torch.equal(ra['mask_outbbox'], rb['mask_outbbox'])
+    assert abs(float(ra['mask'].float().mean()) - float(rb['mask'].float().mean())) == 0.0   # the logged statistic
+
+
+def test_extract_fields_matches_grid_sample(dev, oracle):
+    from fgs_nerf_amd import synth
+    m = synth.build_model(32, synth.FINE_MODEL, device=dev)
+    lo, hi = torch.tensor([-1., -1., -1.]), torch.tensor([1., 1., 1.])
+    u = m.extract_fields(lo, hi, resolution=70)                       # crosses the 64^3 block boundary
+    assert u.shape == (70, 70, 70) and u.dtype == np.float32
+    xs = torch.linspace(-1, 1, 70)
+    pts = torch.stack(torch.meshgrid(xs, xs, xs, indexing='ij'), -1).reshape(-1, 3)
+    ref = oracle.dense_grid_forward(-m.sdf.grid.detach().cpu(), pts, lo, hi).reshape(70, 70, 70)
+    assert rel_l2(u, ref) < 1e-6
+    with pytest.raises(ImportError):
+        m.extract_geometry(lo, hi, resolution=16)                     # PyMCubes is not part of this image
+
+
+def test_stage_checkpoint_to_mask_cache_roundtrip(dev, tmp_path):
+    """model/nerf_training.py:522-531 -> model/nerf.py:1192-1200: `set_sdf_mask`, save, next stage builds its MaskCache."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.nerf import nerf
+    coarse = synth.build_model(24, synth.COARSE_MODEL, device=dev, fused=False)
+    coarse.set_sdf_mask()
+    path = os.path.join(tmp_path, "coarse_last.tar")
+    torch.save({'global_step': 7, 'model_kwargs': coarse.get_kwargs(), 'MaskCache_kwargs': coarse.get_MaskCache_kwargs(),
+                'model_state_dict': coarse.state_dict()}, path)
+    assert 'sdf_mask.grid' in coarse.state_dict()
+    fine = nerf(xyz_min=[-1., -1., -1.], xyz_max=[1., 1., 1.], num_voxels=32 ** 3, num_voxels_base=32 ** 3,
+                mask_cache_path=path, mask_cache_thres=1e-3, **synth.FINE_MODEL).to(dev)
+    assert fine.mask_cache is not None and fine.nonempty_mask.shape == fine.sdf.grid.shape
+    # the cache keeps the neighbourhood of the coarse surface (sdf < 0.5) and drops the far corners
+    inside = fine.mask_cache(torch.tensor([[0.0, 0.0, 0.55]], device=dev))
+    corner = fine.mask_cache(torch.tensor([[0.98, 0.98, 0.98]], device=dev))
+    assert bool(inside[0]) and not bool(corner[0])
+    rays = tuple(r.to(dev) for r in synth.random_rays(128, seed=2))
+    res = fine(*rays, global_step=10, **synth.RENDER_KWARGS)          # fused path with the mask cache active
+    assert res['rgb_marched'].shape == (128, 3) and torch.isfinite(res['rgb_marched']).all()
+    # the reference's compute_bbox_by_coarse_geo (nerf_training.py:40-58) reads the same file
+    st = torch.load(path, weights_only=False)
+    assert (st['model_state_dict']['sdf_mask.grid'] > 0).any()
+
+
+def test_voxel_count_views(dev):
+    from fgs_nerf_amd import synth
+    m = synth.build_model(16, synth.FINE_MODEL, device=dev)
+    ro, rd, _ = synth.view_rays(0, 12, 12)
+    cnt = m.voxel_count_views(ro.reshape(1, 12, 12, 3).to(dev), rd.reshape(1, 12, 12, 3).to(dev), imsz=[1], near=2.0,
+                              far=6.0, stepsize=0.5, irregular_shape=False)
+    assert cnt.shape == m.sdf.grid.shape and float(cnt.sum()) > 0
