@@ -1,0 +1,105 @@
+// bricks.hip -- brick-sparse view of a channel-last grid gradient for the multi-GPU gradient exchange
+// (fgs-nerf_amd/dist.py).  The reference has no distributed code; this serves the north_star's "dense grid replicated,
+// gradients all-reduced over xGMI" with the observation that rays touch only a thin shell of voxels, so only the
+// occupied 4x4x4-voxel bricks need to travel.
+//
+// Storage: [X][Y][Z][C] floats (DenseGrid channel-last).  A brick is 16 runs of 4*C contiguous floats (4 z-voxels x C
+// channels at fixed x', y').  One wavefront handles one brick; lanes walk its 16*C float4s.
+//   fgs_brick_flags   : flags[b] = 1 if any element of brick b is non-zero (one streaming pass over the gradient)
+//   fgs_brick_gather  : buf[i] (64*C floats, order x',y',z',c) = brick idx[i]
+//   fgs_brick_scatter : brick idx[i] = buf[i] * scale
+#include "fgs_common.h"
+
+namespace {
+
+struct BrickGrid {
+  int C, X, Y, Z, nbx, nby, nbz;
+};
+
+// float4 q of brick (bx,by,bz): run = q / C (x' = run / 4, y' = run % 4), within-run float4 = q % C
+__device__ __forceinline__ int64_t brick_f4_offset(const BrickGrid &g, int bx, int by, int bz, int q) {
+  const int run = q / g.C, w4 = q - run * g.C;
+  const int x = bx * 4 + (run >> 2), y = by * 4 + (run & 3);
+  return (((int64_t)x * g.Y + y) * g.Z + bz * 4) * g.C + (int64_t)w4 * 4;
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_brick_flags(const float *__restrict__ grad, BrickGrid g,
+                                                           int *__restrict__ flags) {
+  const int64_t b = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)g.nbx * g.nby * g.nbz;
+  if (b >= total) return;
+  const int bz = (int)(b % g.nbz), by = (int)((b / g.nbz) % g.nby), bx = (int)(b / ((int64_t)g.nbz * g.nby));
+  bool nz = false;
+  for (int q = lane; q < 16 * g.C; q += FGS_WAVE) {
+    const float4 v = *reinterpret_cast<const float4 *>(grad + brick_f4_offset(g, bx, by, bz, q));
+    nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+  }
+  const unsigned long long any = __ballot(nz);
+  if (lane == 0) flags[b] = any ? 1 : 0;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(FGS_BLOCK) void k_brick_copy(float *__restrict__ grad, BrickGrid g,
+                                                          const int64_t *__restrict__ idx, int64_t n,
+                                                          float *__restrict__ buf, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const int64_t b = idx[i];
+  const int bz = (int)(b % g.nbz), by = (int)((b / g.nbz) % g.nby), bx = (int)(b / ((int64_t)g.nbz * g.nby));
+  float4 *dst = reinterpret_cast<float4 *>(buf + i * 64 * g.C);
+  for (int q = lane; q < 16 * g.C; q += FGS_WAVE) {
+    float4 *gp = reinterpret_cast<float4 *>(grad + brick_f4_offset(g, bx, by, bz, q));
+    if (SCATTER) {
+      float4 v = dst[q];
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      *gp = v;
+    } else {
+      dst[q] = *gp;
+    }
+  }
+}
+
+int make_grid(const char *who, int C, int X, int Y, int Z, BrickGrid *g) {
+  if (C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || (X & 3) || (Y & 3) || (Z & 3))
+    return fgs_set_error(FGS_E_INVALID, "%s: grid %dx%dx%dx%d must have sides that are multiples of 4", who, X, Y, Z, C);
+  g->C = C; g->X = X; g->Y = Y; g->Z = Z; g->nbx = X / 4; g->nby = Y / 4; g->nbz = Z / 4;
+  return 0;
+}
+
+}  // namespace
+
+FGS_API int fgs_brick_flags(const float *grad, int C, int X, int Y, int Z, int *flags, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_flags", C, X, Y, Z, &g)) return e;
+  FGS_REQUIRE(grad && flags, FGS_E_INVALID, "fgs_brick_flags: null pointer");
+  const int64_t total = (int64_t)g.nbx * g.nby * g.nbz;
+  hipLaunchKernelGGL(k_brick_flags, dim3(fgs_blocks(total * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), grad, g, flags);
+  FGS_LAUNCH_OK("fgs_brick_flags");
+  return 0;
+}
+
+FGS_API int fgs_brick_gather(const float *grad, int C, int X, int Y, int Z, const int64_t *idx, int64_t n, float *buf,
+                             fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_gather", C, X, Y, Z, &g)) return e;
+  if (n == 0) return 0;
+  FGS_REQUIRE(grad && idx && buf && n > 0, FGS_E_INVALID, "fgs_brick_gather: bad arguments");
+  hipLaunchKernelGGL(k_brick_copy<false>, dim3(fgs_blocks(n * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream),
+                     const_cast<float *>(grad), g, idx, n, buf, 1.f);
+  FGS_LAUNCH_OK("fgs_brick_gather");
+  return 0;
+}
+
+FGS_API int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int64_t *idx, int64_t n, const float *buf,
+                              float scale, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_scatter", C, X, Y, Z, &g)) return e;
+  if (n == 0) return 0;
+  FGS_REQUIRE(grad && idx && buf && n > 0, FGS_E_INVALID, "fgs_brick_scatter: bad arguments");
+  hipLaunchKernelGGL(k_brick_copy<true>, dim3(fgs_blocks(n * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), grad, g, idx, n,
+                     const_cast<float *>(buf), scale);
+  FGS_LAUNCH_OK("fgs_brick_scatter");
+  return 0;
+}

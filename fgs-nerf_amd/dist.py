@@ -1,15 +1,22 @@
-"""Data-parallel ray sharding: one process per GPU, grids and MLPs replicated, one gradient sum per step.
+"""Data-parallel ray sharding: one process per GPU, grids and MLPs replicated, one gradient exchange per step.
 
-The reference has no distributed code; this is the north_star's
-multi-GPU extension.  Rank r renders rays [r*N/P, (r+1)*N/P) of the global batch with a loss that is a
-mean over its local rays; averaging the gradients over ranks (sum all-reduce, then 1/P) gives exactly
-the gradient of the global-batch mean loss.  TV and MaskedAdam then run identically on every rank, so
-the replicas stay bit-identical without a parameter broadcast.
+The reference has no distributed code; this is the north_star's multi-GPU extension.
+Rank r renders rays [r*N/P, (r+1)*N/P) of the global batch with a loss that is a mean over its local rays; averaging
+the gradients over ranks (sum all-reduce, then 1/P) gives exactly the gradient of the global-batch mean loss.  TV and
+MaskedAdam then run identically on every rank, so the replicas stay bit-identical without a parameter broadcast.
 
-Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on ROCm, "gloo" is used by
-the CPU tests.  The dense grid gradients are reduced in place as their own messages (they are single
-contiguous tensors of 16 MB .. 1.7 GB: already at the large-message plateau of a direct
-reduce-scatter + all-gather); the few hundred small MLP gradients are packed into one bucket.
+Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on ROCm, "gloo" is used by the CPU tests.
+
+What is exchanged (160^3: k0.grad 197 MB, sdf.grad 16 MB, MLP grads 1.7 MB; 320^3: 1.57 GB + 131 MB):
+  * small tensors (MLP weights / biases): packed into one bucket, one all-reduce;
+  * medium dense tensors (the 1-channel sdf gradient): one all-reduce each, in place on the flat storage;
+  * the multi-channel feature-grid gradient: **brick-sparse**.  Rays only touch voxels near the surface, so a few per cent
+    of k0.grad is non-zero on a rank and, the scene being the same on all ranks, the union over ranks is barely larger.
+    The grid is cut into 4x4x4-voxel bricks; ranks OR their brick-occupancy flags (one tiny all-reduce), gather the
+    union's bricks into a dense [n_bricks, 64*C] buffer, sum-all-reduce that, and scatter it back.  A brick whose flag is
+    clear is zero on every rank, so the result equals the dense all-reduce bit for bit in which elements are non-zero
+    (masked_adam_upd keys on grad != 0) and, up to the collective's summation order, in value.  Falls back to the dense
+    exchange when more than `sparse_max_fill` of the bricks are occupied or the grid sides are not multiples of 4.
 """
 from __future__ import annotations
 
@@ -17,6 +24,8 @@ from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+BRICK = 4
 
 
 def shard_rays(n_total: int, rank: int, world_size: int) -> slice:
@@ -26,42 +35,95 @@ def shard_rays(n_total: int, rank: int, world_size: int) -> slice:
     return slice(start, start + base + (1 if rank < rem else 0))
 
 
-class GradAverager:
-    """Averages `.grad` of the given parameters over the process group.
+def _brick_view(g: torch.Tensor):
+    """[1,C,X,Y,Z] gradient -> view [X/4, 4, Y/4, 4, Z/4, 4, C] over the same storage, or None if not applicable."""
+    if g.dim() != 5 or g.shape[0] != 1:
+        return None
+    _, C, X, Y, Z = g.shape
+    if X % BRICK or Y % BRICK or Z % BRICK:
+        return None
+    v = g[0].permute(1, 2, 3, 0)                      # [X,Y,Z,C] logical view (contiguous for channel-last storage)
+    return v.reshape(X // BRICK, BRICK, Y // BRICK, BRICK, Z // BRICK, BRICK, C) if v.is_contiguous() else None
 
-    Large tensors (numel >= big_numel) are reduced one message each, asynchronously; the rest are
-    flattened into a single bucket.  ``masked_adam_upd`` keys on grad != 0: a sum keeps every voxel that
-    any rank touched non-zero, so the masked update touches the union, as a single-GPU run on the
-    concatenated batch would."""
+
+class GradAverager:
+    """Averages `.grad` of the given parameters over the process group (see the module docstring for the scheme)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
-                 big_numel: int = 1 << 20):
+                 big_numel: int = 1 << 20, sparse_min_numel: int = 1 << 24, sparse_max_fill: float = 0.5):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.big_numel = big_numel
+        self.sparse_min_numel = sparse_min_numel
+        self.sparse_max_fill = sparse_max_fill
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self._bucket = None
+        self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
 
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _dense(self, g: torch.Tensor, async_op: bool):
+        flat = g.as_strided((g.numel(),), (1,))       # the dense storage as a flat view (layout-agnostic, no copy)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), flat
+
+    def _sparse(self, g: torch.Tensor, inv: float) -> bool:
+        """Brick-sparse exchange of one multi-channel grid gradient.  Returns False if the dense path should be used."""
+        bv = _brick_view(g)
+        if bv is None:
+            return False
+        nbx, _, nby, _, nbz, _, C = bv.shape
+        total = nbx * nby * nbz
+        on_gpu = g.is_cuda
+        dims = (C, nbx * BRICK, nby * BRICK, nbz * BRICK)
+        if on_gpu:       # csrc/bricks.hip: one streaming pass over the gradient
+            from ._lib import call, ptr, stream
+            flags = torch.empty(total, dtype=torch.int32, device=g.device)
+            call("fgs_brick_flags", ptr(g), *dims, ptr(flags), stream())
+        else:            # host tensors (gloo tests): the same thing with torch indexing
+            flags = (bv != 0).any(dim=6).any(dim=5).any(dim=3).any(dim=1).to(torch.int32).reshape(-1)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)                         # union of occupancy
+        idx = flags.nonzero(as_tuple=False).squeeze(1)                                          # identical on all ranks
+        n = int(idx.numel())
+        self.last_sparse_fill = n / max(total, 1)
+        if n > self.sparse_max_fill * total:
+            return False
+        if n == 0:
+            return True
+        if on_gpu:
+            buf = torch.empty(n, BRICK ** 3 * C, dtype=g.dtype, device=g.device)
+            call("fgs_brick_gather", ptr(g), *dims, ptr(idx), n, ptr(buf), stream())
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), float(inv), stream())
+            return True
+        bx = idx // (nby * nbz)
+        by = (idx // nbz) % nby
+        bz = idx % nbz
+        buf = bv[bx, :, by, :, bz, :, :].contiguous()                                           # [n,4,4,4,C] gather
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        buf.mul_(inv)
+        bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
+        return True
+
+    # ------------------------------------------------------------------------------------------------ driver
     @torch.no_grad()
     def average(self) -> None:
         if self.world_size == 1:
             return
         inv = 1.0 / self.world_size
-        handles = []
-        small = []
+        handles, small, sparse_later = [], [], []
         for p in self.params:
-            if p.grad is None:
+            g = p.grad
+            if g is None:
                 continue
-            if p.grad.numel() >= self.big_numel:
-                g = p.grad
-                if not (g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last_3d)):
+            if g.numel() >= self.big_numel:
+                if not (g.is_contiguous() or (g.dim() == 5 and g.is_contiguous(memory_format=torch.channels_last_3d))):
                     g = g.contiguous()
                     p.grad = g
-                # reduce the dense storage as a flat view (layout-agnostic, no copy)
-                flat = g.as_strided((g.numel(),), (1,))
-                handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+                if g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1:
+                    sparse_later.append(g)
+                else:
+                    handles.append(self._dense(g, async_op=True))
             else:
-                small.append(p.grad)
+                small.append(g)
         if small:
             n = sum(g.numel() for g in small)
             if self._bucket is None or self._bucket.numel() != n or self._bucket.device != small[0].device:
@@ -76,6 +138,10 @@ class GradAverager:
             for g in small:
                 g.copy_(self._bucket[off:off + g.numel()].view_as(g))
                 off += g.numel()
+        for g in sparse_later:
+            if not self._sparse(g, inv):
+                h, flat = self._dense(g, async_op=False)
+                flat.mul_(inv)
         for h, flat in handles:
             h.wait()
             flat.mul_(inv)

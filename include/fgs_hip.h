@@ -129,6 +129,18 @@ int fgs_adam_upd_multi(int n_tensors, float *const *params, const float *const *
                        const int *masked, float beta1, float beta2, float eps, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
+ * Brick-sparse view of a channel-last grid gradient [X][Y][Z][C] (X, Y, Z multiples of 4) for the multi-GPU gradient
+ * exchange (no reference counterpart: the reference is single-GPU).  Bricks are 4x4x4 voxels, numbered
+ * (bx * nby + by) * nbz + bz.  flags[b] = 1 iff brick b has a non-zero element; gather/scatter move the bricks listed
+ * in idx[n] to / from a dense buffer [n][4][4][4][C]; scatter multiplies by `scale` (the 1/world_size of the average).
+ * ------------------------------------------------------------------------------ */
+int fgs_brick_flags(const float *grad, int C, int X, int Y, int Z, int *flags, fgs_stream_t stream);
+int fgs_brick_gather(const float *grad, int C, int X, int Y, int Z, const int64_t *idx, int64_t n, float *buf,
+                     fgs_stream_t stream);
+int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int64_t *idx, int64_t n, const float *buf,
+                      float scale, fgs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * Ray-dependent loss terms of one iteration -- model/nerf_training.py:308-327 (+ nerf.orientation_loss,
  * model/nerf.py:469-478) and their gradients, two launches each instead of the ~40 of the autograd graph.
  * weights5_host = {weight_main, weight_rgbper, weight_entropy_last, weight_orientation, sigmoid_rgb_loss}.

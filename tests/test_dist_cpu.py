@@ -1,7 +1,7 @@
-"""world_size-2 gloo tests of the data-parallel layer (fgs-nerf_amd/dist.py): ray sharding and gradient averaging.
+"""world_size-2 gloo tests of the data-parallel layer (fgs-nerf_amd/dist.py): ray sharding and gradient averaging,
+including the brick-sparse exchange of the multi-channel grid gradient.
 
-The GPU path uses the same code with backend "nccl" (RCCL over xGMI); the collective pattern -- one sum all-reduce per
-large grid gradient, one bucket for the small MLP gradients -- is backend independent."""
+The GPU path uses the same code with backend "nccl" (RCCL over xGMI); the collective pattern is backend independent."""
 import os
 import socket
 
@@ -23,36 +23,45 @@ def _worker(rank, world, port, out):
     try:
         from fgs_nerf_amd.dist import GradAverager, shard_rays
         torch.manual_seed(0)
-        # a "grid" (big, channel-last like DenseGrid storage) and two small "MLP" tensors, identical on all ranks
-        grid = torch.nn.Parameter(torch.randn(1, 4, 6, 7, 8).contiguous(memory_format=torch.channels_last_3d))
+        # identical replicas: a channel-last feature grid (brick-sparse path), an odd-sized 1-channel grid (dense path)
+        # and two small "MLP" tensors (bucket path)
+        k0 = torch.nn.Parameter(torch.randn(1, 4, 8, 12, 16).contiguous(memory_format=torch.channels_last_3d))
+        sdf = torch.nn.Parameter(torch.randn(1, 1, 6, 7, 9))
         w = torch.nn.Parameter(torch.randn(5, 3))
         b = torch.nn.Parameter(torch.randn(5))
         n_total = 11
         x_all = torch.randn(n_total, 3)
         t_all = torch.randn(n_total, 5)
-        idx_all = torch.randint(0, 4 * 6 * 7 * 8, (n_total,))
+        vox = torch.randint(0, 8 * 12 * 16, (n_total,))          # each "ray" touches one k0 voxel (4 channels) ...
+        vs = torch.randint(0, 6 * 7 * 9, (n_total,))              # ... and one sdf voxel
 
-        def loss_of(x, t, idx):
-            pred = x @ w.T + b + grid.reshape(-1)[idx][:, None]
+        def loss_of(k0_, sdf_, w_, b_, x, t, v, s):
+            feat = k0_[0].permute(1, 2, 3, 0).reshape(-1, 4)[v]                       # [n,4]
+            pred = x @ w_.T + b_ + feat.sum(-1, keepdim=True) + sdf_.reshape(-1)[s][:, None]
             return (pred - t).pow(2).mean()
 
         sl = shard_rays(n_total, rank, world)
         n_local = sl.stop - sl.start
         # local mean loss scaled by n_local * world / n_total so that the rank-average equals the global mean
-        loss = loss_of(x_all[sl], t_all[sl], idx_all[sl]) * (n_local * world / n_total)
-        loss.backward()
-        avg = GradAverager([grid, w, b], big_numel=512)      # the grid goes the "large message" way
+        (loss_of(k0, sdf, w, b, x_all[sl], t_all[sl], vox[sl], vs[sl]) * (n_local * world / n_total)).backward()
+        avg = GradAverager([k0, sdf, w, b], big_numel=256, sparse_min_numel=1024, sparse_max_fill=0.9)
         avg.average()
+        used_sparse = avg.last_sparse_fill is not None and 0 < avg.last_sparse_fill < 0.9
         # reference: the whole batch on one process
-        g2 = torch.nn.Parameter(grid.detach().clone())
-        w2, b2 = torch.nn.Parameter(w.detach().clone()), torch.nn.Parameter(b.detach().clone())
-        pred = x_all @ w2.T + b2 + g2.reshape(-1)[idx_all][:, None]
-        (pred - t_all).pow(2).mean().backward()
-        ok = (torch.allclose(grid.grad, g2.grad, atol=1e-6) and torch.allclose(w.grad, w2.grad, atol=1e-6)
-              and torch.allclose(b.grad, b2.grad, atol=1e-6) and grid.grad.stride() == grid.stride())
-        # a voxel touched by only one rank stays non-zero after the sum (masked Adam keys on grad != 0)
-        touched_union = (g2.grad != 0)
-        ok = ok and bool(((grid.grad != 0) == touched_union).all())
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in (k0, sdf, w, b)]
+        loss_of(*ref, x_all, t_all, vox, vs).backward()
+        ok = all(torch.allclose(p.grad, r.grad, atol=1e-6) for p, r in zip((k0, sdf, w, b), ref))
+        ok = ok and k0.grad.stride() == k0.stride() and used_sparse
+        # a voxel touched by only one rank stays non-zero after the exchange (masked Adam keys on grad != 0)
+        ok = ok and bool(((k0.grad != 0) == (ref[0].grad != 0)).all())
+        # dense fallback when the occupancy is above the limit gives the same numbers
+        k0.grad = None
+        sdf.grad = None
+        w.grad = None
+        b.grad = None
+        (loss_of(k0, sdf, w, b, x_all[sl], t_all[sl], vox[sl], vs[sl]) * (n_local * world / n_total)).backward()
+        GradAverager([k0, sdf, w, b], big_numel=256, sparse_min_numel=1024, sparse_max_fill=0.0).average()
+        ok = ok and torch.allclose(k0.grad, ref[0].grad, atol=1e-6)
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
