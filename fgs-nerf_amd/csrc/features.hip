@@ -21,6 +21,9 @@ struct FeatLayout {
   float disp[MAXK];
   int off_k0, off_xyz, off_view, off_sdf, off_feat, off_hgrad, off_grad, x0_cols, ldx0;
   int off_ref, z_cols, ldz;
+  // coarse stages (model/nerf.py:993-1009): ONE operand buffer [k0, xyz_emb, reflect_emb, normal, viewdirs_emb];
+  // off_ref / ldz then address the reflection block inside X0 and off_grad holds the NORMAL, not the raw gradient
+  int coarse;
 };
 
 struct SurvArgs {
@@ -225,7 +228,7 @@ __device__ __forceinline__ void write_pe_component(float *__restrict__ row, int 
   }
 }
 
-__global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *__restrict__ X0, float *__restrict__ Z,
+__global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X0, float *Z /* == X0 in coarse mode */,
                                                             float *__restrict__ normal_out) {
   const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int slot = threadIdx.x & 15;
@@ -249,11 +252,19 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *_
     normal_out[3 * m + c] = nn.n[c];
   } else {  // slot 9: scalar features and zero padding
     if (L.center_sdf) x0[L.off_sdf] = S.sdf[m];
-    x0[L.off_grad + 0] = S.gradient[3 * m + 0];
-    x0[L.off_grad + 1] = S.gradient[3 * m + 1];
-    x0[L.off_grad + 2] = S.gradient[3 * m + 2];
+    if (L.coarse) {
+      const Normal3 nn = normal_of(S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]);
+      x0[L.off_grad + 0] = nn.n[0];
+      x0[L.off_grad + 1] = nn.n[1];
+      x0[L.off_grad + 2] = nn.n[2];
+    } else {
+      x0[L.off_grad + 0] = S.gradient[3 * m + 0];
+      x0[L.off_grad + 1] = S.gradient[3 * m + 1];
+      x0[L.off_grad + 2] = S.gradient[3 * m + 2];
+    }
     for (int c = L.x0_cols; c < L.ldx0; ++c) x0[c] = 0.f;
-    for (int c = L.z_cols; c < L.ldz; ++c) Z[m * L.ldz + c] = 0.f;
+    if (!L.coarse)
+      for (int c = L.z_cols; c < L.ldz; ++c) Z[m * L.ldz + c] = 0.f;
   }
 }
 
@@ -296,7 +307,10 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
   const float drn = (dr[0] * n[0] + dr[1] * n[1]) + dr[2] * n[2];
   float dn[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) dn[c] = -2.f * (v[c] * drn + s * dr[c]) + (g_normal ? g_normal[3 * m + c] : 0.f);
+  for (int c = 0; c < 3; ++c) {
+    dn[c] = -2.f * (v[c] * drn + s * dr[c]) + (g_normal ? g_normal[3 * m + c] : 0.f);
+    if (L.coarse) dn[c] += dX0[m * L.ldx0 + L.off_grad + c];  // the normal itself is an MLP input column
+  }
   // normal = x / sqrt(max(sum x^2, eps))
   const float dnx = (dn[0] * x[0] + dn[1] * x[1]) + dn[2] * x[2];
   float dx[3];
@@ -308,9 +322,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
   for (int c = 0; c < 3; ++c) {
     float dg = dx[c] / (rn + 1e-7f);
     if (rn > 0.f) dg -= dxg / ((rn + 1e-7f) * (rn + 1e-7f)) * (g[c] / rn);
-    g_gradient[3 * m + c] = dg + dX0[m * L.ldx0 + L.off_grad + c];
+    g_gradient[3 * m + c] = L.coarse ? dg : dg + dX0[m * L.ldx0 + L.off_grad + c];
   }
-  g_sdf[m] = L.center_sdf ? dX0[m * L.ldx0 + L.off_sdf] : 0.f;
+  if (g_sdf) g_sdf[m] = L.center_sdf ? dX0[m * L.ldx0 + L.off_sdf] : 0.f;
 }
 
 // ------------------------------------------------------------------------- 3-wide output head (refnet last Linear)
@@ -537,6 +551,7 @@ int fill_layout(const int *li, const float *disp, FeatLayout *L) {
   L->k0_dim = li[0]; L->n_posfreq = li[1]; L->n_viewfreq = li[2]; L->n_reffreq = li[3];
   L->use_viewdir = li[4]; L->center_sdf = li[5]; L->use_grad_norm = li[6]; L->K = li[7];
   L->ldx0 = li[8]; L->off_ref = li[9]; L->ldz = li[10];
+  L->coarse = 0;
   if (L->K < 0 || L->K > 5) return fgs_set_error(FGS_E_RANGE, "feature layout: K=%d displacements (0..5 supported)", L->K);
   for (int i = 0; i < MAXK; ++i) L->disp[i] = (i < L->K && disp) ? disp[i] : 0.f;
   // column order of torch.cat([k0, xyz_emb, viewdirs_emb, sdf, all_feat, all_grad, gradient]) (model/nerf.py:874)
@@ -556,7 +571,73 @@ int fill_layout(const int *li, const float *disp, FeatLayout *L) {
   return 0;
 }
 
+int fill_layout_coarse(const int *li, FeatLayout *L) {
+  // li: k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, ldx0
+  L->k0_dim = li[0]; L->n_posfreq = li[1]; L->n_viewfreq = li[2]; L->n_reffreq = li[3]; L->use_viewdir = li[4];
+  L->center_sdf = 0; L->use_grad_norm = 0; L->K = 0; L->ldx0 = li[5]; L->coarse = 1;
+  for (int i = 0; i < MAXK; ++i) L->disp[i] = 0.f;
+  // column order of torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb]) (model/nerf.py:1007)
+  int c = 0;
+  L->off_k0 = c; c += L->k0_dim;
+  L->off_xyz = c; c += 3 + 6 * L->n_posfreq;
+  L->off_ref = c; c += 3 + 6 * L->n_reffreq;
+  L->off_grad = c; c += 3;
+  L->off_view = c; c += L->use_viewdir ? 3 + 6 * L->n_viewfreq : 0;
+  L->off_sdf = L->off_feat = L->off_hgrad = c;
+  L->x0_cols = c;
+  L->ldz = L->ldx0; L->z_cols = L->ldx0;
+  if (L->ldx0 < L->x0_cols || (L->ldx0 & 3))
+    return fgs_set_error(FGS_E_INVALID, "coarse feature layout: ldx0=%d (need >= %d, multiple of 4)", L->ldx0, L->x0_cols);
+  return 0;
+}
+
 }  // namespace
+
+// Coarse-stage operand rows [k0, xyz_emb, reflect_emb, normal, viewdirs_emb] (model/nerf.py:992-1009).
+// layout_i: 6 ints (see fill_layout_coarse).
+FGS_API int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient,
+                                const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                                int Z, const int *layout_i, const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY,
+                                int64_t ksZ, float *X0, float *normal_out, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_coarse_fwd: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && k0_grid && X0 && normal_out,
+              FGS_E_INVALID, "fgs_feat_coarse_fwd: null pointer");
+  SurvArgs S;
+  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
+  if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
+  hipStream_t st = fgs_s(stream);
+  const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
+  hipLaunchKernelGGL(k_feat_k0_fwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grid, kd, X0);
+  FGS_LAUNCH_OK("fgs_feat_coarse_fwd/k0");
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 16)), dim3(FGS_BLOCK), 0, st, S, X0, X0, normal_out);
+  FGS_LAUNCH_OK("fgs_feat_coarse_fwd/enc");
+  return 0;
+}
+
+FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient,
+                                const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                                int Z, const int *layout_i, const float *X0, const float *dX0, const float *g_normal,
+                                float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient,
+                                fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_coarse_bwd: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && k0_grad_grid &&
+                  g_gradient, FGS_E_INVALID, "fgs_feat_coarse_bwd: null pointer");
+  SurvArgs S;
+  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
+  if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
+  hipStream_t st = fgs_s(stream);
+  const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
+  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+  FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
+                     (float *)nullptr, g_gradient);
+  FGS_LAUNCH_OK("fgs_feat_coarse_bwd/enc");
+  return 0;
+}
 
 // layout_i: 11 ints (see fill_layout); displace_host: K floats.  Returns x0_cols through *x0_cols_out when non-null.
 FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,

@@ -15,7 +15,7 @@
 //
 // The backward kernel walks the same records per ray: alpha2weight backward (exact reverse chain), NeuS-alpha
 // backward, then scatters d sdf (8 corners) and d gradient (6 taps x 8 corners) into sdf.grad with fp32 atomics.
-#include "fgs_taps.h"
+#include "fgs_march.h"
 
 namespace {
 
@@ -42,49 +42,6 @@ struct MarchArgs {
   int64_t *n_alive, *n_surv, *n_inbbox;
   float *alphainv_last;
 };
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-struct RaySetup {
-  float start[3], dir[3];
-  int64_t n_steps;
-};
-
-// ray/AABB entry + sample count + start/dir: render_utils_kernel.cu:11-79 (same statements as csrc/sampling.hip)
-__device__ __forceinline__ RaySetup ray_setup(const float *o, const float *d, const SceneGeom &g, float near, float far,
-                                              float stepdist) {
-  float a[3], b[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v = (d[c] == 0.f) ? (float)1e-6 : d[c];
-    a[c] = (g.hi[c] - o[c]) / v;
-    b[c] = (g.lo[c] - o[c]) / v;
-  }
-  const float en = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(a[2], b[2]));
-  const float ex = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(a[2], b[2]));
-  const float t_min = fmaxf(fminf(en, far), near), t_max = fmaxf(fminf(ex, far), near);
-  const float rn = fgs_rnorm3(d[0], d[1], d[2]);
-  RaySetup r;
-  r.n_steps = (int64_t)fmax((double)ceilf((t_max - t_min) * rn / stepdist), 1.);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    r.start[c] = fmaf(d[c], t_min, o[c]);
-    r.dir[c] = d[c] / rn;
-  }
-  return r;
-}
-
-// model/nerf.py:525-543 (cos_anneal_ratio = 1, use_mid)
-__device__ __forceinline__ float neus_alpha(float sdf, float gx, float gy, float gz, float vx, float vy, float vz,
-                                            float dist, float inv_s) {
-  const float true_cos = (vx * gx + vy * gy) + vz * gz;
-  const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.f) * 0.0f + fmaxf(-true_cos, 0.f) * 1.0f);
-  const float half = iter_cos * dist * 0.5f;
-  const float prev_cdf = sigmoidf_((sdf - half) * inv_s);
-  const float next_cdf = sigmoidf_((sdf + half) * inv_s);
-  const float a = ((prev_cdf - next_cdf) + 1e-5f) / (prev_cdf + 1e-5f);
-  return fminf(fmaxf(a, 0.f), 1.f);
-}
 
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {

@@ -1,0 +1,311 @@
+// march_coarse.hip -- the fused front half of nerf.forward_coarse (model/nerf.py:943-990), one wavefront per ray.
+//
+// Differences from the fine stage (march.hip), all taken from the reference:
+//   * the SDF value is the trilinear lookup of the SMOOTHED grid (smooth_conv(sdf.grid), :969-971), the gradient is the
+//     trilinear lookup of the central-difference volume of the UN-smoothed grid (:972-973) -- both dense volumes are
+//     produced by csrc/dense.hip once per forward;
+//   * optional voxel-increment mask (MaskGrid nearest-voxel lookup, :962-967) besides the mask cache (:952-959);
+//   * no `alpha > thres` compaction: Alphas2Weights runs on every sample (early termination at T < 1e-3), the
+//     `weights > thres` mask selects the kept samples, and Alphas2Weights runs AGAIN on the kept list (:978-990).
+//     Both exact sequential chains are replayed per 64-step chunk; kept samples behind the second chain's terminating
+//     sample keep weight 0 (the reference's zero-initialised tail) but stay in the output lists.
+// Records are written for the kept samples only; the backward walks the second chain's [i_start, i_end) prefix.
+#include "fgs_march.h"
+
+namespace {
+
+struct IncMask {  // grid.MaskGrid buffers (model/grid.py:270-273), scale / shift by value
+  const uint8_t *world;
+  int sx, sy, sz;
+  float scale[3], shift[3];
+};
+
+struct CoarseArgs {
+  const float *rays_o, *rays_d, *viewdirs;
+  int64_t n_rays;
+  SceneGeom geom;
+  float near, far, stepdist;
+  const float *sdf_smooth;  // [X,Y,Z]
+  const float *gradvol;     // [3,X,Y,Z]
+  float dist, inv_s, thres;
+  const float *mask_grid;
+  SceneGeom mask_geom;
+  float mask_thres;
+  IncMask inc;
+  int max_steps;
+  int *a_step;
+  float *a_alpha, *a_T, *a_weight, *a_sdf, *a_grad;
+  int *a_surv, *surv_slot;
+  int64_t *n_alive, *n_surv, *n_inbbox;
+  float *alphainv_last;
+};
+
+__device__ __forceinline__ GridDesc grad_desc(const SceneGeom &s) {
+  return GridDesc{3, s.X, s.Y, s.Z, (int64_t)s.X * s.Y * s.Z, (int64_t)s.Y * s.Z, (int64_t)s.Z, 1};
+}
+
+// one step of the reference's transmittance recurrence (render_utils_kernel.cu:596-597)
+__device__ __forceinline__ bool chain_step(float &T_cum, float alpha_j) {
+  T_cum = (float)((double)T_cum * (1. - (double)alpha_j));
+  return fgs_uniform((double)T_cum < 1e-3 ? 1 : 0) != 0;
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_fwd(CoarseArgs A) {
+  const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (ray >= A.n_rays) return;
+  const float o[3] = {A.rays_o[3 * ray], A.rays_o[3 * ray + 1], A.rays_o[3 * ray + 2]};
+  const float d[3] = {A.rays_d[3 * ray], A.rays_d[3 * ray + 1], A.rays_d[3 * ray + 2]};
+  const float vx = A.viewdirs[3 * ray], vy = A.viewdirs[3 * ray + 1], vz = A.viewdirs[3 * ray + 2];
+  const RaySetup rs = ray_setup(o, d, A.geom, A.near, A.far, A.stepdist);
+  const int n_steps = (int)fgs_uniform((int64_t)(rs.n_steps < A.max_steps ? rs.n_steps : A.max_steps));
+  const int64_t rec0 = ray * A.max_steps;
+  const GridDesc sd = fgs_sdf_desc(A.geom), gd3 = grad_desc(A.geom);
+
+  float T1 = 1.f, T2 = 1.f;
+  bool term1 = false, term2 = false;
+  int kept_base = 0, active_total = 0, inb_count = 0;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int base = 0; base < n_steps && !term1; base += FGS_WAVE) {
+    const int s = base + lane;
+    const float dist_s = A.stepdist * (float)s;
+    const float px = fmaf(rs.dir[0], dist_s, rs.start[0]);
+    const float py = fmaf(rs.dir[1], dist_s, rs.start[1]);
+    const float pz = fmaf(rs.dir[2], dist_s, rs.start[2]);
+    const bool outb = (A.geom.lo[0] > px) | (A.geom.lo[1] > py) | (A.geom.lo[2] > pz) | (A.geom.hi[0] < px) |
+                      (A.geom.hi[1] < py) | (A.geom.hi[2] < pz);
+    bool in = (s < n_steps) && !outb;
+    inb_count += __popcll(__ballot(in));
+    if (A.mask_grid && in) {
+      const GridDesc md = fgs_sdf_desc(A.mask_geom);
+      const PointIdx mp = fgs_point_to_index(px, py, pz, A.mask_geom.lo, A.mask_geom.hi, md);
+      in = fgs_tri_sample(A.mask_grid, md, 0, fgs_tri_setup(mp.fx, mp.fy, mp.fz)) >= A.mask_thres;
+    }
+    if (A.inc.world && in) {  // render_utils_kernel.cu:385-390
+      const int i = (int)roundf(fmaf(px, A.inc.scale[0], A.inc.shift[0]));
+      const int j = (int)roundf(fmaf(py, A.inc.scale[1], A.inc.shift[1]));
+      const int k = (int)roundf(fmaf(pz, A.inc.scale[2], A.inc.shift[2]));
+      in = fgs_in(i, A.inc.sx) && fgs_in(j, A.inc.sy) && fgs_in(k, A.inc.sz) &&
+           A.inc.world[((int64_t)i * A.inc.sy + j) * A.inc.sz + k] != 0;
+    }
+    float alpha = 0.f, sdf = 0.f, g[3] = {0.f, 0.f, 0.f};
+    if (in) {
+      const PointIdx p = fgs_point_to_index(px, py, pz, A.geom.lo, A.geom.hi, sd);
+      const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
+      sdf = fgs_tri_sample(A.sdf_smooth, sd, 0, t);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = fgs_tri_sample(A.gradvol, gd3, c, t);
+      alpha = neus_alpha(sdf, g[0], g[1], g[2], vx, vy, vz, A.dist, A.inv_s);
+    }
+    // first Alphas2Weights (model/nerf.py:978): every sample, early termination
+    unsigned long long bal = __ballot(in);
+    float T_first = 1.f;
+    int last1 = 64;
+    while (bal) {
+      const int j = __builtin_ctzll(bal);
+      const float aj = fgs_bcast_lane(alpha, j);
+      if (lane == j) T_first = T1;
+      if (chain_step(T1, aj)) {
+        term1 = true;
+        last1 = j;
+        break;
+      }
+      bal &= bal - 1;
+    }
+    const bool kept = in && lane <= last1 && (T_first * alpha > A.thres);  // mask = weights > fast_color_thres (:982)
+    // second Alphas2Weights on the kept list (:990)
+    const unsigned long long kept_bal = __ballot(kept);
+    float T_second = 1.f;  // T is ones-initialised, weight zero-initialised (render_utils_kernel.cu:624-625)
+    bool active = false;
+    if (!term2) {
+      unsigned long long b2 = kept_bal;
+      while (b2) {
+        const int j = __builtin_ctzll(b2);
+        const float aj = fgs_bcast_lane(alpha, j);
+        if (lane == j) {
+          T_second = T2;
+          active = true;
+        }
+        if (chain_step(T2, aj)) {
+          term2 = true;
+          break;
+        }
+        b2 &= b2 - 1;
+      }
+    }
+    const float w2 = active ? T_second * alpha : 0.f;
+    if (kept) {
+      const int k_local = kept_base + __popcll(kept_bal & lt_mask);
+      const int64_t rec = rec0 + k_local;
+      A.a_step[rec] = s;
+      A.a_alpha[rec] = alpha;
+      A.a_T[rec] = T_second;
+      A.a_weight[rec] = w2;
+      A.a_sdf[rec] = sdf;
+      A.a_grad[3 * rec + 0] = g[0];
+      A.a_grad[3 * rec + 1] = g[1];
+      A.a_grad[3 * rec + 2] = g[2];
+      A.a_surv[rec] = k_local;          // every kept sample is a survivor
+      A.surv_slot[rec0 + k_local] = k_local;
+    }
+    kept_base += __popcll(kept_bal);
+    active_total += __popcll(__ballot(active));
+  }
+  if (lane == 0) {
+    A.n_alive[ray] = active_total;   // the second chain's [i_start, i_end) prefix of the kept list
+    A.n_surv[ray] = kept_base;
+    A.n_inbbox[ray] = inb_count;
+    A.alphainv_last[ray] = T2;
+  }
+}
+
+struct CoarseBwdArgs {
+  const float *rays_o, *rays_d, *viewdirs;
+  int64_t n_rays;
+  SceneGeom geom;
+  float near, far, stepdist, dist, inv_s;
+  int max_steps;
+  const int *a_step;
+  const float *a_alpha, *a_T, *a_weight, *a_sdf, *a_grad;
+  const int64_t *n_alive, *n_surv, *surv_off;
+  const float *alphainv_last;
+  const float *g_weights, *g_last, *g_gradient;  // [M_s], [n_rays] or null, [M_s,3] or null
+  float *d_sdf_smooth;                           // [X,Y,Z]   accumulated with atomics
+  float *d_gradvol;                              // [3,X,Y,Z] accumulated with atomics
+};
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A) {
+  const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  if (ray >= A.n_rays) return;
+  const int n_active = (int)fgs_uniform(A.n_alive[ray]), n_kept = (int)fgs_uniform(A.n_surv[ray]);
+  if (n_kept == 0) return;
+  const int64_t rec0 = ray * A.max_steps, s_off = fgs_uniform(A.surv_off[ray]);
+  const float o[3] = {A.rays_o[3 * ray], A.rays_o[3 * ray + 1], A.rays_o[3 * ray + 2]};
+  const float d[3] = {A.rays_d[3 * ray], A.rays_d[3 * ray + 1], A.rays_d[3 * ray + 2]};
+  const float vx = A.viewdirs[3 * ray], vy = A.viewdirs[3 * ray + 1], vz = A.viewdirs[3 * ray + 2];
+  const RaySetup rs = ray_setup(o, d, A.geom, A.near, A.far, A.stepdist);
+  const GridDesc sd = fgs_sdf_desc(A.geom), gd3 = grad_desc(A.geom);
+
+  float back_cum = (A.g_last ? A.g_last[ray] : 0.f) * A.alphainv_last[ray];
+  for (int top = n_kept; top > 0; top -= FGS_WAVE) {
+    const int cnt = top < FGS_WAVE ? top : FGS_WAVE;
+    const int k_local = top - 1 - lane;
+    const bool act = lane < cnt;
+    const bool in_chain = act && k_local < n_active;   // inside the second chain's [i_start, i_end)
+    const int64_t rec = rec0 + (act ? k_local : 0);
+    float gw = 0.f, w = 0.f, tt = 0.f, alpha = 0.f;
+    if (in_chain) {
+      gw = A.g_weights[s_off + k_local];
+      w = A.a_weight[rec];
+      tt = A.a_T[rec];
+      alpha = A.a_alpha[rec];
+    }
+    float my_back = 0.f;
+    for (int j = 0; j < cnt; ++j) {  // lanes outside the chain carry gw = w = 0: no effect on the recurrence
+      if (lane == j) my_back = back_cum;
+      back_cum = fmaf(fgs_bcast_lane(gw, j), fgs_bcast_lane(w, j), back_cum);
+    }
+    if (!act) continue;
+    float d_sdf = 0.f, dg[3] = {0.f, 0.f, 0.f};
+    if (in_chain) {
+      const double den = (double)(1.f - alpha) + 1e-10;
+      const float g_alpha = (float)((double)(gw * tt) - (double)my_back / den);
+      const AlphaGrad ag = neus_alpha_bwd(g_alpha, A.a_sdf[rec], A.a_grad[3 * rec], A.a_grad[3 * rec + 1],
+                                          A.a_grad[3 * rec + 2], vx, vy, vz, A.dist, A.inv_s);
+      d_sdf = ag.d_sdf;
+      dg[0] = ag.dgx; dg[1] = ag.dgy; dg[2] = ag.dgz;
+    }
+    if (A.g_gradient) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dg[c] += A.g_gradient[3 * (s_off + k_local) + c];
+    }
+    if (d_sdf == 0.f && dg[0] == 0.f && dg[1] == 0.f && dg[2] == 0.f) continue;
+    const float dist_s = A.stepdist * (float)A.a_step[rec];
+    const float px = fmaf(rs.dir[0], dist_s, rs.start[0]);
+    const float py = fmaf(rs.dir[1], dist_s, rs.start[1]);
+    const float pz = fmaf(rs.dir[2], dist_s, rs.start[2]);
+    const PointIdx p = fgs_point_to_index(px, py, pz, A.geom.lo, A.geom.hi, sd);
+    const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
+    if (d_sdf != 0.f) fgs_tri_scatter(A.d_sdf_smooth, sd, 0, t, d_sdf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (dg[c] != 0.f) fgs_tri_scatter(A.d_gradvol, gd3, c, t, dg[c]);
+  }
+}
+
+SceneGeom geom_make(const float *lo, const float *hi, int X, int Y, int Z, float voxel_size) {
+  SceneGeom g;
+  for (int c = 0; c < 3; ++c) { g.lo[c] = lo[c]; g.hi[c] = hi[c]; }
+  g.X = X; g.Y = Y; g.Z = Z; g.voxel_size = voxel_size;
+  return g;
+}
+
+}  // namespace
+
+FGS_API int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                                 const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near,
+                                 float far, float stepdist, const float *sdf_smooth, const float *gradvol, float dist,
+                                 float inv_s, float thres, const float *mask_grid, const float *mask_min_host,
+                                 const float *mask_max_host, int mX, int mY, int mZ, float mask_thres,
+                                 const uint8_t *inc_world, int iX, int iY, int iZ, const float *inc_scale_host,
+                                 const float *inc_shift_host, int max_steps, int *a_step, float *a_alpha, float *a_T,
+                                 float *a_weight, float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive,
+                                 int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream) {
+  FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_coarse_fwd: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return 0;
+  FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && sdf_smooth && gradvol && a_step && a_alpha &&
+                  a_T && a_weight && a_sdf && a_grad && a_surv && surv_slot && n_alive && n_surv && n_inbbox && alphainv_last,
+              FGS_E_INVALID, "fgs_march_coarse_fwd: null pointer");
+  FGS_REQUIRE(X > 1 && Y > 1 && Z > 1 && max_steps > 0 && stepdist > 0.f && thres > 0.f, FGS_E_INVALID,
+              "fgs_march_coarse_fwd: bad geometry or fast_color_thres <= 0");
+  CoarseArgs A;
+  A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
+  A.geom = geom_make(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf_smooth = sdf_smooth; A.gradvol = gradvol;
+  A.dist = dist; A.inv_s = inv_s; A.thres = thres;
+  A.mask_grid = mask_grid; A.mask_geom = A.geom; A.mask_thres = mask_thres;
+  if (mask_grid) {
+    FGS_REQUIRE(mask_min_host && mask_max_host && mX > 1 && mY > 1 && mZ > 1, FGS_E_INVALID, "fgs_march_coarse_fwd: bad mask cache");
+    A.mask_geom = geom_make(mask_min_host, mask_max_host, mX, mY, mZ, 0.f);
+  }
+  A.inc.world = inc_world; A.inc.sx = iX; A.inc.sy = iY; A.inc.sz = iZ;
+  for (int c = 0; c < 3; ++c) { A.inc.scale[c] = 0.f; A.inc.shift[c] = 0.f; }
+  if (inc_world) {
+    FGS_REQUIRE(inc_scale_host && inc_shift_host && iX > 0 && iY > 0 && iZ > 0, FGS_E_INVALID, "fgs_march_coarse_fwd: bad inc mask");
+    for (int c = 0; c < 3; ++c) { A.inc.scale[c] = inc_scale_host[c]; A.inc.shift[c] = inc_shift_host[c]; }
+  }
+  A.max_steps = max_steps;
+  A.a_step = a_step; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf; A.a_grad = a_grad;
+  A.a_surv = a_surv; A.surv_slot = surv_slot; A.n_alive = n_alive; A.n_surv = n_surv; A.n_inbbox = n_inbbox;
+  A.alphainv_last = alphainv_last;
+  hipLaunchKernelGGL(k_march_coarse_fwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
+  FGS_LAUNCH_OK("fgs_march_coarse_fwd");
+  return 0;
+}
+
+FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                                 const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near,
+                                 float far, float stepdist, float dist, float inv_s, int max_steps, const int *a_step,
+                                 const float *a_alpha, const float *a_T, const float *a_weight, const float *a_sdf,
+                                 const float *a_grad, const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off,
+                                 const float *alphainv_last, const float *g_weights, const float *g_last,
+                                 const float *g_gradient, float *d_sdf_smooth, float *d_gradvol, fgs_stream_t stream) {
+  FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_coarse_bwd: n_rays=%lld", (long long)n_rays);
+  if (n_rays == 0) return 0;
+  FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_alpha && a_T && a_weight && a_sdf &&
+                  a_grad && n_alive && n_surv && surv_off && alphainv_last && g_weights && d_sdf_smooth && d_gradvol,
+              FGS_E_INVALID, "fgs_march_coarse_bwd: null pointer");
+  CoarseBwdArgs A;
+  A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
+  A.geom = geom_make(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
+  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.max_steps = max_steps;
+  A.a_step = a_step; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf; A.a_grad = a_grad;
+  A.n_alive = n_alive; A.n_surv = n_surv; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
+  A.g_weights = g_weights; A.g_last = g_last; A.g_gradient = g_gradient;
+  A.d_sdf_smooth = d_sdf_smooth; A.d_gradvol = d_gradvol;
+  hipLaunchKernelGGL(k_march_coarse_bwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
+  FGS_LAUNCH_OK("fgs_march_coarse_bwd");
+  return 0;
+}

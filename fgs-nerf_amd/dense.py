@@ -1,0 +1,75 @@
+"""Per-iteration full-volume operators of the coarse stages as HIP stencil kernels with autograd.
+
+``smooth3d(grid, taps)``      = ``nn.Conv3d(1, 1, k, padding=k//2, padding_mode='replicate')(grid)`` with the frozen
+                                Gaussian taps of model/nerf.py:260-272 (the coarse stages smooth the SDF grid on
+                                every forward, :791 / :969).
+``sdf_gradient_volume(g, vs)`` = ``nerf.neus_sdf_gradient(mode='interpolate')`` (model/nerf.py:485-494): [1,3,X,Y,Z].
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import call, ptr, stream
+
+
+def _taps_c(taps: torch.Tensor):
+    t = taps.detach().float().cpu().contiguous().reshape(-1)
+    return (ctypes.c_float * t.numel())(*t.tolist())
+
+
+def _check_grid(g: torch.Tensor):
+    if not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 5 and g.shape[0] == 1 and g.shape[1] == 1):
+        raise RuntimeError("expected a float32 CUDA grid of shape [1,1,X,Y,Z]")
+    return int(g.shape[2]), int(g.shape[3]), int(g.shape[4])
+
+
+class _Smooth3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, taps_c, k):
+        X, Y, Z = _check_grid(grid)
+        g = grid.contiguous()
+        out = torch.empty_like(g)
+        call("fgs_smooth3d_fwd", ptr(g), X, Y, Z, k, taps_c, ptr(out), stream())
+        ctx.meta = (X, Y, Z, k, taps_c)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        X, Y, Z, k, taps_c = ctx.meta
+        d_out = d_out.contiguous()
+        d_in = torch.empty_like(d_out)
+        call("fgs_smooth3d_bwd", ptr(d_out), X, Y, Z, k, taps_c, ptr(d_in), stream())
+        return d_in, None, None
+
+
+def smooth3d(grid: torch.Tensor, taps: torch.Tensor, taps_c=None) -> torch.Tensor:
+    """taps: [k,k,k] (or Conv3d weight [1,1,k,k,k]) normalised Gaussian weights."""
+    k = int(taps.shape[-1])
+    return _Smooth3d.apply(grid, taps_c if taps_c is not None else _taps_c(taps), k)
+
+
+class _GradVol(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, voxel_size):
+        X, Y, Z = _check_grid(grid)
+        g = grid.contiguous()
+        out = torch.empty(1, 3, X, Y, Z, dtype=torch.float32, device=g.device)
+        call("fgs_sdf_gradvol_fwd", ptr(g), X, Y, Z, float(voxel_size), ptr(out), stream())
+        ctx.meta = (X, Y, Z, float(voxel_size))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        X, Y, Z, vs = ctx.meta
+        d_out = d_out.contiguous()
+        d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
+        call("fgs_sdf_gradvol_bwd", ptr(d_out), X, Y, Z, vs, ptr(d_in), 0, stream())
+        return d_in, None
+
+
+def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    return _GradVol.apply(grid, float(voxel_size))

@@ -324,6 +324,163 @@ class _FusedFine(torch.autograd.Function):
         return tuple(grads)
 
 
+def supports_coarse(model) -> bool:
+    """Coarse-stage configurations ('coarse', 'geometry_searching') the fused kernels cover."""
+    from .nerf import mlp_layers
+    if model.stage not in ('coarse', 'geometry_searching') or model.s_learn or not (model.fast_color_thres > 0):
+        return False
+    if getattr(model, 'grad_mode', 'interpolate') != 'interpolate':
+        return False
+    if model.smooth_sdf and int(model.smooth_conv.weight.shape[-1]) > 7:
+        return False
+    fl = mlp_layers(model.refnet)
+    cols = (model.k0_dim + (3 + 6 * len(model.posfreq)) + (3 + 6 * len(model.reffreq)) + 3 +
+            ((3 + 6 * len(model.viewfreq)) if model.use_viewdir else 0))
+    fw = fl[0].out_features
+    if cols != fl[0].in_features or fw % 4 or fw > 256 or len(fl) < 2 or fl[-1].out_features != 3:
+        return False
+    if any(l.out_features != fw for l in fl[:-1]):
+        return False
+    g = model.sdf.grid
+    return g.is_cuda and g.is_contiguous() and model.k0.grid.is_cuda
+
+
+class _FusedCoarse(torch.autograd.Function):
+    """inputs: smoothed SDF grid [1,1,X,Y,Z], gradient volume [1,3,X,Y,Z] (both autograd nodes of dense.py over
+    sdf.grid), k0 grid, then (weight, bias) of every refnet Linear."""
+
+    @staticmethod
+    def forward(ctx, run, sdf_smooth, gradvol, k0_grid, *mlp):
+        dev = sdf_smooth.device
+        g, N, st, ms, ws = run.geom, run.n_rays, stream(), run.max_steps, run.workspace
+        sdf_smooth, gradvol = sdf_smooth.contiguous(), gradvol.contiguous()
+        use_mc = run.mask_grid is not None
+        inc = run.inc
+        call("fgs_march_coarse_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+             run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), run.dist, run.inv_s, run.thres,
+             ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
+             g.mask[3] if use_mc else 0.0, ptr(inc[0]) if inc else None, *(inc[1] if inc else (0, 0, 0)),
+             inc[2] if inc else None, inc[3] if inc else None, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']),
+             ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
+             ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
+        call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        M = int(ws['surv_off'][N].item())          # the one host read of the step
+        run.M = M
+        ray_id = torch.empty(M, dtype=I64, device=dev)
+        step_id = torch.empty(M, dtype=I64, device=dev)
+        rec_idx = torch.empty(M, dtype=I32, device=dev)
+        weights = torch.empty(M, dtype=F32, device=dev)
+        alpha = torch.empty(M, dtype=F32, device=dev)
+        sdf = torch.empty(M, dtype=F32, device=dev)
+        gradient = torch.empty(M, 3, dtype=F32, device=dev)
+        pts = torch.empty(M, 3, dtype=F32, device=dev)
+        call("fgs_surv_compact", N, M, ptr(ws['surv_off']), ms, ptr(ws['surv_slot']), ptr(ws['a_step']), ptr(ws['a_alpha']),
+             ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(run.rays_o), ptr(run.rays_d), g.lo_c, g.hi_c,
+             g.X, g.Y, g.Z, run.near, 1e9, run.stepdist, ptr(ray_id), ptr(step_id), ptr(rec_idx), ptr(weights), ptr(alpha),
+             ptr(sdf), ptr(gradient), ptr(pts), st)
+        ldx0 = run.ldx0
+        X0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+        normal = torch.empty(M, 3, dtype=F32, device=dev)
+        kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
+        call("fgs_feat_coarse_fwd", M, ptr(ray_id), ptr(pts), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c, g.X, g.Y,
+             g.Z, run.layout_i, ptr(k0_grid), ksC, ksX, ksY, ksZ, ptr(X0), ptr(normal), st)
+        n_ref = run.n_ref
+        ref_w = [mlp[2 * i] for i in range(n_ref)]
+        ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
+        fw = ref_w[0].shape[0]
+        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
+        acts = [X0]
+        a = X0
+        for i in range(n_ref - 1):
+            out = torch.empty(M, fw, dtype=F32, device=dev)
+            _gemm(fo.GEMM_NT, a, V0p if i == 0 else ref_w[i].detach(), out, M, fw, ldx0 if i == 0 else fw,
+                  bias=ref_b[i].detach(), relu=True, logical=(M, fw, ref_w[i].shape[1]))
+            a = out
+            acts.append(out)
+        rgb = torch.empty(M, 3, dtype=F32, device=dev)
+        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
+        rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
+        sigmoid_rgb = torch.empty(N, 3, dtype=F32, device=dev)
+        pre_rgb = torch.empty(N, 3, dtype=F32, device=dev)
+        pre_sig = torch.empty(N, 3, dtype=F32, device=dev)
+        normal_marched = torch.empty(N, 3, dtype=F32, device=dev) if run.render_grad else None
+        depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
+        call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
+             ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+        alphainv_last = ws['alphainv_last'].clone()
+        run.saved = dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts, V0p=V0p,
+                         pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ))
+        run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
+                          n_inbbox=ws['n_inbbox'])
+        ctx.run = run
+        ctx.save_for_backward(k0_grid, *mlp)
+        ctx.mark_non_differentiable(ray_id, alpha, gradient)
+        return rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
+        run = ctx.run
+        k0_grid, *mlp = ctx.saved_tensors
+        S, g, N, M, st, ws = run.saved, run.geom, run.n_rays, run.M, stream(), run.workspace
+        dev = k0_grid.device
+        n_ref = run.n_ref
+        ref_w = [mlp[2 * i] for i in range(n_ref)]
+        fw, ldx0 = ref_w[0].shape[0], run.ldx0
+
+        def c(t):
+            return None if t is None else t.contiguous()
+        g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
+            c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
+        d_out = torch.empty(M, 3, dtype=F32, device=dev)
+        d_w = torch.empty(M, dtype=F32, device=dev)
+        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
+             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
+        shapes = [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in ref_w] + [(fw, ldx0)]
+        sizes = [(int(np.prod(s)) + 3) // 4 * 4 for s in shapes]
+        flat = torch.zeros(sum(sizes), dtype=F32, device=dev)
+        views, off = [], 0
+        for s, n in zip(shapes, sizes):
+            views.append(flat[off:off + int(np.prod(s))].view(*s))
+            off += n
+        gw, gb, gV0p = views[:n_ref], views[n_ref:2 * n_ref], views[-1]
+        acts = S['acts']
+        a_last = acts[n_ref - 1]
+        dY = torch.empty(M, fw, dtype=F32, device=dev)
+        call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
+             ptr(gb[-1]), ptr(gb[n_ref - 2]), st)
+        dX0 = None
+        for i in range(n_ref - 2, -1, -1):
+            a_in = acts[i]
+            if i == 0:
+                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldx0, M, logical=(fw, ref_w[0].shape[1], M))
+                dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
+            else:
+                _gemm(fo.GEMM_TN, dY, a_in, gw[i], fw, fw, M)
+                d_in = torch.empty(M, fw, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dY, ref_w[i], d_in, M, fw, fw, mask=a_in, colsum=gb[i - 1])
+                dY = d_in
+        gw[0] = gV0p[:, :ref_w[0].shape[1]]
+        grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+        g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
+        ksC, ksX, ksY, ksZ = S['k0_strides']
+        call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
+             g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
+             ptr(g_grad_s), st)
+        d_smooth = torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev)
+        d_gradvol = torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev)
+        call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+             run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']), ptr(ws['a_alpha']),
+             ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['n_alive']), ptr(ws['n_surv']),
+             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d_smooth),
+             ptr(d_gradvol), st)
+        grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]
+        for i in range(n_ref):
+            grads += [gw[i].contiguous(), gb[i].contiguous()]
+        return tuple(grads)
+
+
 def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tensor]:
     """Per-(n_rays, max_steps) record arrays, cached on the model: no allocator traffic in the steady state."""
     key = (n_rays, max_steps, str(dev))
@@ -363,9 +520,8 @@ class LazyResult(dict):
         return self[k] if k in self else default
 
 
-def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
-    from .nerf import mlp_layers
-    dev = rays_o.device
+def _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, default_depth):
+    """The per-call scalars both stages share; returns (run, s_val)."""
     run = _Run()
     run.geom = _geom(model)
     run.n_rays = N = len(rays_o)
@@ -385,11 +541,89 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     model._s_val_host = float(s32)
     run.inv_s = float(np.float32(1.0) / s32)
     run.max_steps = int(math.ceil(run.geom.diag / run.stepdist)) + 2
-    run.workspace = _workspace(model, N, run.max_steps, dev)
+    run.workspace = _workspace(model, N, run.max_steps, rays_o.device)
+    run.render_grad = bool(render_kwargs.get('render_grad', False))
+    run.render_depth = bool(render_kwargs.get('render_depth', default_depth))
+    return run, s_val
+
+
+def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
+    """nerf.forward_coarse (model/nerf.py:943-1075) through the fused kernels; same ret_dict."""
+    from . import dense
+    from .nerf import mlp_layers
+    dev = rays_o.device
+    run, s_val = _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, default_depth=True)
+    N, g = run.n_rays, run.geom
+    fl = mlp_layers(model.refnet)
+    run.n_ref = len(fl)
+    cols = fl[0].in_features
+    run.ldx0 = (cols + 3) // 4 * 4
+    run.layout_i = (ctypes.c_int * 6)(model.k0_dim, len(model.posfreq), len(model.viewfreq), len(model.reffreq),
+                                      int(model.use_viewdir), run.ldx0)
+    # the mask cache only prunes in stage 'coarse' (model/nerf.py:951)
+    run.mask_grid = model.mask_cache.sdf_mask if (model.stage == 'coarse' and model.mask_cache is not None) else None
+    run.inc = None
+    if model.inc_mask is not None:
+        im = model.inc_mask
+        key = id(im)
+        cached = getattr(model, '_fused_inc', None)
+        if cached is None or cached[0] != key:
+            world = im.mask.to(torch.uint8).contiguous()
+            sc = im.xyz2ijk_scale.detach().cpu().float().tolist()
+            sh = im.xyz2ijk_shift.detach().cpu().float().tolist()
+            cached = (key, (world, tuple(int(s) for s in world.shape), (ctypes.c_float * 3)(*sc), (ctypes.c_float * 3)(*sh)))
+            model._fused_inc = cached
+        run.inc = cached[1]
+    # dense per-iteration volumes (row a6): smoothed SDF grid and central-difference gradient volume, both autograd
+    # nodes over sdf.grid; model.gradient stays differentiable for density_total_variation (model/nerf.py:440-446)
+    if model.smooth_sdf:
+        taps = getattr(model, '_fused_taps', None)
+        if taps is None or taps[0] is not model.smooth_conv:
+            taps = (model.smooth_conv, dense._taps_c(model.smooth_conv.weight))
+            model._fused_taps = taps
+        sdf_smooth = dense.smooth3d(model.sdf.grid, model.smooth_conv.weight, taps[1])
+    else:
+        sdf_smooth = model.sdf.grid
+    model.gradient = dense.sdf_gradient_volume(model.sdf.grid, g.voxel_size)
+    mlp = []
+    for layer in fl:
+        mlp += [layer.weight, layer.bias]
+    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
+        run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
+    ex = run.extras
+    depth = ex['depth']
+
+    def lazy_outbbox():
+        with torch.no_grad():
+            pts, _, _, mask_outbbox, _ = model.sample_ray(rays_o=rays_o, rays_d=rays_d, **render_kwargs)
+            if run.mask_grid is not None:
+                mask_outbbox[~mask_outbbox] |= ~model.mask_cache(pts)
+        return mask_outbbox
+
+    def lazy_mask():
+        """`weights > thres` of the first Alphas2Weights over the (mask-cache / inc-mask filtered) sample list
+        (model/nerf.py:982), rebuilt with the operator-at-a-time path only when somebody reads it."""
+        keep = model.gradient
+        with torch.no_grad():
+            mask = model._forward_coarse_composed(rays_o, rays_d, viewdirs, global_step, **render_kwargs)['mask']
+        model.gradient = keep
+        return mask
+
+    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id, 'viewdirs': run.viewdirs[ray_id],
+             'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
+             'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
+             'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
+             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs}
+    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox})
+
+
+def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
+    from .nerf import mlp_layers
+    dev = rays_o.device
+    run, s_val = _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, default_depth=False)
+    N = run.n_rays
     run.layout_i, run.displace, run.ldx0, run.ldz, _ = _layout(model, run.geom)
     run.mask_grid = model.mask_cache.sdf_mask if model.mask_cache is not None else None
-    run.render_grad = bool(render_kwargs.get('render_grad', False))
-    run.render_depth = bool(render_kwargs.get('render_depth', False))
     rl, fl = mlp_layers(model.rgbnet), mlp_layers(model.refnet)
     run.n_rgb, run.n_ref = len(rl), len(fl)
     mlp = []

@@ -454,6 +454,10 @@ class nerf(torch.nn.Module):
 
     def forward_coarse(self, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
         """model/nerf.py:943-1075."""
+        if self.fused is not False and rays_o.is_cuda:
+            from . import fused
+            if fused.supports_coarse(self):
+                return fused.forward_coarse(self, rays_o, rays_d, viewdirs, global_step, **render_kwargs)
         return self._forward_coarse_composed(rays_o, rays_d, viewdirs, global_step, **render_kwargs)
 
     def _composite(self, weights, rgb, ray_id, N, bg, normal, step_id, dist, render_grad, render_depth):

@@ -308,6 +308,63 @@ int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, co
                       const float *pre_sig, const float *g_rgb_marched, const float *g_sigmoid_rgb, const float *g_raw_rgb,
                       const float *g_weights_direct, float bg, float *d_out, float *d_w, fgs_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Coarse stages (nerf.forward_coarse, model/nerf.py:943-1075) -- SURVEY.md 8a row a6 and BASELINE config 3.
+ * ------------------------------------------------------------------------------------------------------------------
+ * Dense per-iteration volume operators.
+ * fgs_smooth3d_*: nn.Conv3d(1,1,k,padding=k//2,padding_mode='replicate') with the frozen Gaussian taps of
+ *   model/nerf.py:260-278 (`smooth_conv`, applied every forward at :969).  taps_host: k^3 floats on the HOST in torch's
+ *   weight order; k odd, <= 7.  in/out [X,Y,Z] fp32, must not alias.  The backward is the exact adjoint (gather form).
+ * fgs_sdf_gradvol_*: neus_sdf_gradient(mode='interpolate') (model/nerf.py:485-494): grad3 [3,X,Y,Z], central
+ *   differences / 2 / voxel_size, zero on the two boundary faces of each axis.  bwd: d_sdf (+)= adjoint(d_grad3). */
+int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const float *taps_host, float *out, fgs_stream_t stream);
+int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *d_in,
+                     fgs_stream_t stream);
+int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, fgs_stream_t stream);
+int fgs_sdf_gradvol_bwd(const float *d_grad3, int X, int Y, int Z, float voxel_size, float *d_sdf, int accumulate,
+                        fgs_stream_t stream);
+
+/* Fused front half of forward_coarse (model/nerf.py:946-990), one wavefront per ray: sample_pts_on_rays, optional mask
+ * cache (stage 'coarse' only, :952-959) and voxel-increment MaskGrid (:962-967; inc_world uint8 [iX,iY,iZ] with the
+ * MaskGrid's xyz2ijk scale / shift on the host, NULL = none), trilinear lookups of the smoothed SDF grid [X,Y,Z] and of
+ * the gradient volume [3,X,Y,Z], NeuS alpha, Alphas2Weights over every sample, `weights > thres` (thres > 0 required),
+ * Alphas2Weights again over the kept list.  Record arrays as in fgs_march_fine_fwd, but holding the KEPT samples only
+ * (n_surv[ray] of them, a_surv[rec] = its index); n_alive[ray] = how many of them the second chain reached (the rest
+ * carry weight 0, T 1).  fgs_surv_compact then builds the flat result lists exactly as for the fine stage. */
+int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                         const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near, float far,
+                         float stepdist, const float *sdf_smooth, const float *gradvol, float dist, float inv_s, float thres,
+                         const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
+                         int mZ, float mask_thres, const uint8_t *inc_world, int iX, int iY, int iZ,
+                         const float *inc_scale_host, const float *inc_shift_host, int max_steps, int *a_step,
+                         float *a_alpha, float *a_T, float *a_weight, float *a_sdf, float *a_grad, int *a_surv,
+                         int *surv_slot, int64_t *n_alive, int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last,
+                         fgs_stream_t stream);
+/* Backward of the second Alphas2Weights + NeuS alpha + the two trilinear lookups: g_weights [M_s], g_last [n_rays]
+ * (may be NULL), g_gradient [M_s,3] (gradient reaching the sampled gradient vectors through the features, may be NULL)
+ * -> atomically accumulated d_sdf_smooth [X,Y,Z] and d_gradvol [3,X,Y,Z] (not zeroed here).  The first
+ * Alphas2Weights only selects samples and carries no gradient (its weights are overwritten at :990). */
+int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
+                         const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near, float far,
+                         float stepdist, float dist, float inv_s, int max_steps, const int *a_step, const float *a_alpha,
+                         const float *a_T, const float *a_weight, const float *a_sdf, const float *a_grad,
+                         const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off, const float *alphainv_last,
+                         const float *g_weights, const float *g_last, const float *g_gradient, float *d_sdf_smooth,
+                         float *d_gradvol, fgs_stream_t stream);
+
+/* Coarse-stage MLP operand rows X0 [M, ldx0] = torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb]) (zero padded),
+ * model/nerf.py:992-1009.  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, ldx0}. */
+int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient, const float *viewdirs,
+                        const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, const int *layout_i,
+                        const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *X0,
+                        float *normal_out, fgs_stream_t stream);
+/* dX0 [M, ldx0] (+ optional direct gradient g_normal [M,3]) -> scatter-add into k0_grad_grid, g_gradient [M,3] for
+ * fgs_march_coarse_bwd. */
+int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient, const float *viewdirs,
+                        const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, const int *layout_i,
+                        const float *X0, const float *dX0, const float *g_normal, float *k0_grad_grid, int64_t ksC,
+                        int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient, fgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
