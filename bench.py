@@ -33,14 +33,14 @@ GLOBAL_STEP = 1000
 
 
 def make_optimizer(model):
-    """Fine-stage param groups (config/shiny_blender.py:184-187,214-216; model/nerf_training.py:9-37)."""
+    """Stage param groups (config/shiny_blender.py:184-187,214-216; model/nerf_training.py:9-37)."""
     from fgs_nerf_amd.adam import MaskedAdam
-    return MaskedAdam([
-        {'params': [model.k0.grid], 'lr': 0.1, 'name': 'k0', 'skip_zero_grad': True},
-        {'params': [model.sdf.grid], 'lr': 0.005, 'name': 'sdf', 'skip_zero_grad': False},
-        {'params': list(model.rgbnet.parameters()), 'lr': 1e-3, 'name': 'rgbnet', 'skip_zero_grad': False},
-        {'params': list(model.refnet.parameters()), 'lr': 1e-3, 'name': 'refnet', 'skip_zero_grad': False}],
-        betas=(0.9, 0.99))
+    groups = [{'params': [model.k0.grid], 'lr': 0.1, 'name': 'k0', 'skip_zero_grad': True},
+              {'params': [model.sdf.grid], 'lr': 0.005, 'name': 'sdf', 'skip_zero_grad': False}]
+    if model.rgbnet is not None:
+        groups.append({'params': list(model.rgbnet.parameters()), 'lr': 1e-3, 'name': 'rgbnet', 'skip_zero_grad': False})
+    groups.append({'params': list(model.refnet.parameters()), 'lr': 1e-3, 'name': 'refnet', 'skip_zero_grad': False})
+    return MaskedAdam(groups, betas=(0.9, 0.99))
 
 
 def train_step(model, opt, averager, batch, n_rays_global):
@@ -49,7 +49,7 @@ def train_step(model, opt, averager, batch, n_rays_global):
     ro, rd, vd, target = batch
     res = model(ro, rd, vd, global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
     # nerf_training.py:308-327; two HIP launches each way on the fused path, plain torch on the composed path
-    loss = fused_render_losses(res, target, synth.FINE_LOSS, model)
+    loss = fused_render_losses(res, target, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     averager.average()
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--composed", action="store_true", help="operator-at-a-time HIP path instead of the fused kernels")
+    ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
+                    help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -118,7 +120,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    model = synth.build_model(GRID, synth.FINE_MODEL, device=dev, fused=False if args.composed else None)
+    model = synth.build_model(GRID, synth.FINE_MODEL if args.stage == "fine" else synth.COARSE_MODEL, device=dev,
+                              fused=False if args.composed else None)
     opt = make_optimizer(model)
     averager = GradAverager(model.parameters())
     n_global = RAYS_PER_GPU * world
@@ -172,13 +175,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 160^3 sdf(1ch)+k0(12ch) fine-stage training step "
-                                   "(forward_fine + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step",
+            "config": {"workload": ("configs[1]: 160^3 sdf(1ch)+k0(12ch) fine-stage training step "
+                                    "(forward_fine + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step")
+                       if args.stage == "fine" else
+                       ("configs[2] path at the bench size: 160^3 coarse-stage training step (5^3 smoothing + gradient "
+                        "volume + forward_coarse + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step"),
                        "grid": GRID, "rays_per_gpu": RAYS_PER_GPU, "inbbox_samples_per_step_per_gpu": int(sum(n_inbbox) / len(n_inbbox)),
                        "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
         }
         line["roofline"] = fused.roofline_report()
-        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine") else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
