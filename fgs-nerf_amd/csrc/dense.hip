@@ -3,8 +3,9 @@
 //     taps (model/nerf.py:260-278, applied every forward at :791/:969), forward and backward;
 //   * the central-difference gradient volume neus_sdf_gradient(mode='interpolate') (model/nerf.py:485-494),
 //     forward and backward.
-// Both are pure streaming stencils over [X,Y,Z] fp32 (16 MB at 160^3): one thread per voxel, neighbours served by
-// L1/L2; the backward passes are written as gathers (no atomics).
+// The smoothing is a direct k^3-tap convolution tiled through LDS (no separability assumed: the taps are whatever the
+// Conv3d holds); its backward is the same kernel run as the adjoint on the padded domain followed by a fold of the
+// replicate-padding halo -- deterministic, no atomics.  The gradient volume is a pure streaming stencil.
 #include "fgs_common.h"
 
 namespace {
@@ -18,65 +19,100 @@ struct Conv3 {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// out[x,y,z] = sum_t w[t] * in[clamp(x+tx), clamp(y+ty), clamp(z+tz)]     (replicate padding)
-__global__ __launch_bounds__(FGS_BLOCK) void k_smooth3d_fwd(const float *__restrict__ in, Conv3 c,
+// Tiled direct convolution: out[o] = sum_t w[t] * fetch(o + t - shift), t in [0,k)^3 in (dx, dy, dz) order.
+//   REPL = true : fetch(q) = in[clamp(q)]               (forward, replicate padding, shift = k/2)
+//   REPL = false: fetch(q) = q inside ? in[q] : 0       (adjoint on the padded domain, shift = k-1, flipped taps)
+// One 256-thread block produces an 8 x 8 x 32 output tile from an LDS halo tile of (8+K-1)(8+K-1)(32+K-1) values
+// (20 KB for K = 5); a thread owns 8 consecutive z outputs of one (x, y) column and slides an (8+K-1)-value register
+// window over each of the K*K tap rows: (8+K-1) LDS reads per 8K FMAs.  The accumulation order per output is the plain
+// (dx, dy, dz) fmaf chain, the same order the one-thread-per-voxel form used.
+constexpr int CT_X = 8, CT_Y = 8, CT_Z = 32, CT_ZPT = 8;
+
+template <int K, bool REPL>
+__global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restrict__ in, int nx, int ny, int nz,
+                                                            Conv3 c /* X,Y,Z = OUTPUT dims */, int shift,
                                                             float *__restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t N = (int64_t)c.X * c.Y * c.Z;
-  if (idx >= N) return;
-  const int z = (int)(idx % c.Z), y = (int)((idx / c.Z) % c.Y), x = (int)(idx / ((int64_t)c.Z * c.Y));
-  const int r = c.k / 2;
-  float acc = 0.f;
-  for (int dx = 0; dx < c.k; ++dx) {
-    const int xx = clampi(x + dx - r, 0, c.X - 1);
-    for (int dy = 0; dy < c.k; ++dy) {
-      const int yy = clampi(y + dy - r, 0, c.Y - 1);
-      const float *row = in + ((int64_t)xx * c.Y + yy) * c.Z;
-      const float *wr = c.w + (dx * c.k + dy) * c.k;
-      for (int dz = 0; dz < c.k; ++dz) acc = fmaf(wr[dz], row[clampi(z + dz - r, 0, c.Z - 1)], acc);
-    }
+  constexpr int LX = CT_X + K - 1, LY = CT_Y + K - 1, LZU = CT_Z + K - 1;
+  constexpr int LZ = LZU | 1;  // odd row pitch: the 8 (y) x 4 (z-group) lanes of a wave hit distinct banks
+  __shared__ float tile[LX * LY * LZ];
+  const int tiles_z = (c.Z + CT_Z - 1) / CT_Z, tiles_y = (c.Y + CT_Y - 1) / CT_Y;
+  const int bz = blockIdx.x % tiles_z, by = (blockIdx.x / tiles_z) % tiles_y, bx = blockIdx.x / (tiles_z * tiles_y);
+  const int ox0 = bx * CT_X, oy0 = by * CT_Y, oz0 = bz * CT_Z;
+  // halo tile -> LDS: z-rows of LZU values, one (lx, ly) row per group of LZU consecutive work items; the fixed trip
+  // count lets the compiler keep several global loads in flight per thread
+  constexpr int TOTAL = LX * LY * LZU, ITERS = (TOTAL + FGS_BLOCK - 1) / FGS_BLOCK;
+#pragma unroll 6
+  for (int it = 0; it < ITERS; ++it) {
+    const int i = it * FGS_BLOCK + threadIdx.x;
+    const int ic = i < TOTAL ? i : TOTAL - 1;
+    const int lz = ic % LZU, ly = (ic / LZU) % LY, lx = ic / (LZU * LY);
+    int qx = ox0 + lx - shift, qy = oy0 + ly - shift, qz = oz0 + lz - shift;
+    const bool ok = REPL || (fgs_in(qx, nx) && fgs_in(qy, ny) && fgs_in(qz, nz));
+    qx = clampi(qx, 0, nx - 1); qy = clampi(qy, 0, ny - 1); qz = clampi(qz, 0, nz - 1);
+    const float v = in[((int64_t)qx * ny + qy) * nz + qz];   // address always valid: branch-free load
+    if (i < TOTAL) tile[(lx * LY + ly) * LZ + lz] = ok ? v : 0.f;
   }
-  out[idx] = acc;
-}
-
-// Along one axis: the output coordinates o whose tap t lands (after clamping) on input coordinate v.
-//   interior v: o = v - t ; v == 0: o in [0, -t] ; v == n-1: o in [n-1-t, n-1]   (intersected with [0, n))
-__device__ __forceinline__ void src_range(int v, int t, int n, int &lo, int &hi) {
-  lo = hi = v - t;
-  if (v == 0) lo = 0;          // o + t <= 0
-  if (v == n - 1) hi = n - 1;  // o + t >= n-1
-  if (lo < 0) lo = 0;
-  if (hi > n - 1) hi = n - 1;
-}
-
-// d_in[v] = sum over (o, t) with clamp(o + t) == v of w[t] * d_out[o]
-__global__ __launch_bounds__(FGS_BLOCK) void k_smooth3d_bwd(const float *__restrict__ d_out, Conv3 c,
-                                                            float *__restrict__ d_in) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t N = (int64_t)c.X * c.Y * c.Z;
-  if (idx >= N) return;
-  const int z = (int)(idx % c.Z), y = (int)((idx / c.Z) % c.Y), x = (int)(idx / ((int64_t)c.Z * c.Y));
-  const int r = c.k / 2;
-  float acc = 0.f;
-  for (int dx = 0; dx < c.k; ++dx) {
-    int x0, x1;
-    src_range(x, dx - r, c.X, x0, x1);
-    for (int dy = 0; dy < c.k; ++dy) {
-      int y0, y1;
-      src_range(y, dy - r, c.Y, y0, y1);
-      for (int dz = 0; dz < c.k; ++dz) {
-        int z0, z1;
-        src_range(z, dz - r, c.Z, z0, z1);
-        const float w = c.w[(dx * c.k + dy) * c.k + dz];
-        for (int ox = x0; ox <= x1; ++ox)
-          for (int oy = y0; oy <= y1; ++oy) {
-            const float *row = d_out + ((int64_t)ox * c.Y + oy) * c.Z;
-            for (int oz = z0; oz <= z1; ++oz) acc = fmaf(w, row[oz], acc);
-          }
+  __syncthreads();
+  const int tz = threadIdx.x & 3, ty = (threadIdx.x >> 2) & 7, tx = threadIdx.x >> 5;
+  float acc[CT_ZPT];
+#pragma unroll
+  for (int j = 0; j < CT_ZPT; ++j) acc[j] = 0.f;
+#pragma unroll 1
+  for (int dx = 0; dx < K; ++dx) {
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy) {
+      const float *row = tile + ((tx + dx) * LY + (ty + dy)) * LZ + tz * CT_ZPT;
+      float win[CT_ZPT + K - 1];
+#pragma unroll
+      for (int j = 0; j < CT_ZPT + K - 1; ++j) win[j] = row[j];
+#pragma unroll
+      for (int dz = 0; dz < K; ++dz) {
+        const float w = c.w[(dx * K + dy) * K + dz];
+#pragma unroll
+        for (int j = 0; j < CT_ZPT; ++j) acc[j] = fmaf(w, win[j + dz], acc[j]);
       }
     }
   }
+  const int x = ox0 + tx, y = oy0 + ty, z0 = oz0 + tz * CT_ZPT;
+  if (x < c.X && y < c.Y) {
+    float *o = out + ((int64_t)x * c.Y + y) * c.Z;
+#pragma unroll
+    for (int j = 0; j < CT_ZPT; ++j)
+      if (z0 + j < c.Z) o[z0 + j] = acc[j];
+  }
+}
+
+// Fold the adjoint computed on the padded domain [(n + 2r)^3, index p = q + r] back onto the grid:
+// d_in[v] = sum of dP[q] over the q that replicate padding maps to v (q == v, plus the r halo layers on a boundary face).
+__global__ __launch_bounds__(FGS_BLOCK) void k_fold_padded(const float *__restrict__ dP, int X, int Y, int Z, int r,
+                                                           float *__restrict__ d_in) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t N = (int64_t)X * Y * Z;
+  if (idx >= N) return;
+  const int z = (int)(idx % Z), y = (int)((idx / Z) % Y), x = (int)(idx / ((int64_t)Z * Y));
+  const int PY = Y + 2 * r, PZ = Z + 2 * r;
+  const int x0 = (x == 0) ? 0 : x + r, x1 = (x == X - 1) ? X - 1 + 2 * r : x + r;
+  const int y0 = (y == 0) ? 0 : y + r, y1 = (y == Y - 1) ? Y - 1 + 2 * r : y + r;
+  const int z0 = (z == 0) ? 0 : z + r, z1 = (z == Z - 1) ? Z - 1 + 2 * r : z + r;
+  float acc = 0.f;
+  for (int px = x0; px <= x1; ++px)
+    for (int py = y0; py <= y1; ++py) {
+      const float *row = dP + ((int64_t)px * PY + py) * PZ;
+      for (int pz = z0; pz <= z1; ++pz) acc += row[pz];
+    }
   d_in[idx] = acc;
+}
+
+template <bool REPL>
+void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int shift, float *out, hipStream_t st) {
+  const int64_t tiles = (int64_t)((c.X + CT_X - 1) / CT_X) * ((c.Y + CT_Y - 1) / CT_Y) * ((c.Z + CT_Z - 1) / CT_Z);
+  const dim3 grid((unsigned)tiles), block(FGS_BLOCK);
+  switch (c.k) {
+    case 1: hipLaunchKernelGGL((k_conv3d_tiled<1, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
+    case 3: hipLaunchKernelGGL((k_conv3d_tiled<3, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
+    case 5: hipLaunchKernelGGL((k_conv3d_tiled<5, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
+    default: hipLaunchKernelGGL((k_conv3d_tiled<7, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
+  }
 }
 
 // g[0] = (s[x+1] - s[x-1]) / 2 / vs on 1 <= x <= X-2 (zero on the two faces), likewise g[1] along y, g[2] along z
@@ -127,18 +163,28 @@ FGS_API int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const 
   Conv3 c;
   if (int e = make_conv("fgs_smooth3d_fwd", X, Y, Z, k, taps_host, &c)) return e;
   FGS_REQUIRE(in && out && in != out, FGS_E_INVALID, "fgs_smooth3d_fwd: null or aliased pointers");
-  hipLaunchKernelGGL(k_smooth3d_fwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), in, c, out);
+  launch_conv<true>(in, X, Y, Z, c, k / 2, out, fgs_s(stream));
   FGS_LAUNCH_OK("fgs_smooth3d_fwd");
   return 0;
 }
 
-FGS_API int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *d_in,
-                             fgs_stream_t stream) {
+// d_in = adjoint(d_out).  `scratch` holds the adjoint on the padded domain: (X+k-1)(Y+k-1)(Z+k-1) floats.
+FGS_API int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *scratch,
+                             float *d_in, fgs_stream_t stream) {
   Conv3 c;
   if (int e = make_conv("fgs_smooth3d_bwd", X, Y, Z, k, taps_host, &c)) return e;
-  FGS_REQUIRE(d_out && d_in && d_in != d_out, FGS_E_INVALID, "fgs_smooth3d_bwd: null or aliased pointers");
-  hipLaunchKernelGGL(k_smooth3d_bwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_out, c, d_in);
-  FGS_LAUNCH_OK("fgs_smooth3d_bwd");
+  FGS_REQUIRE(d_out && d_in && scratch && d_in != d_out && scratch != d_out && scratch != d_in, FGS_E_INVALID,
+              "fgs_smooth3d_bwd: null or aliased pointers");
+  // dP[q] = sum_t w[t] d_out[q - (t - r)] = sum_t' w[k-1-t'] d_out[q + t' - r]: flipped taps on the padded output domain
+  Conv3 f = c;
+  const int n3 = k * k * k;
+  for (int i = 0; i < n3; ++i) f.w[i] = c.w[n3 - 1 - i];
+  f.X = X + k - 1; f.Y = Y + k - 1; f.Z = Z + k - 1;
+  launch_conv<false>(d_out, X, Y, Z, f, k - 1, scratch, fgs_s(stream));
+  FGS_LAUNCH_OK("fgs_smooth3d_bwd/conv");
+  hipLaunchKernelGGL(k_fold_padded, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), scratch, X, Y, Z,
+                     k / 2, d_in);
+  FGS_LAUNCH_OK("fgs_smooth3d_bwd/fold");
   return 0;
 }
 

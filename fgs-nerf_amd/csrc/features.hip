@@ -428,14 +428,14 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict_
   }
   red[wv][12][lane] = osum.x; red[wv][13][lane] = osum.y; red[wv][14][lane] = osum.z; red[wv][15][lane] = osum.w;
   __syncthreads();
-  if (col_ok) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int v = wv * 4 + q;  // this wave finishes values 4*wv .. 4*wv+3 for column quad `lane`
-      const float s = (red[0][v][lane] + red[1][v][lane]) + (red[2][v][lane] + red[3][v][lane]);
-      if (v < 12) atomicAdd(dV + (v >> 2) * W + 4 * lane + (v & 3), s);
-      else if (dR_colsum) atomicAdd(dR_colsum + 4 * lane + (v - 12), s);
-    }
+  // consecutive threads finish consecutive output elements: one atomic wave-instruction covers 4 cache lines, not 16
+  // (memory-side float atomics are priced per 64-byte line, and every block hits the same 4W floats)
+  (void)wv;
+  for (int idx = threadIdx.x; idx < 4 * W; idx += FGS_BLOCK) {
+    const int c = idx / W, col = idx - c * W, v = 4 * c + (col & 3), l = col >> 2;
+    const float s = (red[0][v][l] + red[1][v][l]) + (red[2][v][l] + red[3][v][l]);
+    if (c < 3) atomicAdd(dV + idx, s);
+    else if (dR_colsum) atomicAdd(dR_colsum + col, s);
   }
   if (lane < 3) atomicAdd(dbias + lane, bsum[lane]);  // every lane of the wave walked the same rows
 }
@@ -728,8 +728,10 @@ FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const fl
               "fgs_head_bwd: M=%lld W=%d ldr=%lld", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
   FGS_REQUIRE(R && V && d_out && dR && dV && dbias, FGS_E_INVALID, "fgs_head_bwd: null pointer");
-  const int64_t want = (M + 63) / 64;  // ~16 rows per wave
-  const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  // >= 16 rows per wave, at most 4 blocks per CU: every block ends with ~4W atomics on the same few cache lines
+  const int64_t want = (M + 63) / 64;
+  static const int64_t cap = getenv("FGS_HEAD_BLOCKS") ? atoll(getenv("FGS_HEAD_BLOCKS")) : 1024;
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
                      dR_colsum);
   FGS_LAUNCH_OK("fgs_head_bwd");

@@ -41,7 +41,8 @@ class _Smooth3d(torch.autograd.Function):
         X, Y, Z, k, taps_c = ctx.meta
         d_out = d_out.contiguous()
         d_in = torch.empty_like(d_out)
-        call("fgs_smooth3d_bwd", ptr(d_out), X, Y, Z, k, taps_c, ptr(d_in), stream())
+        scratch = torch.empty((X + k - 1) * (Y + k - 1) * (Z + k - 1), dtype=torch.float32, device=d_out.device)
+        call("fgs_smooth3d_bwd", ptr(d_out), X, Y, Z, k, taps_c, ptr(scratch), ptr(d_in), stream())
         return d_in, None, None
 
 

@@ -314,11 +314,12 @@ int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, co
  * Dense per-iteration volume operators.
  * fgs_smooth3d_*: nn.Conv3d(1,1,k,padding=k//2,padding_mode='replicate') with the frozen Gaussian taps of
  *   model/nerf.py:260-278 (`smooth_conv`, applied every forward at :969).  taps_host: k^3 floats on the HOST in torch's
- *   weight order; k odd, <= 7.  in/out [X,Y,Z] fp32, must not alias.  The backward is the exact adjoint (gather form).
+ *   weight order; k odd, <= 7.  in/out [X,Y,Z] fp32, must not alias.  The backward is the exact adjoint: the same
+ *   LDS-tiled kernel evaluated on the padded domain into `scratch` [(X+k-1)(Y+k-1)(Z+k-1) floats], then folded.
  * fgs_sdf_gradvol_*: neus_sdf_gradient(mode='interpolate') (model/nerf.py:485-494): grad3 [3,X,Y,Z], central
  *   differences / 2 / voxel_size, zero on the two boundary faces of each axis.  bwd: d_sdf (+)= adjoint(d_grad3). */
 int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const float *taps_host, float *out, fgs_stream_t stream);
-int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *d_in,
+int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *scratch, float *d_in,
                      fgs_stream_t stream);
 int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, fgs_stream_t stream);
 int fgs_sdf_gradvol_bwd(const float *d_grad3, int X, int Y, int Z, float voxel_size, float *d_sdf, int accumulate,
