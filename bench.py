@@ -105,6 +105,10 @@ def main():
                     help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
     args = ap.parse_args()
 
+    # host side of this path is one Python thread + the autograd thread; the box grants a 16-CPU quota per GPU and
+    # torch would otherwise spawn one OpenMP worker per visible core (256) for the synthetic-scene setup
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
+
     import torch.distributed as dist
     from fgs_nerf_amd import synth
     from fgs_nerf_amd.dist import GradAverager

@@ -27,7 +27,7 @@ from .ops import grid_strides
 F32, I64, I32 = torch.float32, torch.int64, torch.int32
 
 # event pairs recorded around the dominant kernel family (the MLP GEMMs) when profiling is switched on by bench.py
-PROFILE = {"enabled": False, "gemm_events": [], "gemm_flops": 0.0}
+PROFILE = {"enabled": False, "gemm_events": [], "open": None}
 
 
 def supports(model) -> bool:
@@ -111,17 +111,42 @@ class _Run:
     """Everything one forward produced that the backward needs (plain attribute bag)."""
 
 
+def _detached(d):
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+class _gemm_group:
+    """HIP-event bracket around an uninterrupted run of k_gemm launches (the forward chain, the backward chain): two
+    events per chain instead of two per launch -- 42 event records per step cost ~0.5 ms of launch latency."""
+
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if PROFILE["enabled"]:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            PROFILE["open"] = [0, 0.0]
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE["enabled"] and PROFILE.get("open") is not None:
+            self.e1.record()
+            n, fl = PROFILE["open"]
+            PROFILE["open"] = None
+            if n:
+                PROFILE["gemm_events"].append((self.e0, self.e1, self.label, n, fl))
+        return False
+
+
 def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
     """`logical` = un-padded (M, N, K) of the product, for the algorithmic FLOP count of the roofline report."""
-    if PROFILE["enabled"]:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fo.gemm(op, A, B, C, M, N, K, **kw)
-        e1.record()
+    fo.gemm(op, A, B, C, M, N, K, **kw)
+    grp = PROFILE.get("open")
+    if grp is not None:
         lm, ln, lk = logical or (M, N, K)
-        PROFILE["gemm_events"].append((e0, e1, op, 2.0 * lm * ln * lk))
-    else:
-        fo.gemm(op, A, B, C, M, N, K, **kw)
+        grp[0] += 1
+        grp[1] += 2.0 * lm * ln * lk
 
 
 class _FusedFine(torch.autograd.Function):
@@ -175,6 +200,7 @@ class _FusedFine(torch.autograd.Function):
         rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
         W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
+        grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
         acts_rgb = [X0]                                    # input of each rgbnet layer
         a = X0
         for i in range(n_rgb):
@@ -195,6 +221,7 @@ class _FusedFine(torch.autograd.Function):
                   logical=(M, fw, ref_w[i].shape[1]))
             a = out
             acts_ref.append(out)
+        grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
         call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
         # 5. compositing
@@ -208,9 +235,12 @@ class _FusedFine(torch.autograd.Function):
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
         alphainv_last = ws['alphainv_last'].clone()
 
-        run.saved = dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
-                         acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig,
-                         alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ))
+        # Tensors this function RETURNS must not be reachable from ctx through plain attributes: output -> grad_fn -> ctx
+        # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
+        # detached aliases (same storage, no grad_fn) instead.
+        run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
+                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig,
+                                   alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
         ctx.run = run
@@ -265,6 +295,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_ref[-1]),
              ptr(gb_ref[-1]), ptr(gb_ref[n_ref - 2]), st)
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
+        grp = _gemm_group("backward chain (TN/NN alternating: k_gemm<false,false,1>, k_gemm<true,false,0>)").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts_ref[i]                      # input of layer i: Z for i == 0
             if i == 0:
@@ -294,6 +325,7 @@ class _FusedFine(torch.autograd.Function):
                 _gemm(fo.GEMM_NN, dY, rgb_w[i], d_in, M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
                 dY = d_in
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
+        grp.__exit__()
 
         # 5. features -> grids
         grad_sdf = torch.zeros_like(sdf_grid)
@@ -389,6 +421,7 @@ class _FusedCoarse(torch.autograd.Function):
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
         fw = ref_w[0].shape[0]
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
+        grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
         acts = [X0]
         a = X0
         for i in range(n_ref - 1):
@@ -397,6 +430,7 @@ class _FusedCoarse(torch.autograd.Function):
                   bias=ref_b[i].detach(), relu=True, logical=(M, fw, ref_w[i].shape[1]))
             a = out
             acts.append(out)
+        grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
         call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
         rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
@@ -408,8 +442,9 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
         alphainv_last = ws['alphainv_last'].clone()
-        run.saved = dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts, V0p=V0p,
-                         pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ))
+        run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
+                                   V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
+                                   k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
         ctx.run = run
@@ -450,6 +485,7 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
              ptr(gb[-1]), ptr(gb[n_ref - 2]), st)
         dX0 = None
+        grp = _gemm_group("backward chain (TN/NN alternating: k_gemm<false,false,1>, k_gemm<true,false,0>)").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts[i]
             if i == 0:
@@ -462,6 +498,7 @@ class _FusedCoarse(torch.autograd.Function):
                 _gemm(fo.GEMM_NN, dY, ref_w[i], d_in, M, fw, fw, mask=a_in, colsum=gb[i - 1])
                 dY = d_in
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
+        grp.__exit__()
         grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
@@ -668,27 +705,26 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
 
 def roofline_report():
     """Achieved fp32 FLOP/s of the dominant kernel (the k_gemm template: MLP forward, data- and weight-gradient products)
-    from the HIP events bench.py had recorded around every launch in its timed region, against the gfx950 fp32
+    from the HIP events recorded around every k_gemm chain in bench.py's timed region, against the gfx950 fp32
     matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD)."""
     ev = PROFILE["gemm_events"]
     if not ev:
         return None
-    names = {fo.GEMM_NT: "k_gemm<true,true,0> (forward)", fo.GEMM_NN: "k_gemm<true,false,0> (data grad)",
-             fo.GEMM_TN: "k_gemm<false,false,1> (weight grad)"}
     per = {}
-    tot_ms, tot_fl = 0.0, 0.0
-    for e0, e1, op, fl in ev:
+    tot_ms, tot_fl, tot_n = 0.0, 0.0, 0
+    for e0, e1, label, n, fl in ev:
         ms = e0.elapsed_time(e1)
-        d = per.setdefault(names[op], [0, 0.0, 0.0])
-        d[0] += 1
+        d = per.setdefault(label, [0, 0.0, 0.0])
+        d[0] += n
         d[1] += ms
         d[2] += fl
         tot_ms += ms
         tot_fl += fl
+        tot_n += n
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = 157.3
     traffic = _pmc_traffic()
-    return _roofline_dict(achieved, peak, traffic, ev, tot_ms, tot_fl, per)
+    return _roofline_dict(achieved, peak, traffic, tot_n, tot_ms, tot_fl, per)
 
 
 def _pmc_traffic():
@@ -705,11 +741,12 @@ def _pmc_traffic():
         return None
 
 
-def _roofline_dict(achieved, peak, traffic, ev, tot_ms, tot_fl, per):
+def _roofline_dict(achieved, peak, traffic, n_launches, tot_ms, tot_fl, per):
     return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32; rgbnet/refnet forward, data-grad, weight-grad)",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_gemm.json)",
-            "launches": len(ev), "avg_launch_us": round(tot_ms * 1e3 / len(ev), 2),
-            "algorithmic_gflop_per_launch": round(tot_fl / len(ev) / 1e9, 3),
-            "variants": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
+            "launches": n_launches, "avg_launch_us": round(tot_ms * 1e3 / n_launches, 2),
+            "algorithmic_gflop_per_launch": round(tot_fl / n_launches / 1e9, 3),
+            "timing": "HIP events on the launch stream around each uninterrupted k_gemm chain in the timed region",
+            "chains": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
                              "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()}}

@@ -71,3 +71,31 @@ def test_voxel_count_views(dev):
     cnt = m.voxel_count_views(ro.reshape(1, 12, 12, 3).to(dev), rd.reshape(1, 12, 12, 3).to(dev), imsz=[1], near=2.0,
                               far=6.0, stepsize=0.5, irregular_shape=False)
     assert cnt.shape == m.sdf.grid.shape and float(cnt.sum()) > 0
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_training_steps_do_not_leak_device_memory(dev, stage):
+    """The fused autograd nodes must not keep their own outputs alive (output -> grad_fn -> ctx -> output is a cycle the
+    Python collector cannot see): device memory after step 6 and after step 30 must agree."""
+    import gc
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    cfg, lossw = (synth.FINE_MODEL, synth.FINE_LOSS) if stage == "fine" else (synth.COARSE_MODEL, synth.COARSE_LOSS)
+    model = synth.build_model(48, cfg, device=dev)
+    rays = tuple(r.to(dev) for r in synth.random_rays(1024, seed=3))
+    target = torch.rand(1024, 3, device=dev)
+    gc.disable()
+    try:
+        marks = {}
+        for i in range(31):
+            for p in model.parameters():
+                p.grad = None
+            res = model(*rays, global_step=500, **synth.RENDER_KWARGS)
+            fused_render_losses(res, target, lossw, model).backward()
+            del res
+            if i in (6, 30):
+                torch.cuda.synchronize()
+                marks[i] = torch.cuda.memory_allocated()
+    finally:
+        gc.enable()
+    assert marks[30] - marks[6] < (8 << 20), marks
