@@ -50,6 +50,9 @@ def train_step(model, opt, averager, batch, n_rays_global):
     res = model(ro, rd, vd, global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
     # nerf_training.py:308-327; two HIP launches each way on the fused path, plain torch on the composed path
     loss = fused_render_losses(res, target, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model)
+    pts = res.get('survivor_pts') if hasattr(res, 'get') else None
+    if pts is not None:   # every k0 gradient of this step comes from trilinear lookups at the survivors
+        averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     averager.average()
@@ -119,15 +122,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("FGS_FORCE_DIST") == "1"   # rehearse the RCCL exchange on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model = synth.build_model(GRID, synth.FINE_MODEL if args.stage == "fine" else synth.COARSE_MODEL, device=dev,
                               fused=False if args.composed else None)
     opt = make_optimizer(model)
-    averager = GradAverager(model.parameters())
+    averager = GradAverager(model.parameters(), force=force_dist)
     n_global = RAYS_PER_GPU * world
 
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)
@@ -190,7 +197,7 @@ def main():
         line["roofline"] = fused.roofline_report()
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine") else cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -8,7 +8,7 @@
 //   fgs_brick_flags   : flags[b] = 1 if any element of brick b is non-zero (one streaming pass over the gradient)
 //   fgs_brick_gather  : buf[i] (64*C floats, order x',y',z',c) = brick idx[i]
 //   fgs_brick_scatter : brick idx[i] = buf[i] * scale
-#include "fgs_common.h"
+#include "fgs_taps.h"
 
 namespace {
 
@@ -61,6 +61,48 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_brick_copy(float *__restrict__ gr
   }
 }
 
+// flags[b] = 1 for every brick holding one of the 8 trilinear corners of a sample point: the bricks a DenseGrid backward
+// (fgs_trilerp_bwd / k_feat_k0_bwd) can write for these points -- known as soon as the forward has its survivor list,
+// i.e. ~2 ms before the gradient itself exists.  Plain stores of the same value: the race is benign.
+__global__ __launch_bounds__(FGS_BLOCK) void k_brick_flags_pts(const float *__restrict__ pts, int64_t M, SceneGeom sg,
+                                                               BrickGrid g, int *__restrict__ flags) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const GridDesc d = fgs_sdf_desc(sg);
+  const PointIdx p = fgs_point_to_index(pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], sg.lo, sg.hi, d);
+  const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = t.x0 + (k >> 2), y = t.y0 + ((k >> 1) & 1), z = t.z0 + (k & 1);
+    if (fgs_in(x, g.X) && fgs_in(y, g.Y) && fgs_in(z, g.Z)) flags[((int64_t)(x >> 2) * g.nby + (y >> 2)) * g.nbz + (z >> 2)] = 1;
+  }
+}
+
+// Ordered compaction of the set flags into idx[0..count) on the device (one workgroup; the brick count of a 320^3 grid
+// is 512 K).  No host involvement: the count is fetched asynchronously by whoever sizes the exchange buffer.
+constexpr int COMPACT_THREADS = 1024;
+__global__ __launch_bounds__(COMPACT_THREADS) void k_brick_compact(const int *__restrict__ flags, int64_t total,
+                                                                   int64_t *__restrict__ idx, int64_t *__restrict__ count) {
+  __shared__ int64_t part[COMPACT_THREADS];
+  const int t = threadIdx.x;
+  const int64_t per = (total + COMPACT_THREADS - 1) / COMPACT_THREADS;
+  const int64_t lo = t * per, hi = (lo + per < total) ? lo + per : total;
+  int64_t c = 0;
+  for (int64_t i = lo; i < hi; ++i) c += flags[i] != 0;
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < COMPACT_THREADS; off <<= 1) {   // Hillis-Steele inclusive scan
+    const int64_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int64_t w = part[t] - c;
+  for (int64_t i = lo; i < hi; ++i)
+    if (flags[i] != 0) idx[w++] = i;
+  if (t == COMPACT_THREADS - 1) *count = part[t];
+}
+
 int make_grid(const char *who, int C, int X, int Y, int Z, BrickGrid *g) {
   if (C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || (X & 3) || (Y & 3) || (Z & 3))
     return fgs_set_error(FGS_E_INVALID, "%s: grid %dx%dx%dx%d must have sides that are multiples of 4", who, X, Y, Z, C);
@@ -101,5 +143,32 @@ FGS_API int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int
   hipLaunchKernelGGL(k_brick_copy<true>, dim3(fgs_blocks(n * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), grad, g, idx, n,
                      const_cast<float *>(buf), scale);
   FGS_LAUNCH_OK("fgs_brick_scatter");
+  return 0;
+}
+
+// Brick occupancy from sample points instead of from the gradient (see k_brick_flags_pts).  ORs into `flags`
+// (caller zeroes it once per step); xyz_min/max on the host, grid [X,Y,Z] as for the trilinear kernels.
+FGS_API int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X,
+                                int Y, int Z, int *flags, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_flags_pts", 1, X, Y, Z, &g)) return e;
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_brick_flags_pts: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(pts && xyz_min_host && xyz_max_host && flags && X > 1 && Y > 1 && Z > 1, FGS_E_INVALID,
+              "fgs_brick_flags_pts: bad arguments");
+  SceneGeom sg;
+  for (int c = 0; c < 3; ++c) { sg.lo[c] = xyz_min_host[c]; sg.hi[c] = xyz_max_host[c]; }
+  sg.X = X; sg.Y = Y; sg.Z = Z; sg.voxel_size = 0.f;
+  hipLaunchKernelGGL(k_brick_flags_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, sg, g, flags);
+  FGS_LAUNCH_OK("fgs_brick_flags_pts");
+  return 0;
+}
+
+// idx[0..*count) = ascending indices of the non-zero flags; idx must hold `total` entries; count is a device int64.
+FGS_API int fgs_brick_compact(const int *flags, int64_t total, int64_t *idx, int64_t *count, fgs_stream_t stream) {
+  FGS_REQUIRE(total >= 0 && total < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_brick_compact: total=%lld", (long long)total);
+  FGS_REQUIRE(count && (total == 0 || (flags && idx)), FGS_E_INVALID, "fgs_brick_compact: null pointer");
+  hipLaunchKernelGGL(k_brick_compact, dim3(1), dim3(COMPACT_THREADS), 0, fgs_s(stream), flags, total, idx, count);
+  FGS_LAUNCH_OK("fgs_brick_compact");
   return 0;
 }

@@ -50,22 +50,79 @@ class GradAverager:
     """Averages `.grad` of the given parameters over the process group (see the module docstring for the scheme)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
-                 big_numel: int = 1 << 20, sparse_min_numel: int = 1 << 24, sparse_max_fill: float = 0.5):
+                 big_numel: int = 1 << 20, sparse_min_numel: int = 1 << 24, sparse_max_fill: float = 0.5,
+                 force: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.big_numel = big_numel
         self.sparse_min_numel = sparse_min_numel
         self.sparse_max_fill = sparse_max_fill
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()      # run the exchange even in a group of one (path rehearsal)
+        # RCCL averages inside the collective (ncclAvg); gloo only sums, so the CPU tests scale afterwards
+        import os
+        self.avg_in_collective = (dist.is_initialized() and dist.get_backend(group) == "nccl"
+                                  and os.environ.get("FGS_DIST_SUM") != "1")
         self._bucket = None
         self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
+        self._hints = {}                  # id(param) -> state of hint_touched()
+
+    # ------------------------------------------------------------------------------------------------ early occupancy
+    def hint_touched(self, param: torch.nn.Parameter, pts: torch.Tensor, xyz_min, xyz_max) -> None:
+        """Tell the averager, right after the forward, which sample points the backward of the DenseGrid `param` will
+        scatter into (`pts` [M,3], the survivor list).  The brick occupancy (a superset of the non-zero bricks), its union
+        over ranks and the compacted brick list are then produced on a side stream while the MLP forward/backward runs,
+        and `average()` sizes the exchange from a count that is already on the host: no blocking nonzero(), no pass over
+        the 197 MB gradient.  Only valid when every gradient of `param` in this step comes from trilinear lookups at
+        `pts`; without a hint the occupancy is read from the gradient itself."""
+        if (self.world_size == 1 and not self.force) or not (pts.is_cuda and param.dim() == 5):
+            return
+        _, C, X, Y, Z = param.shape
+        if X % BRICK or Y % BRICK or Z % BRICK or C == 1:
+            return
+        import ctypes
+        from ._lib import call, ptr, stream
+        total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
+        h = self._hints.get(id(param))
+        if h is None or h['total'] != total:
+            dev = pts.device
+            h = dict(total=total, flags=torch.empty(total, dtype=torch.int32, device=dev),
+                     idx=torch.empty(total, dtype=torch.int64, device=dev), count=torch.empty(1, dtype=torch.int64, device=dev),
+                     count_host=torch.empty(1, dtype=torch.int64).pin_memory(), stream=torch.cuda.Stream(device=dev),
+                     event=torch.cuda.Event(), armed=False)
+            self._hints[id(param)] = h
+        if h.get('box_key') != (id(xyz_min), id(xyz_max)):      # one device->host read per box, not per step
+            h['lo'] = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(xyz_min).flatten().tolist()])
+            h['hi'] = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(xyz_max).flatten().tolist()])
+            h['box_key'] = (id(xyz_min), id(xyz_max))
+        lo, hi = h['lo'], h['hi']
+        pts = pts.detach().contiguous()
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(h['stream']):
+            h['stream'].wait_event(ready)
+            h['flags'].zero_()
+            call("fgs_brick_flags_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(h['flags']), stream())
+            dist.all_reduce(h['flags'], op=dist.ReduceOp.MAX, group=self.group)               # union over ranks
+            call("fgs_brick_compact", ptr(h['flags']), total, ptr(h['idx']), ptr(h['count']), stream())
+            h['count_host'].copy_(h['count'], non_blocking=True)
+            h['event'].record()
+        pts.record_stream(h['stream'])
+        h['armed'] = True
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _dense(self, g: torch.Tensor, async_op: bool):
         flat = g.as_strided((g.numel(),), (1,))       # the dense storage as a flat view (layout-agnostic, no copy)
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op), flat
+        return dist.all_reduce(flat, op=self._op(), group=self.group, async_op=async_op), flat
 
-    def _sparse(self, g: torch.Tensor, inv: float) -> bool:
+    def _op(self):
+        return dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+
+    def _post_scale(self, t: torch.Tensor, inv: float) -> None:
+        if not self.avg_in_collective:
+            t.mul_(inv)
+
+    def _sparse(self, g: torch.Tensor, inv: float, param=None) -> bool:
         """Brick-sparse exchange of one multi-channel grid gradient.  Returns False if the dense path should be used."""
         bv = _brick_view(g)
         if bv is None:
@@ -74,6 +131,25 @@ class GradAverager:
         total = nbx * nby * nbz
         on_gpu = g.is_cuda
         dims = (C, nbx * BRICK, nby * BRICK, nbz * BRICK)
+        h = self._hints.get(id(param)) if param is not None else None
+        if on_gpu and h is not None and h['armed'] and h['total'] == total:
+            from ._lib import call, ptr, stream
+            h['armed'] = False
+            h['event'].synchronize()                       # side-stream work issued ~one MLP pass ago: already complete
+            torch.cuda.current_stream().wait_event(h['event'])
+            n = int(h['count_host'][0])
+            self.last_sparse_fill = n / max(total, 1)
+            if n > self.sparse_max_fill * total:
+                return False
+            if n == 0:
+                return True
+            idx = h['idx'][:n]
+            buf = torch.empty(n, BRICK ** 3 * C, dtype=g.dtype, device=g.device)
+            call("fgs_brick_gather", ptr(g), *dims, ptr(idx), n, ptr(buf), stream())
+            dist.all_reduce(buf, op=self._op(), group=self.group)
+            call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), 1.0 if self.avg_in_collective else float(inv),
+                 stream())
+            return True
         if on_gpu:       # csrc/bricks.hip: one streaming pass over the gradient
             from ._lib import call, ptr, stream
             flags = torch.empty(total, dtype=torch.int32, device=g.device)
@@ -91,8 +167,9 @@ class GradAverager:
         if on_gpu:
             buf = torch.empty(n, BRICK ** 3 * C, dtype=g.dtype, device=g.device)
             call("fgs_brick_gather", ptr(g), *dims, ptr(idx), n, ptr(buf), stream())
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), float(inv), stream())
+            dist.all_reduce(buf, op=self._op(), group=self.group)
+            call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), 1.0 if self.avg_in_collective else float(inv),
+                 stream())
             return True
         bx = idx // (nby * nbz)
         by = (idx // nbz) % nby
@@ -106,10 +183,11 @@ class GradAverager:
     # ------------------------------------------------------------------------------------------------ driver
     @torch.no_grad()
     def average(self) -> None:
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return
         inv = 1.0 / self.world_size
         handles, small, sparse_later = [], [], []
+        owner = {}
         for p in self.params:
             g = p.grad
             if g is None:
@@ -120,6 +198,7 @@ class GradAverager:
                     p.grad = g
                 if g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1:
                     sparse_later.append(g)
+                    owner[id(g)] = p
                 else:
                     handles.append(self._dense(g, async_op=True))
             else:
@@ -128,20 +207,18 @@ class GradAverager:
             n = sum(g.numel() for g in small)
             if self._bucket is None or self._bucket.numel() != n or self._bucket.device != small[0].device:
                 self._bucket = torch.empty(n, dtype=small[0].dtype, device=small[0].device)
-            off = 0
+            torch.cat([g.reshape(-1) for g in small], out=self._bucket)                    # one launch in
+            dist.all_reduce(self._bucket, op=self._op(), group=self.group)
+            self._post_scale(self._bucket, inv)
+            views, off = [], 0
             for g in small:
-                self._bucket[off:off + g.numel()].copy_(g.reshape(-1))
+                views.append(self._bucket[off:off + g.numel()].view(g.shape))
                 off += g.numel()
-            dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self._bucket.mul_(inv)
-            off = 0
-            for g in small:
-                g.copy_(self._bucket[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            torch._foreach_copy_(small, views)                                             # a few launches out
         for g in sparse_later:
-            if not self._sparse(g, inv):
+            if not self._sparse(g, inv, owner.get(id(g))):
                 h, flat = self._dense(g, async_op=False)
-                flat.mul_(inv)
+                self._post_scale(flat, inv)
         for h, flat in handles:
             h.wait()
-            flat.mul_(inv)
+            self._post_scale(flat, inv)

@@ -650,7 +650,8 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
              'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
-             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs}
+             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
+             'survivor_pts': run.saved['pts']}
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox})
 
 
@@ -699,7 +700,8 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
              'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
-             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs}
+             'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
+             'survivor_pts': run.saved['pts']}
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks})
 
 

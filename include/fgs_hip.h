@@ -139,6 +139,14 @@ int fgs_brick_gather(const float *grad, int C, int X, int Y, int Z, const int64_
                      fgs_stream_t stream);
 int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int64_t *idx, int64_t n, const float *buf,
                       float scale, fgs_stream_t stream);
+/* Occupancy from the sample points whose 8 trilinear corners a DenseGrid backward will write (a superset of the
+ * non-zero bricks, known right after the forward): ORs 1 into flags[b]; the caller zeroes flags once per step.
+ * xyz_min / xyz_max on the HOST; index mapping identical to fgs_trilerp_*. */
+int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                        int Z, int *flags, fgs_stream_t stream);
+/* idx[0 .. *count) = ascending indices of the set flags, entirely on the device (idx holds `total` entries, count is a
+ * device int64): the exchange is sized from a count fetched asynchronously, never from a blocking nonzero(). */
+int fgs_brick_compact(const int *flags, int64_t total, int64_t *idx, int64_t *count, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Ray-dependent loss terms of one iteration -- model/nerf_training.py:308-327 (+ nerf.orientation_loss,

@@ -28,8 +28,7 @@ def test_sparse_exchange_on_real_gradient(dev):
         fused_render_losses(res, target, synth.FINE_LOSS, model).backward()
         g = model.k0.grid.grad
         before = g.clone()
-        avg = GradAverager(model.parameters())
-        avg.world_size = 2                       # force the exchange code path; with one rank SUM is the identity
+        avg = GradAverager(model.parameters(), force=True)   # run the exchange in a group of one: it must be the identity
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         assert avg._sparse(g, 1.0)
@@ -38,9 +37,52 @@ def test_sparse_exchange_on_real_gradient(dev):
         assert torch.equal(g, before)
         assert 0 < avg.last_sparse_fill < 0.5, avg.last_sparse_fill
         print(f"sparse exchange: fill {avg.last_sparse_fill:.3f}, {dt * 1e3:.2f} ms single-rank")
-        # the full driver, dense + bucket + sparse, is the identity at one rank up to the 1/P factor
+        # the full driver (dense + bucket + sparse, ncclAvg inside the collectives) is the identity at one rank
         sdf_before = model.sdf.grid.grad.clone()
+        w_before = [p.grad.clone() for p in model.refnet.parameters()]
         avg.average()
-        assert torch.allclose(model.sdf.grid.grad, sdf_before * 0.5) and torch.allclose(g, before * 0.5)
+        assert torch.equal(model.sdf.grid.grad, sdf_before) and torch.equal(g, before)
+        assert all(torch.equal(p.grad, w) for p, w in zip(model.refnet.parameters(), w_before))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hinted_exchange_matches_gradient_occupancy(dev):
+    """hint_touched (occupancy from the survivor points, on a side stream, count fetched asynchronously) must cover every
+    non-zero brick of the real k0 gradient and leave the gradient unchanged at one rank."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.dist import GradAverager
+    from fgs_nerf_amd.losses import fused_render_losses
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for stage, cfg, lossw in (("fine", synth.FINE_MODEL, synth.FINE_LOSS), ("coarse", synth.COARSE_MODEL, synth.COARSE_LOSS)):
+            model = synth.build_model(64, cfg, device=dev)
+            rays = tuple(r.to(dev) for r in synth.random_rays(2048, seed=5))
+            target = torch.rand(2048, 3, device=dev)
+            avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16)
+            res = model(*rays, global_step=1000, **synth.RENDER_KWARGS)
+            avg.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
+            fused_render_losses(res, target, lossw, model).backward()
+            g = model.k0.grid.grad
+            before = g.clone()
+            # occupancy read from the gradient itself (the un-hinted path's kernel)
+            from fgs_nerf_amd._lib import call, ptr, stream
+            C, X, Y, Z = g.shape[1:]
+            flags = torch.empty((X // 4) * (Y // 4) * (Z // 4), dtype=torch.int32, device=dev)
+            call("fgs_brick_flags", ptr(g), C, X, Y, Z, ptr(flags), stream())
+            h = avg._hints[id(model.k0.grid)]
+            assert h['armed']
+            avg.average()
+            assert not h['armed']
+            hinted = torch.zeros_like(flags)
+            hinted[h['idx'][:int(h['count_host'][0])]] = 1
+            assert bool(((flags == 1) & (hinted == 0)).sum() == 0), stage        # superset of the non-zero bricks
+            assert int(hinted.sum()) <= 2 * int(flags.sum()) + 8, stage           # and not much more
+            assert torch.equal(g, before), stage                                  # world size 1: SUM and 1/P are identities
+            assert 0 < avg.last_sparse_fill < 0.5
     finally:
         dist.destroy_process_group()
