@@ -602,14 +602,14 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     run.inc = None
     if model.inc_mask is not None:
         im = model.inc_mask
-        key = id(im)
-        cached = getattr(model, '_fused_inc', None)
-        if cached is None or cached[0] != key:
+        key = im                                   # the module itself: keeps it alive, so no id() reuse
+        cached = model.__dict__.get('_fused_inc')
+        if cached is None or cached[0] is not key:
             world = im.mask.to(torch.uint8).contiguous()
             sc = im.xyz2ijk_scale.detach().cpu().float().tolist()
             sh = im.xyz2ijk_shift.detach().cpu().float().tolist()
             cached = (key, (world, tuple(int(s) for s in world.shape), (ctypes.c_float * 3)(*sc), (ctypes.c_float * 3)(*sh)))
-            model._fused_inc = cached
+            model.__dict__['_fused_inc'] = cached   # plain attribute, not a registered sub-module
         run.inc = cached[1]
     # dense per-iteration volumes (row a6): smoothed SDF grid and central-difference gradient volume, both autograd
     # nodes over sdf.grid; model.gradient stays differentiable for density_total_variation (model/nerf.py:440-446)

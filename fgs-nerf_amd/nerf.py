@@ -162,7 +162,29 @@ class nerf(torch.nn.Module):
         self.init_gradient_conv()
         self.get_rays_of_a_view = nerf_ray.get_rays_of_a_view
         self.fused = fused
-        self.gradient = None
+        self._gradient, self._gradient_pending = None, False
+
+    # `self.gradient` -- the dense central-difference volume the reference recomputes inside EVERY forward
+    # (model/nerf.py:856 fine, :972 coarse).  The fine stage only reads it from density_total_variation (every
+    # tv_every-th iteration), so forward_fine marks it pending and the volume (a HIP stencil over the current sdf.grid,
+    # an autograd node) is built on first access.
+    @property
+    def gradient(self):
+        if self._gradient_pending:
+            self._gradient_pending = False
+            self._gradient = self._gradient_volume()
+        return self._gradient
+
+    @gradient.setter
+    def gradient(self, value):
+        self._gradient, self._gradient_pending = value, False
+
+    def _gradient_volume(self):
+        g = self.sdf.grid
+        if g.is_cuda and self.grad_mode == 'interpolate' and g.is_contiguous():
+            from . import dense
+            return dense.sdf_gradient_volume(g, float(self.voxel_size))
+        return self.neus_sdf_gradient()
 
     # ------------------------------------------------------------------ resolution / bookkeeping
     def _set_grid_resolution(self, num_voxels):
@@ -316,8 +338,22 @@ class nerf(torch.nn.Module):
         if sdf_tv > 0:
             tv += total_variation(self.sdf.grid, self.nonempty_mask) / 2 / self.voxel_size * sdf_tv
         if smooth_grad_tv > 0:
-            g = self.gradient.permute(1, 0, 2, 3, 4)
-            err = self.tv_smooth_conv(g).detach() - g
+            grad = self.gradient                                     # [1,3,X,Y,Z]
+            if grad.is_cuda and grad.is_contiguous():
+                # tv_smooth_conv(g).detach(): the detached 3^3 binomial smoothing of each component, HIP stencil
+                from . import dense
+                w = self.tv_smooth_conv.weight
+                taps = self.__dict__.get('_tv_taps_c')
+                if taps is None or taps[0] is not w:                 # host copy of the frozen taps, made once
+                    taps = (w, dense._taps_c(w))
+                    self.__dict__['_tv_taps_c'] = taps
+                with torch.no_grad():
+                    gd = grad.detach()
+                    sm = torch.cat([dense.smooth3d(gd[:, c:c + 1], w, taps[1]) for c in range(3)], dim=1)
+                err = (sm - grad).permute(1, 0, 2, 3, 4)
+            else:
+                g = grad.permute(1, 0, 2, 3, 4)
+                err = self.tv_smooth_conv(g).detach() - g
             if self.nonempty_mask is not None:
                 err = err[self.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2
             else:
@@ -447,6 +483,7 @@ class nerf(torch.nn.Module):
 
     def forward_fine(self, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
         """model/nerf.py:776-941."""
+        self._gradient, self._gradient_pending = None, True     # model/nerf.py:856, evaluated lazily
         if self._use_fused(rays_o):
             from . import fused
             return fused.forward_fine(self, rays_o, rays_d, viewdirs, global_step, **render_kwargs)

@@ -1,0 +1,258 @@
+"""Per-iteration body of the reference's training loop (model/nerf_training.py:237-456) as a sync-free stepper
+(SURVEY.md 8f row f1).
+
+The reference loop touches the host many times per iteration: a CPU index batch copied to the GPU, ``psnr.item()``, five
+``.cpu().numpy()`` statistics, ``empty_cache``.  Here everything an iteration needs stays on the device:
+
+* ray batches come from a device-resident permutation (same epoch semantics as ``batch_indices_generator``);
+* the loss terms are the two-launch HIP loss (`losses.fused_render_losses`) when the model ran the fused path;
+* statistics are kept as device scalars and reduced only when `stats()` is called (the reference's print interval);
+* the only device->host read left in an iteration is the survivor count inside the fused forward.
+
+What is mirrored from the reference, statement by statement: optimizer construction from ``lrate_*`` keys (:9-37), the
+voxel-increment schedule (:288-295), the loss terms (:306-327), the TV schedule in both forms (autograd TV losses
+:330-345, TV add-grad after backward :353-371), exponential / cosine LR decay with ``decay_step_module`` (:389-436),
+``tv_updates`` / ``s_updates`` / ``smooth_updates`` (:438-456), progressive grid scaling with optimizer re-creation
+(:243-253).  Out of scope: dataset loading, logging, checkpoint writing, evaluation.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .adam import MaskedAdam
+from .losses import fused_render_losses
+
+
+class Cfg(dict):
+    """dict with attribute access (what the reference gets from mmcv.Config)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return Cfg(v) if isinstance(v, dict) and not isinstance(v, Cfg) else v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def create_optimizer_or_freeze_model(model, cfg_train, global_step, logger=None):
+    """model/nerf_training.py:9-37."""
+    cfg_train = Cfg(cfg_train)
+    decay_steps = cfg_train.lrate_decay * 1000
+    decay_factor = 0.1 ** (global_step / decay_steps)
+    groups = []
+    for k in cfg_train.keys():
+        if not k.startswith('lrate_'):
+            continue
+        k = k[len('lrate_'):]
+        if not hasattr(model, k):
+            continue
+        param = getattr(model, k)
+        if param is None:
+            continue
+        lr = cfg_train[f'lrate_{k}'] * decay_factor
+        if lr > 0:
+            if isinstance(param, nn.Module):
+                param = param.parameters()
+            groups.append({'params': param, 'lr': lr, 'name': k,
+                           'skip_zero_grad': (k in cfg_train.get('skip_zero_grad_fields', []))})
+        else:
+            param.requires_grad = False
+    return MaskedAdam(groups, betas=(0.9, 0.99))
+
+
+def cosine_lr_func(it, warm_up_iters, warm_up_min_ratio, max_steps, const_warm_up=False, min_ratio=0):
+    """model/nerf_training.py:397-406."""
+    if it < warm_up_iters:
+        if not const_warm_up:
+            return warm_up_min_ratio + (1 - warm_up_min_ratio) * (it / warm_up_iters)
+        return warm_up_min_ratio
+    return (1 + math.cos((it - warm_up_iters) / (max_steps - warm_up_iters) * math.pi)) * 0.5 * (1 - min_ratio) + min_ratio
+
+
+def lr_decay_factor(cfg_train, global_step) -> float:
+    """The factor every param group's lr is multiplied by after iteration `global_step` (model/nerf_training.py:389-430)."""
+    cfg_train = Cfg(cfg_train)
+    if not cfg_train.get('cosine_lr', ''):
+        return 0.1 ** (1 / (cfg_train.lrate_decay * 1000))
+    c = cfg_train.get('cosine_lr_cfg', {})
+    wu, wr = c.get('warm_up_iters', 0), c.get('warm_up_min_ratio', 1.0)
+    const, cmin = c.get('const_warm_up', False), c.get('cos_min_ratio', False)
+    g_ = global_step - 1
+    pre = 1.0 if global_step == 0 else cosine_lr_func(g_ - 1, wu, wr, cfg_train.N_iters, const, cmin)
+    pos = cosine_lr_func(g_, wu, wr, cfg_train.N_iters, const, cmin)
+    return pos / pre
+
+
+class DeviceBatchSampler:
+    """``batch_indices_generator`` (model/dvgo_ray.py:251-258) with the permutation resident on the device: endless
+    epochs, `BS` indices per call, reshuffle when fewer than `BS` remain.  No per-iteration host->device copy."""
+
+    def __init__(self, n: int, batch: int, device, seed: Optional[int] = None):
+        self.n, self.batch, self.device = int(n), int(batch), device
+        self.gen = torch.Generator(device=device)
+        if seed is not None:
+            self.gen.manual_seed(int(seed))
+        self.order, self.top = torch.randperm(self.n, generator=self.gen, device=device), 0
+
+    def __call__(self) -> torch.Tensor:
+        if self.top + self.batch > self.n:
+            self.order, self.top = torch.randperm(self.n, generator=self.gen, device=self.device), 0
+        sel = self.order[self.top:self.top + self.batch]
+        self.top += self.batch
+        return sel
+
+
+class TrainStepper:
+    """One stage of ``scene_rep_reconstruction`` from the point where rays are gathered (model/nerf_training.py:151-186)
+    to the end of the per-iteration body.  `rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr` are flat [R,3] device tensors."""
+
+    def __init__(self, model, cfg_train, cfg_model, render_kwargs, rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr,
+                 stage: str = 'fine', optimizer=None, averager=None, seed: Optional[int] = None,
+                 poses_train=None, near=None):
+        self.model, self.stage = model, stage
+        self.cfg_train, self.cfg_model = Cfg(cfg_train), Cfg(cfg_model or {})
+        self.render_kwargs = dict(render_kwargs)
+        self.rgb_tr, self.rays_o_tr, self.rays_d_tr, self.viewdirs_tr = rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr
+        self.optimizer = optimizer or create_optimizer_or_freeze_model(model, self.cfg_train, global_step=0)
+        self.averager = averager
+        self.poses_train, self.near = poses_train, near
+        if self.cfg_train.get('ray_sampler', 'flatten') not in ('flatten', 'in_maskcache', 'random'):
+            raise NotImplementedError(self.cfg_train.ray_sampler)
+        self.sampler = DeviceBatchSampler(len(rgb_tr), self.cfg_train.N_rand, rgb_tr.device, seed)
+        self._rand = torch.Generator(device=rgb_tr.device)
+        if seed is not None:
+            self._rand.manual_seed(int(seed) + 1)
+        ct = self.cfg_train
+        if ct.get('voxel_inc', False):   # model/nerf_training.py:196-211
+            lo = [ct.x_mid - ct.x_init_ratio * ct.x_mid, ct.y_mid - ct.y_init_ratio * ct.y_mid,
+                  ct.z_mid - ct.z_init_ratio * ct.z_mid]
+            hi = [ct.x_mid + ct.x_init_ratio * (1 - ct.x_mid), ct.y_mid + ct.y_init_ratio * (1 - ct.y_mid),
+                  ct.z_mid + ct.z_init_ratio * (1 - ct.z_mid)]
+            self.inc_lower_init, self.inc_upper_init = torch.tensor(lo), torch.tensor(hi)
+        self._stat_keys = ('psnr', 'wmax', 'wsum', 'wnonzero', 's_val')
+        self._stats = {k: [] for k in self._stat_keys}
+        self.last_result = None
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _tv_active(self, global_step) -> bool:
+        ct = self.cfg_train
+        return ct.tv_from < global_step < ct.tv_end and global_step % ct.tv_every == 0
+
+    def _select_rays(self):
+        ct = self.cfg_train
+        if ct.get('ray_sampler', 'flatten') == 'random':   # flat equivalent of the reference's [B,H,W] triple randint
+            sel = torch.randint(len(self.rgb_tr), [ct.N_rand], generator=self._rand, device=self.rgb_tr.device)
+        else:
+            sel = self.sampler()
+        return self.rgb_tr[sel], self.rays_o_tr[sel], self.rays_d_tr[sel], self.viewdirs_tr[sel]
+
+    # ------------------------------------------------------------------------------------------------ one iteration
+    def step(self, global_step: int) -> torch.Tensor:
+        model, ct, opt = self.model, self.cfg_train, self.optimizer
+        # progressive growing (:243-253)
+        if global_step in ct.get('pg_scale', []):
+            model.scale_volume_grid(model.num_voxels * ct.scale_ratio)
+            if global_step in ct.get('reset_iter', []):
+                model.reset_voxel_and_mlp()
+                if self.cfg_model.get('maskout_near_cam_vox', False) and self.poses_train is not None:
+                    model.maskout_near_cam_vox(self.poses_train[:, :3, 3], self.near)
+            opt = self.optimizer = create_optimizer_or_freeze_model(model, ct, global_step=0)
+        target, rays_o, rays_d, viewdirs = self._select_rays()
+        # voxel increment (:288-295)
+        if ct.get('voxel_inc', False):
+            if global_step <= ct.inc_steps:
+                w = min(global_step * 1.0 / ct.inc_steps, 1.0)
+                model.set_inc_mask(self.inc_lower_init - w * self.inc_lower_init,
+                                   self.inc_upper_init + w * (1 - self.inc_upper_init))
+        else:
+            model.unset_inc_mask()
+        # render (:301)
+        res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs)
+        self.last_result = res
+        opt.zero_grad(set_to_none=True)
+        # losses (:306-327): HIP loss kernels on the fused path, the same torch expressions otherwise
+        loss = fused_render_losses(res, target, ct, model)
+        with torch.no_grad():
+            mse = F.mse_loss(res['rgb_marched'].detach(), target)
+        hinted = False
+        if self.averager is not None and hasattr(res, 'get') and res.get('survivor_pts') is not None:
+            hinted = True
+        tv_now = self._tv_active(global_step)
+        tv_terms = Cfg(ct.get('tv_terms', {}))
+        ori_tv = bool(ct.get('ori_tv', False))
+        if tv_now and ct.get('weight_tv_density', 0) > 0:    # autograd TV terms (:330-345)
+            sdf_tv, smooth_grad_tv = tv_terms.get('sdf_tv', 0), tv_terms.get('smooth_grad_tv', 0)
+            if smooth_grad_tv > 0:
+                loss = loss + ct.weight_tv_density * model.density_total_variation(sdf_tv=0, smooth_grad_tv=smooth_grad_tv)
+            if ori_tv:
+                loss = loss + ct.weight_tv_density * model.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0)
+                if ct.get('weight_tv_k0', 0) > 0:
+                    loss = loss + ct.weight_tv_k0 * model.k0_total_variation(**ct.get('k0_tv_terms', {}))
+                    hinted = False            # k0 receives a dense gradient: the survivor-point occupancy does not cover it
+        if hinted:
+            self.averager.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
+        loss.backward()
+        if self.averager is not None:
+            self.averager.average()
+        n_rays = len(rays_o) * (self.averager.world_size if self.averager is not None else 1)
+        if tv_now and not ori_tv:                            # TV add-grad (:353-371)
+            dense = global_step < ct.get('tv_dense_before', 0)
+            if ct.get('weight_tv_density', 0) > 0 and tv_terms.get('sdf_tv', 0) > 0:
+                model.sdf_total_variation_add_grad(ct.weight_tv_density * tv_terms.sdf_tv / n_rays, dense)
+            if ct.get('weight_tv_k0', 0) > 0:
+                model.k0_total_variation_add_grad(ct.weight_tv_k0 / n_rays, dense)
+        opt.step()
+        # statistics (:374-385), kept on the device
+        # (`weights` is the flat [M] list, so the reference's `.max(-1)` / `.sum(-1)` are over all samples of the batch;
+        # its per-iteration `render_result['mask'].float().mean()` would force the lazily built mask: not collected)
+        with torch.no_grad():
+            w = res['weights'].detach()
+            st = self._stats
+            st['psnr'].append(-10.0 * torch.log10(mse))
+            st['wmax'].append(w.max() if w.numel() else w.new_zeros(()))
+            st['wsum'].append(w.sum())
+            st['wnonzero'].append((w.sum() > 0).float())
+            st['s_val'].append(float(res['s_val']) if 's_val' in res else 0.0)      # a host number already
+        # schedules (:389-456)
+        g_ = global_step - 1
+        f = lr_decay_factor(ct, global_step)
+        for group in opt.param_groups:
+            group['lr'] = group['lr'] * f
+        dsm = ct.get('decay_step_module', {})
+        if g_ in dsm:
+            for group in opt.param_groups:
+                if group['name'] in dsm[g_]:
+                    group['lr'] = group['lr'] * dsm[g_][group['name']]
+        tvu = ct.get('tv_updates', {})
+        if g_ in tvu:
+            terms = dict(ct.get('tv_terms', {}))
+            terms.update(tvu[g_])
+            ct['tv_terms'] = terms
+        su = self.cfg_model.get('s_updates', {})
+        if g_ in su:
+            for k, v in su[g_].items():
+                setattr(model, k, v)
+        smu = self.cfg_model.get('smooth_updates', {})
+        if g_ in smu:
+            model.init_smooth_conv(**smu[g_])
+        return loss
+
+    def stats(self, reset: bool = True) -> Dict[str, float]:
+        """Means of the per-iteration statistics since the last call (one device->host transfer)."""
+        if not self._stats['psnr']:
+            return {}
+        dev_keys = [k for k in self._stat_keys if k != 's_val']
+        stacked = torch.stack([torch.stack(self._stats[k]).float().mean() for k in dev_keys]).cpu()
+        out = {k: float(v) for k, v in zip(dev_keys, stacked)}
+        out['s_val'] = sum(self._stats['s_val']) / len(self._stats['s_val'])
+        if reset:
+            self._stats = {k: [] for k in self._stat_keys}
+        return out

@@ -1,0 +1,125 @@
+"""GPU tests of the per-iteration training body (fgs-nerf_amd/nerf_training.py) against an explicit
+oracle-side loop: CPU autograd through oracle.forward_fine, the oracle's TV-add-grad and Adam kernels, the reference's
+schedule arithmetic written out literally (model/nerf_training.py:300-456)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TRAIN = dict(N_iters=20, N_rand=256, lrate_k0=0.1, lrate_sdf=0.005, lrate_rgbnet=1e-3, lrate_refnet=1e-3, lrate_decay=20,
+             ray_sampler='flatten', weight_main=1.0, weight_entropy_last=0.001, weight_rgbper=0.05, weight_tv_density=0.01,
+             weight_tv_k0=0.0, sigmoid_rgb_loss=0.02, weight_orientation=1e-4, tv_every=3, tv_from=0, tv_end=30000,
+             voxel_inc=False, pg_scale=[], reset_iter=[], tv_terms=dict(sdf_tv=0.1, smooth_grad_tv=0.05),
+             tv_dense_before=20000, cosine_lr=True, cosine_lr_cfg=dict(warm_up_iters=0, const_warm_up=True, warm_up_min_ratio=1.0),
+             decay_step_module={2: dict(sdf=0.1)}, skip_zero_grad_fields=['density', 'k0', 'k1'])
+
+
+def test_schedule_arithmetic_matches_reference_formulas():
+    from fgs_nerf_amd import nerf_training as nt
+    cfg = dict(TRAIN, N_iters=20000)
+    # cosine: factor = cos_lr(g-1) / cos_lr(g-2) with the reference's warm-up branch for negative iterations
+    def cos(it):
+        return 1.0 if it < 0 else (1 + math.cos(it / 20000 * math.pi)) * 0.5
+    for g in (1, 2, 3, 777, 19999):
+        assert abs(nt.lr_decay_factor(cfg, g) - cos(g - 1) / cos(g - 2)) < 1e-15
+    assert abs(nt.lr_decay_factor(dict(cfg, cosine_lr=False), 5) - 0.1 ** (1 / 20000)) < 1e-15
+
+
+def test_stepper_matches_oracle_loop(dev, oracle):
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    G, R, ITERS = 24, 256, 6
+    model = synth.build_model(G, synth.FINE_MODEL, device=dev)
+    rays_c = synth.random_rays(R, seed=11)
+    target_c = torch.rand(R, 3, generator=torch.Generator().manual_seed(12))
+    rays = tuple(r.to(dev) for r in rays_c)
+    P = synth.oracle_params(model)                       # snapshot of the initial parameters on the CPU
+    stepper = nt.TrainStepper(model, TRAIN, {}, synth.RENDER_KWARGS, target_c.to(dev), *rays, stage='fine', seed=5)
+    twin = nt.DeviceBatchSampler(R, R, dev, seed=5)      # the same permutations the stepper will draw
+
+    # ---- oracle-side loop
+    names = ['sdf', 'k0'] + [f'rgbnet.{i}.{k}' for i in range(len(P['rgbnet'])) for k in ('w', 'b')] + \
+            [f'refnet.{i}.{k}' for i in range(len(P['refnet'])) for k in ('w', 'b')]
+    leaves = [P['sdf'], P['k0']] + [t for wb in P['rgbnet'] for t in wb] + [t for wb in P['refnet'] for t in wb]
+    lr = {'k0': 0.1, 'sdf': 0.005, 'rgbnet': 1e-3, 'refnet': 1e-3}
+    state = [(np.zeros(t.numel(), np.float32), np.zeros(t.numel(), np.float32)) for t in leaves]
+    tvk = model.tv_smooth_conv.weight.detach().cpu()
+    vs = P['voxel_size']
+    w_tv = float(TRAIN['weight_tv_density'] * 0.1 / R * max(G, G, G) / 128)
+    losses_o = []
+    for gs in range(1, ITERS + 1):
+        sel = twin().cpu()
+        for t in leaves:
+            t.requires_grad_(True)
+            t.grad = None
+        res = oracle.forward_fine(P, rays_c[0][sel], rays_c[1][sel], rays_c[2][sel], global_step=gs, near=2.0, stepsize=0.5, bg=1)
+        loss = render_losses(res, target_c[sel], TRAIN)
+        tv_now = gs % 3 == 0
+        if tv_now:
+            gv = oracle.neus_sdf_gradient(P['sdf'], vs).permute(1, 0, 2, 3, 4)
+            sm = F.conv3d(F.pad(gv, (1,) * 6, mode='replicate'), tvk)
+            loss = loss + 0.01 * ((sm.detach() - gv) ** 2).mean() * 0.05
+        loss.backward()
+        losses_o.append(float(loss))
+        with torch.no_grad():
+            if tv_now:
+                g = np.ascontiguousarray(P['sdf'].grad.numpy())
+                oracle.K.total_variation_add_grad(np.ascontiguousarray(P['sdf'].detach().numpy()), g, w_tv, w_tv, w_tv, True)
+                P['sdf'].grad.copy_(torch.from_numpy(g))
+            for t, name, (m, v) in zip(leaves, names, state):
+                grp = name.split('.')[0]
+                p = np.ascontiguousarray(t.detach().numpy()).reshape(-1)
+                oracle.K.adam_upd(p, np.ascontiguousarray(t.grad.numpy()).reshape(-1), m, v, gs, 0.9, 0.99, lr[grp], 1e-8,
+                                  mode=1 if grp == 'k0' else 0)
+                t.detach().copy_(torch.from_numpy(p).view_as(t))
+        f = (lambda it: 1.0 if it < 0 else (1 + math.cos(it / 20 * math.pi)) * 0.5)
+        fac = f(gs - 1) / f(gs - 2)
+        for k in lr:
+            lr[k] *= fac
+        if gs - 1 == 2:
+            lr['sdf'] *= 0.1
+
+    # ---- the stepper
+    losses_g = [float(stepper.step(gs)) for gs in range(1, ITERS + 1)]
+    for a, b in zip(losses_g, losses_o):
+        assert abs(a - b) < 2e-4 * abs(b), (losses_g, losses_o)
+    lrs = {g['name']: g['lr'] for g in stepper.optimizer.param_groups}
+    for k in lr:
+        assert abs(lrs[k] - lr[k]) < 1e-12 * max(1.0, lr[k]), (k, lrs[k], lr[k])
+    # parameters after 6 Adam steps.  Adam divides by sqrt(v): where a gradient is at rounding-noise level the update
+    # direction is not determined, so a handful of voxels may sit one lr step apart -- bounded by the tolerance below
+    assert rel_l2(model.sdf.grid, P['sdf']) < 2e-3
+    assert rel_l2(model.k0.grid, P['k0']) < 5e-2
+    st = stepper.stats()
+    assert set(st) == {'psnr', 'wmax', 'wsum', 'wnonzero', 's_val'} and st['psnr'] > 0
+
+
+def test_stepper_fused_and_composed_agree_and_coarse_runs(dev):
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    R = 512
+    rays = tuple(r.to(dev) for r in synth.random_rays(R, seed=3))
+    target = torch.rand(R, 3, device=dev)
+    out = {}
+    for fused in (True, False):
+        model = synth.build_model(32, synth.FINE_MODEL, device=dev, fused=fused)
+        st = nt.TrainStepper(model, dict(TRAIN, N_rand=R), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=9)
+        out[fused] = [float(st.step(g)) for g in range(1, 5)]
+    for a, b in zip(out[True], out[False]):
+        assert abs(a - b) < 1e-3 * abs(b), out
+    # coarse stage with the voxel-increment schedule and the exponential decay
+    cfg = dict(TRAIN, N_rand=R, cosine_lr=False, decay_step_module={}, lrate_rgbnet=0, voxel_inc=True, inc_steps=3,
+               x_mid=0.5, y_mid=0.5, z_mid=0.5, x_init_ratio=0.6, y_init_ratio=0.6, z_init_ratio=0.6,
+               weight_rgbper=0.2, sigmoid_rgb_loss=0.1)
+    model = synth.build_model(32, synth.COARSE_MODEL, device=dev)
+    st = nt.TrainStepper(model, cfg, {}, synth.RENDER_KWARGS, target, *rays, stage='coarse', seed=9)
+    ls = [float(st.step(g)) for g in range(1, 7)]
+    assert all(np.isfinite(ls)) and model.inc_mask is not None
+    assert abs(st.optimizer.param_groups[0]['lr'] - 0.1 * (0.1 ** (1 / 20000)) ** 6) < 1e-9
