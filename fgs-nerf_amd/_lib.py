@@ -37,7 +37,7 @@ _SIGNATURES = {
     "fgs_trilerp_bwd": [P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I64, P, P],
     "fgs_sdf_taps_fwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P, P],
     "fgs_sdf_taps_bwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P],
-    "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P],
+    "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P, I64, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -85,7 +85,7 @@ class FgsError(RuntimeError):
 
 def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
-    return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info"])
+    return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes"])
 
 
 def lib() -> ctypes.CDLL:
@@ -103,6 +103,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_last_error.restype = c_char_p
         handle.fgs_last_error.argtypes = []
         handle.fgs_version.restype = c_int
+        handle.fgs_gemm_workspace_bytes.restype = c_int64
+        handle.fgs_gemm_workspace_bytes.argtypes = []
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                            ctypes.POINTER(c_int64)]
         handle.fgs_device_info.restype = c_int

@@ -123,43 +123,23 @@ __device__ __forceinline__ void half_load(float (&f)[8], const float *__restrict
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];  // [buffer][A|B]
+typedef float LdsImage[2][2][TILE_FLOATS];  // [buffer][A|B]
 
-  // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
-  const int b = blockIdx.x;
-  int tile_m, tile_n;
-  int64_t k_begin = 0, k_end = g.K;
-  if (EPI == EPI_ATOMIC) {
-    // split-K: few output tiles, many K slices.  Consecutive ids (dealt round-robin over the 8 XCDs) take the
-    // tiles of one slice, so every XCD works and the 2-4 tiles sharing a slice of A / B run at the same time.
-    const int tiles = g.tiles_m * g.tiles_n;
-    const int split = b / tiles, tile = b - split * tiles;
-    tile_m = tile % g.tiles_m;
-    tile_n = tile / g.tiles_m;
-    k_begin = (int64_t)split * g.k_per_split;
-    k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
-    if (k_begin >= k_end) return;
-  } else {
-    const int grp = b / (8 * g.tiles_n);
-    const int within = b - grp * 8 * g.tiles_n;
-    tile_m = grp * 8 + (within & 7);
-    tile_n = within >> 3;
-    if (tile_m >= g.tiles_m) return;
-  }
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
-  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-
-  floatx16 acc[2][2];
+__device__ __forceinline__ void acc_zero(floatx16 (&acc)[2][2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// acc += A[m0.., k_begin..k_end) * B[n0.., k_begin..k_end) for one 128x128 tile.  Leaves every wave past its last LDS read.
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
+                                              floatx16 (&acc)[2][2], LdsImage &lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
 
   // Software pipeline, three stages deep, one raw barrier per K chunk:
   //   global -> staging registers : chunk c+2 (issued at the top of iteration c, a full iteration to land)
@@ -230,8 +210,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();  // every wave is past its last LDS fragment read before the epilogue reuses the image
+}
 
-  // ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
+// ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int64_t n0, floatx16 (&acc)[2][2],
+                                              LdsImage &lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
   if (EPI == EPI_ATOMIC) {
     // one atomic wave-instruction = two 128-byte row segments (the full-rate shape for global_atomic_add_f32)
 #pragma unroll
@@ -304,6 +290,129 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   }
 }
 
+// One workgroup per output tile (EPI_STORE) or per (tile, K slice) (EPI_ATOMIC).
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) LdsImage lds;
+
+  // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
+  const int b = blockIdx.x;
+  int tile_m, tile_n;
+  int64_t k_begin = 0, k_end = g.K;
+  if (EPI == EPI_ATOMIC) {
+    // split-K: few output tiles, many K slices.  Consecutive ids (dealt round-robin over the 8 XCDs) take the
+    // tiles of one slice, so every XCD works and the 2-4 tiles sharing a slice of A / B run at the same time.
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int split = b / tiles, tile = b - split * tiles;
+    tile_m = tile % g.tiles_m;
+    tile_n = tile / g.tiles_m;
+    k_begin = (int64_t)split * g.k_per_split;
+    k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
+    if (k_begin >= k_end) return;
+  } else {
+    const int grp = b / (8 * g.tiles_n);
+    const int within = b - grp * 8 * g.tiles_n;
+    tile_m = grp * 8 + (within & 7);
+    tile_n = within >> 3;
+    if (tile_m >= g.tiles_m) return;
+  }
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+  floatx16 acc[2][2];
+  acc_zero(acc);
+  tile_mainloop<A_KC, B_KC>(g, m0, n0, k_begin, k_end, acc, lds);
+  tile_epilogue<EPI>(g, m0, n0, acc, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream-K form of the EPI_STORE products -- OPT-IN (the caller passes a workspace), NOT the default: measured on MI355X it
+// only ties with the tile-per-workgroup kernel (M = 49 920, K = N = 256: 83.0 vs 82.4 us; M = 16 384: 48 vs 29 us;
+// M = 105 000, K = 192: 126 vs 114 us).  The balance it buys (ideal 51 us of MFMA time at M = 49 920 instead of two
+// rounds) is eaten by what every extra tile SEGMENT costs here: ~2.5 us first-chunk latency, ~3 us LDS-staged epilogue,
+// ~3 us of the 64 KB output burst, the 64 KB partial-tile hand-over and its agent-scope release / acquire.  It stays as
+// the tested base for the next step (overlapping a segment's epilogue with the next segment's first loads).
+// One tile's K loop is only n_chunks = K/32 (8 for the 256-wide layers) long and
+// a launch has T = tiles_m * tiles_n tiles for 2 x 256 workgroup slots: T = 780 (M_s = 50 K) costs two full rounds, the
+// second one 52 % occupied (measured: 88 us, the same as T = 1024).  Here the T * n_chunks chunk-units are cut into
+// G = 2 x CUs equal contiguous ranges, one per resident workgroup.  A range covers the tail of one tile, zero or more
+// whole tiles and the head of another.  The workgroup that holds a tile's FIRST chunk owns it: it adds the partial
+// accumulators of the following workgroup(s) (parked in a per-workgroup 64 KB workspace slot, announced through an
+// agent-scope release/acquire flag) and runs the ordinary bias / ReLU / mask / column-sum epilogue.  A non-owned partial is
+// always the first thing a workgroup computes and never waits on anybody, so there is no circular wait, and with
+// G <= resident capacity every producer is running.  The k-order of a split tile's sum is (head chunks) + (tail chunks)
+// instead of one chain: fp32-level reassociation only.  Flags are reset by their consumer: the workspace stays clean.
+struct StreamK {
+  int units, n_chunks;  // total chunk-units (< 2^31), chunks per tile
+  int G;                // workgroups
+  float *ws;            // [G][64][256] partial accumulators in register layout
+  int *flags;           // [G], zero outside a launch
+};
+
+__device__ __forceinline__ int sk_range_begin(const StreamK &s, int w) { return (int)(((int64_t)s.units * w) / s.G); }
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void k_gemm_sk(GemmArgs g, StreamK s) {
+  __shared__ __attribute__((aligned(16))) LdsImage lds;
+  // consecutive ranges on the same XCD (block ids b, b+8, ... share an XCD): neighbours share A row tiles in its L2 and
+  // hand partial tiles over through it
+  const int w = (blockIdx.x & 7) * (s.G >> 3) + (blockIdx.x >> 3);   // G is a multiple of 8
+  const int tid = threadIdx.x;
+  int u = sk_range_begin(s, w);
+  const int u_end = sk_range_begin(s, w + 1);
+  floatx16 acc[2][2];
+  while (u < u_end) {
+    const int tile = u / s.n_chunks, c0 = u - tile * s.n_chunks;
+    const int c1 = (u_end - tile * s.n_chunks < s.n_chunks) ? u_end - tile * s.n_chunks : s.n_chunks;
+    const int tile_m = tile / g.tiles_n, tile_n = tile - tile_m * g.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int64_t k_begin = (int64_t)c0 * BK, k_end = ((int64_t)c1 * BK < g.K) ? (int64_t)c1 * BK : g.K;
+    acc_zero(acc);
+    tile_mainloop<A_KC, B_KC>(g, m0, n0, k_begin, k_end, acc, lds);
+    if (c0 != 0) {
+      // not the owner: park the partial sums (register layout, coalesced) and announce them
+      float *slot = s.ws + (int64_t)w * (64 * 256) + tid;
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const floatx16 v = (q == 0) ? acc[0][0] : (q == 1) ? acc[0][1] : (q == 2) ? acc[1][0] : acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(q * 16 + r) * 256] = v[r];
+      }
+      // one agent-scope release per workgroup: the barrier orders every thread's stores before thread 0's release
+      // (a per-thread __threadfence() costs an L2 write-back per wave and made split tiles 3x slower)
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(s.flags + w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // owner: collect what the following workgroups hold of this tile
+      int have = c1, wn = w;
+      while (have < s.n_chunks) {
+        ++wn;
+        const int nb = sk_range_begin(s, wn), ne = sk_range_begin(s, wn + 1), tile_end = (tile + 1) * s.n_chunks;
+        have += ((ne < tile_end) ? ne : tile_end) - nb;
+        // poll with relaxed loads (an acquire load invalidates caches on every iteration), then ONE acquire fence
+        if (tid == 0)
+          while (__hip_atomic_load(s.flags + wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float *slot = s.ws + (int64_t)wn * (64 * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = slot[((i * 2 + j) * 16 + r) * 256];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += t[r];
+          }
+        __syncthreads();   // all four waves have read the slot
+        if (tid == 0) __hip_atomic_store(s.flags + wn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      tile_epilogue<EPI_STORE>(g, m0, n0, acc, lds);
+    }
+    __syncthreads();  // the LDS image (epilogue staging) is free again
+    u = tile * s.n_chunks + c1;
+  }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
   const unsigned groups = (unsigned)((g.tiles_m + 7) / 8);
@@ -313,13 +422,36 @@ int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
   return 0;
 }
 
+template <bool A_KC, bool B_KC>
+int launch_sk(const GemmArgs &g, const StreamK &s, hipStream_t st) {
+  hipLaunchKernelGGL((k_gemm_sk<A_KC, B_KC>), dim3((unsigned)s.G), dim3(256), 0, st, g, s);
+  FGS_LAUNCH_OK("fgs_gemm_f32 (stream-K)");
+  return 0;
+}
+
+int resident_slots() {  // 2 workgroups of k_gemm_sk per CU (73.7 KB LDS each, <= 128 VGPRs)
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+      cus = 256;
+    slots = 2 * cus;
+  }
+  return slots;
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+// Bytes of scratch the stream-K form wants: G partial-tile slots of 64 KB + G flags (the flag words must be ZERO when
+// first handed in; the kernels leave them zero).
+FGS_API int64_t fgs_gemm_workspace_bytes(void) { return (int64_t)resident_slots() * (64 * 256 * 4 + 4); }
+
 FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
                          int64_t ldb, float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm,
-                         float *colsum, fgs_stream_t stream) {
+                         float *colsum, void *workspace, int64_t workspace_bytes, fgs_stream_t stream) {
   FGS_REQUIRE(op >= 0 && op <= 2, FGS_E_INVALID, "fgs_gemm_f32: op=%d", op);
   FGS_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31),
               FGS_E_RANGE, "fgs_gemm_f32: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -342,6 +474,27 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
   hipStream_t st = fgs_s(stream);
+  if (op != FGS_GEMM_TN && workspace) {
+    // the caller asked for stream-K (by passing a workspace); used when it can balance: more than a handful of tiles,
+    // a K loop worth cutting, every range non-empty
+    const int sk_mode = 1;
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n, n_chunks = (K + BK - 1) / BK;
+    StreamK s;
+    const int64_t units = tiles * n_chunks;
+    s.n_chunks = (int)n_chunks;
+    s.units = (int)units;
+    int64_t G = resident_slots();
+    if (G > units / 2) G = units / 2;
+    G &= ~(int64_t)7;   // a multiple of 8: whole ranges per XCD
+    s.G = (int)G;
+    if (sk_mode && tiles >= 32 && n_chunks >= 2 && G >= 16 && units < ((int64_t)1 << 30)) {
+      FGS_REQUIRE(workspace_bytes >= fgs_gemm_workspace_bytes() && aligned16(workspace), FGS_E_INVALID,
+                  "fgs_gemm_f32: workspace must be 16-byte aligned and hold fgs_gemm_workspace_bytes() bytes");
+      s.ws = reinterpret_cast<float *>(workspace);   // slots first, the flag words behind ALL resident_slots() slots
+      s.flags = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + (int64_t)resident_slots() * (64 * 256 * 4));
+      return op == FGS_GEMM_NT ? launch_sk<true, true>(g, s, st) : launch_sk<true, false>(g, s, st);
+    }
+  }
   switch (op) {
     case FGS_GEMM_NT: return launch<true, true, EPI_STORE>(g, 1, st);
     case FGS_GEMM_NN: return launch<true, false, EPI_STORE>(g, 1, st);

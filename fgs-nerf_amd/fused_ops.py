@@ -7,18 +7,34 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, lib, ptr, stream
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 
+_WORKSPACE = {}   # (device index, stream handle) -> zero-initialised scratch of fgs_gemm_workspace_bytes()
+
+
+def gemm_workspace(device: torch.device) -> torch.Tensor:
+    """Scratch for the stream-K form of the NT / NN products: one buffer per (device, stream), zeroed once (the kernels
+    leave the flag words zero)."""
+    key = (device.index, stream())
+    ws = _WORKSPACE.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib().fgs_gemm_workspace_bytes()), dtype=torch.uint8, device=device)
+        _WORKSPACE[key] = ws
+    return ws
+
 
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, bias=None, relu=False,
-         mask=None, colsum=None) -> torch.Tensor:
+         mask=None, colsum=None, stream_k: bool = False) -> torch.Tensor:
     """C = op(A, B) with the epilogues of include/fgs_hip.h fgs_gemm_f32.  A, B, C, mask are 2-D row-major views
-    (stride(1) == 1); leading dimensions are taken from stride(0)."""
+    (stride(1) == 1); leading dimensions are taken from stride(0).  `stream_k` selects the opt-in stream-K grid for
+    NT / NN (measured: no faster than one tile per workgroup at the MLP shapes, see csrc/gemm_f32.hip)."""
     for t in (A, B, C) + ((mask,) if mask is not None else ()):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError("gemm operands must be 2-D float32 CUDA tensors with unit column stride")
+    ws = gemm_workspace(C.device) if (stream_k and op != GEMM_TN) else None
     call("fgs_gemm_f32", op, M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), ptr(bias),
-         int(bool(relu)), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), stream())
+         int(bool(relu)), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(ws),
+         0 if ws is None else ws.numel(), stream())
     return C

@@ -207,13 +207,19 @@ int fgs_sdf_taps_bwd(float *grad_grid, int64_t X, int64_t Y, int64_t Z, const fl
  * colsum (NT/NN, may be NULL): colsum[n] += sum_m C[m,n] after the epilogue (bias gradients).
  * Operands 16-byte aligned, leading dimensions multiples of 4 floats; NT: K % 4 == 0; NN: K, N % 4 == 0;
  * TN: M, N % 4 == 0.  M (NT/NN) and K (TN) -- the sample count -- are arbitrary.
+ * workspace (may be NULL): fgs_gemm_workspace_bytes() bytes of device scratch, 16-byte aligned, whose LAST
+ * resident-slot-count int32 words were zero when it was first handed in (simplest: zero all of it once).  With it the
+ * NT / NN products run as a stream-K grid (the chunk-units of all tiles cut into one equal range per resident
+ * workgroup), which removes the partially filled last round of tiles; without it, one workgroup per tile.  A workspace
+ * must not be shared by launches that can overlap (one per stream).
  * ------------------------------------------------------------------------------ */
 #define FGS_GEMM_NT 0
 #define FGS_GEMM_NN 1
 #define FGS_GEMM_TN 2
+int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,
-                 fgs_stream_t stream);
+                 void *workspace, int64_t workspace_bytes, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Fused fine-stage render path -- nerf.forward_fine (model/nerf.py:776-941) as a short kernel chain.

@@ -19,8 +19,8 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-for M in (16384, 32768, 65536):
-    for K in (32, 128, 256, 512, 1024, 2048):
+for M in (16384, 32768, 49920, 65536, 105000):
+    for K in (128, 192, 256, 1024):
         X = torch.randn(M, K, device=dev)
         W = torch.randn(256, K, device=dev) * 0.1
         b = torch.randn(256, device=dev)

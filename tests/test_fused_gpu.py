@@ -199,3 +199,32 @@ def test_masked_adam_multi_tensor_matches_oracle(dev, oracle):
             oracle.K.adam_upd(ref[i], g, ms[i], vs[i], step, 0.9, 0.99, 1e-3 if i < 3 else 5e-2, 1e-8, mode=0 if i < 3 else 1)
     for p, r in zip(params, ref):
         assert np.array_equal(p.detach().cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("M,K,N", [(49920, 256, 256), (4100, 108, 256), (4097, 308, 192), (65536, 256, 256),
+                                   (12345, 64, 256), (50001, 192, 192), (4096, 32, 256), (200000, 256, 128)])
+def test_gemm_stream_k_matches_fp64(dev, M, K, N):
+    """The opt-in stream-K form of the NT / NN products (one equal range of chunk-units per resident workgroup, split tiles
+    finished by their owner) against fp64, with every epilogue (bias, ReLU, mask, column sums), repeated launches on the
+    same workspace (the flag words must come back to zero), ragged M and K that is not a multiple of the 32-chunk."""
+    from fgs_nerf_amd import fused_ops as fo
+    torch.manual_seed(M % 1000)
+    ld = (K + 3) // 4 * 4
+    X = torch.randn(M, ld, device=dev)
+    X[:, K:] = 0
+    W, b = torch.randn(N, ld, device=dev) * 0.1, torch.randn(N, device=dev)
+    W[:, K:] = 0
+    ref = torch.relu(X.double() @ W.double().T + b.double())
+    for rep in range(3):
+        Y, cs = torch.full((M, N), float('nan'), device=dev), torch.zeros(N, device=dev)
+        fo.gemm(fo.GEMM_NT, X, W, Y, M, N, ld, bias=b, relu=True, colsum=cs, stream_k=True)
+        assert rel_l2(Y, ref) < 1e-6 and rel_l2(cs, ref.sum(0)) < 1e-5, rep
+    dY, act = torch.randn(M, N, device=dev), torch.randn(M, ld, device=dev)
+    refd = (dY.double() @ W.double()) * (act > 0)
+    for rep in range(2):
+        dX, cs = torch.full((M, ld), float('nan'), device=dev), torch.zeros(ld, device=dev)
+        fo.gemm(fo.GEMM_NN, dY, W, dX, M, ld, N, mask=act, colsum=cs, stream_k=True)
+        assert rel_l2(dX, refd) < 1e-6 and rel_l2(cs, refd.sum(0)) < 1e-5, rep
+    ws = fo.gemm_workspace(X.device)
+    n_flags = 4 * 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    assert int(ws[-n_flags:].view(torch.int32).abs().sum()) == 0          # every flag consumed and reset
