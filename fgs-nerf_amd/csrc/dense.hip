@@ -30,7 +30,7 @@ constexpr int CT_X = 8, CT_Y = 8, CT_Z = 32, CT_ZPT = 8;
 
 template <int K, bool REPL>
 __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restrict__ in, int nx, int ny, int nz,
-                                                            Conv3 c /* X,Y,Z = OUTPUT dims */, int shift,
+                                                            Conv3 c /* X,Y,Z = OUTPUT dims */, int shift, int64_t es,
                                                             float *__restrict__ out) {
   constexpr int LX = CT_X + K - 1, LY = CT_Y + K - 1, LZU = CT_Z + K - 1;
   constexpr int LZ = LZU | 1;  // odd row pitch: the 8 (y) x 4 (z-group) lanes of a wave hit distinct banks
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restr
     int qx = ox0 + lx - shift, qy = oy0 + ly - shift, qz = oz0 + lz - shift;
     const bool ok = REPL || (fgs_in(qx, nx) && fgs_in(qy, ny) && fgs_in(qz, nz));
     qx = clampi(qx, 0, nx - 1); qy = clampi(qy, 0, ny - 1); qz = clampi(qz, 0, nz - 1);
-    const float v = in[((int64_t)qx * ny + qy) * nz + qz];   // address always valid: branch-free load
+    const float v = in[(((int64_t)qx * ny + qy) * nz + qz) * es];   // address always valid: branch-free load (es: element stride)
     if (i < TOTAL) tile[(lx * LY + ly) * LZ + lz] = ok ? v : 0.f;
   }
   __syncthreads();
@@ -104,14 +104,14 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_fold_padded(const float *__restri
 }
 
 template <bool REPL>
-void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int shift, float *out, hipStream_t st) {
+void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int shift, int64_t es, float *out, hipStream_t st) {
   const int64_t tiles = (int64_t)((c.X + CT_X - 1) / CT_X) * ((c.Y + CT_Y - 1) / CT_Y) * ((c.Z + CT_Z - 1) / CT_Z);
   const dim3 grid((unsigned)tiles), block(FGS_BLOCK);
   switch (c.k) {
-    case 1: hipLaunchKernelGGL((k_conv3d_tiled<1, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
-    case 3: hipLaunchKernelGGL((k_conv3d_tiled<3, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
-    case 5: hipLaunchKernelGGL((k_conv3d_tiled<5, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
-    default: hipLaunchKernelGGL((k_conv3d_tiled<7, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, out); break;
+    case 1: hipLaunchKernelGGL((k_conv3d_tiled<1, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
+    case 3: hipLaunchKernelGGL((k_conv3d_tiled<3, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
+    case 5: hipLaunchKernelGGL((k_conv3d_tiled<5, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
+    default: hipLaunchKernelGGL((k_conv3d_tiled<7, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
   }
 }
 
@@ -129,8 +129,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_fwd(const float *__restri
 }
 
 // d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v-1 interior] - dg_axis[v+1] * [v+1 interior] ) / 2 / vs
-__global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restrict__ dg, int X, int Y, int Z, float vs,
-                                                           float *__restrict__ d_s, int accumulate) {
+// dg component c of voxel v lives at dg[c * sC + v * sV] ((XYZ, 1) for the dense [3,X,Y,Z] layout)
+__global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restrict__ dg, int64_t sC, int64_t sV, int X,
+                                                           int Y, int Z, float vs, float *__restrict__ d_s, int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t N = (int64_t)X * Y * Z;
   if (idx >= N) return;
@@ -138,12 +139,12 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restri
   const int64_t sx = (int64_t)Y * Z, sy = Z;
   float acc = 0.f;
   // s[v] appears as "+" in g at v-1 (needs 1 <= v-1 <= n-2) and as "-" in g at v+1 (needs 1 <= v+1 <= n-2)
-  if (x - 1 >= 1 && x - 1 <= X - 2) acc += dg[idx - sx] / 2.f / vs;
-  if (x + 1 >= 1 && x + 1 <= X - 2) acc -= dg[idx + sx] / 2.f / vs;
-  if (y - 1 >= 1 && y - 1 <= Y - 2) acc += dg[N + idx - sy] / 2.f / vs;
-  if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= dg[N + idx + sy] / 2.f / vs;
-  if (z - 1 >= 1 && z - 1 <= Z - 2) acc += dg[2 * N + idx - 1] / 2.f / vs;
-  if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= dg[2 * N + idx + 1] / 2.f / vs;
+  if (x - 1 >= 1 && x - 1 <= X - 2) acc += dg[(idx - sx) * sV] / 2.f / vs;
+  if (x + 1 >= 1 && x + 1 <= X - 2) acc -= dg[(idx + sx) * sV] / 2.f / vs;
+  if (y - 1 >= 1 && y - 1 <= Y - 2) acc += dg[sC + (idx - sy) * sV] / 2.f / vs;
+  if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= dg[sC + (idx + sy) * sV] / 2.f / vs;
+  if (z - 1 >= 1 && z - 1 <= Z - 2) acc += dg[2 * sC + (idx - 1) * sV] / 2.f / vs;
+  if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= dg[2 * sC + (idx + 1) * sV] / 2.f / vs;
   d_s[idx] = accumulate ? d_s[idx] + acc : acc;
 }
 
@@ -163,24 +164,25 @@ FGS_API int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const 
   Conv3 c;
   if (int e = make_conv("fgs_smooth3d_fwd", X, Y, Z, k, taps_host, &c)) return e;
   FGS_REQUIRE(in && out && in != out, FGS_E_INVALID, "fgs_smooth3d_fwd: null or aliased pointers");
-  launch_conv<true>(in, X, Y, Z, c, k / 2, out, fgs_s(stream));
+  launch_conv<true>(in, X, Y, Z, c, k / 2, 1, out, fgs_s(stream));
   FGS_LAUNCH_OK("fgs_smooth3d_fwd");
   return 0;
 }
 
 // d_in = adjoint(d_out).  `scratch` holds the adjoint on the padded domain: (X+k-1)(Y+k-1)(Z+k-1) floats.
-FGS_API int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *scratch,
-                             float *d_in, fgs_stream_t stream) {
+// d_out element (x,y,z) lives at d_out[((x*Y + y)*Z + z) * out_stride] (1 = dense; 4 = channel 0 of a [X,Y,Z,4] buffer).
+FGS_API int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int Y, int Z, int k, const float *taps_host,
+                             float *scratch, float *d_in, fgs_stream_t stream) {
   Conv3 c;
   if (int e = make_conv("fgs_smooth3d_bwd", X, Y, Z, k, taps_host, &c)) return e;
-  FGS_REQUIRE(d_out && d_in && scratch && d_in != d_out && scratch != d_out && scratch != d_in, FGS_E_INVALID,
-              "fgs_smooth3d_bwd: null or aliased pointers");
+  FGS_REQUIRE(d_out && d_in && scratch && d_in != d_out && scratch != d_out && scratch != d_in && out_stride >= 1,
+              FGS_E_INVALID, "fgs_smooth3d_bwd: null or aliased pointers, or out_stride < 1");
   // dP[q] = sum_t w[t] d_out[q - (t - r)] = sum_t' w[k-1-t'] d_out[q + t' - r]: flipped taps on the padded output domain
   Conv3 f = c;
   const int n3 = k * k * k;
   for (int i = 0; i < n3; ++i) f.w[i] = c.w[n3 - 1 - i];
   f.X = X + k - 1; f.Y = Y + k - 1; f.Z = Z + k - 1;
-  launch_conv<false>(d_out, X, Y, Z, f, k - 1, scratch, fgs_s(stream));
+  launch_conv<false>(d_out, X, Y, Z, f, k - 1, out_stride, scratch, fgs_s(stream));
   FGS_LAUNCH_OK("fgs_smooth3d_bwd/conv");
   hipLaunchKernelGGL(k_fold_padded, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), scratch, X, Y, Z,
                      k / 2, d_in);
@@ -197,12 +199,12 @@ FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float vox
   return 0;
 }
 
-FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int X, int Y, int Z, float voxel_size, float *d_sdf, int accumulate,
-                                fgs_stream_t stream) {
+FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
+                                float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream) {
   FGS_REQUIRE(X > 0 && Y > 0 && Z > 0 && (int64_t)X * Y * Z < ((int64_t)1 << 38), FGS_E_RANGE, "fgs_sdf_gradvol_bwd: size");
-  FGS_REQUIRE(d_grad3 && d_sdf, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: null pointer");
-  hipLaunchKernelGGL(k_gradvol_bwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3, X, Y, Z,
-                     voxel_size, d_sdf, accumulate);
+  FGS_REQUIRE(d_grad3 && d_sdf && chan_stride >= 1 && voxel_stride >= 1, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: bad arguments");
+  hipLaunchKernelGGL(k_gradvol_bwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
+                     chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
   FGS_LAUNCH_OK("fgs_sdf_gradvol_bwd");
   return 0;
 }

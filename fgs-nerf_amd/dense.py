@@ -25,6 +25,17 @@ def _check_grid(g: torch.Tensor):
     return int(g.shape[2]), int(g.shape[3]), int(g.shape[4])
 
 
+def _voxel_stride(t: torch.Tensor, X: int, Y: int, Z: int):
+    """e if the spatial strides of a [1,C,X,Y,Z] tensor are (Y*Z*e, Z*e, e) -- dense (e = 1) or a channel slice of a
+    voxel-interleaved buffer (e = 4) -- else None."""
+    if t.dtype != torch.float32 or t.dim() != 5:
+        return None
+    e = t.stride(4)
+    if e >= 1 and t.stride(3) == Z * e and t.stride(2) == Y * Z * e:
+        return int(e)
+    return None
+
+
 class _Smooth3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, taps_c, k):
@@ -39,10 +50,12 @@ class _Smooth3d(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
         X, Y, Z, k, taps_c = ctx.meta
-        d_out = d_out.contiguous()
-        d_in = torch.empty_like(d_out)
+        es = _voxel_stride(d_out, X, Y, Z)         # e.g. channel 0 of the interleaved [X,Y,Z,4] buffer: no copy
+        if es is None:
+            d_out, es = d_out.contiguous(), 1
+        d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
         scratch = torch.empty((X + k - 1) * (Y + k - 1) * (Z + k - 1), dtype=torch.float32, device=d_out.device)
-        call("fgs_smooth3d_bwd", ptr(d_out), X, Y, Z, k, taps_c, ptr(scratch), ptr(d_in), stream())
+        call("fgs_smooth3d_bwd", ptr(d_out), es, X, Y, Z, k, taps_c, ptr(scratch), ptr(d_in), stream())
         return d_in, None, None
 
 
@@ -66,9 +79,12 @@ class _GradVol(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
         X, Y, Z, vs = ctx.meta
-        d_out = d_out.contiguous()
+        sv = _voxel_stride(d_out, X, Y, Z)
+        if sv is None:
+            d_out, sv = d_out.contiguous(), 1
+        sc = d_out.stride(1)
         d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
-        call("fgs_sdf_gradvol_bwd", ptr(d_out), X, Y, Z, vs, ptr(d_in), 0, stream())
+        call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, ptr(d_in), 0, stream())
         return d_in, None
 
 

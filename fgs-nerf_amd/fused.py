@@ -505,13 +505,15 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
              g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
              ptr(g_grad_s), st)
-        d_smooth = torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev)
-        d_gradvol = torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev)
+        # voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of it
+        # in place through element strides
+        d4 = torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev)
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['n_alive']), ptr(ws['n_surv']),
-             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d_smooth),
-             ptr(d_gradvol), st)
+             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), st)
+        d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
+        d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
         grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]
         for i in range(n_ref):
             grads += [gw[i].contiguous(), gb[i].contiguous()]

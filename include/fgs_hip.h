@@ -333,11 +333,15 @@ int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, co
  * fgs_sdf_gradvol_*: neus_sdf_gradient(mode='interpolate') (model/nerf.py:485-494): grad3 [3,X,Y,Z], central
  *   differences / 2 / voxel_size, zero on the two boundary faces of each axis.  bwd: d_sdf (+)= adjoint(d_grad3). */
 int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const float *taps_host, float *out, fgs_stream_t stream);
-int fgs_smooth3d_bwd(const float *d_out, int X, int Y, int Z, int k, const float *taps_host, float *scratch, float *d_in,
-                     fgs_stream_t stream);
+/* The two adjoints read their incoming gradient through element strides, so they can consume the voxel-interleaved
+ * [X,Y,Z,4] buffer fgs_march_coarse_bwd accumulates into without a de-interleaving pass:
+ *   d_out(x,y,z)     = d_out  [((x*Y + y)*Z + z) * out_stride]                 (dense: 1;        interleaved: 4)
+ *   d_grad3(c,x,y,z) = d_grad3[c * chan_stride + ((x*Y + y)*Z + z) * voxel_stride]  (dense: XYZ, 1; interleaved: 1, 4) */
+int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int Y, int Z, int k, const float *taps_host,
+                     float *scratch, float *d_in, fgs_stream_t stream);
 int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, fgs_stream_t stream);
-int fgs_sdf_gradvol_bwd(const float *d_grad3, int X, int Y, int Z, float voxel_size, float *d_sdf, int accumulate,
-                        fgs_stream_t stream);
+int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
+                        float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream);
 
 /* Fused front half of forward_coarse (model/nerf.py:946-990), one wavefront per ray: sample_pts_on_rays, optional mask
  * cache (stage 'coarse' only, :952-959) and voxel-increment MaskGrid (:962-967; inc_world uint8 [iX,iY,iZ] with the
@@ -357,15 +361,16 @@ int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const float *
                          fgs_stream_t stream);
 /* Backward of the second Alphas2Weights + NeuS alpha + the two trilinear lookups: g_weights [M_s], g_last [n_rays]
  * (may be NULL), g_gradient [M_s,3] (gradient reaching the sampled gradient vectors through the features, may be NULL)
- * -> atomically accumulated d_sdf_smooth [X,Y,Z] and d_gradvol [3,X,Y,Z] (not zeroed here).  The first
- * Alphas2Weights only selects samples and carries no gradient (its weights are overwritten at :990). */
+ * -> atomically accumulated into d_grid4 [X,Y,Z,4] (not zeroed here): per voxel (d smoothed-sdf, d gradient-volume x,y,z)
+ * interleaved, so one atomic wave-instruction covers the contiguous corner pairs of two samples (5 cache-line requests
+ * per sample instead of 32).  The first Alphas2Weights only selects samples and carries no gradient (:990). */
 int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
                          const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near, float far,
                          float stepdist, float dist, float inv_s, int max_steps, const int *a_step, const float *a_alpha,
                          const float *a_T, const float *a_weight, const float *a_sdf, const float *a_grad,
                          const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off, const float *alphainv_last,
-                         const float *g_weights, const float *g_last, const float *g_gradient, float *d_sdf_smooth,
-                         float *d_gradvol, fgs_stream_t stream);
+                         const float *g_weights, const float *g_last, const float *g_gradient, float *d_grid4,
+                         fgs_stream_t stream);
 
 /* Coarse-stage MLP operand rows X0 [M, ldx0] = torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb]) (zero padded),
  * model/nerf.py:992-1009.  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, ldx0}. */
