@@ -355,10 +355,16 @@ class nerf(torch.nn.Module):
                 g = grad.permute(1, 0, 2, 3, 4)
                 err = self.tv_smooth_conv(g).detach() - g
             if self.nonempty_mask is not None:
-                err = err[self.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2
+                # mean over the masked elements, written as a masked sum / count: the reference's boolean index
+                # (`err[mask.repeat(3,...)] ** 2).mean()`) is a nonzero() host sync plus a gather of the 3 volumes
+                m = self.nonempty_mask
+                cnt = self.__dict__.get('_nonempty_count')
+                if cnt is None or cnt[0] is not m:
+                    cnt = (m, 3.0 * m.sum().to(torch.float32))
+                    self.__dict__['_nonempty_count'] = cnt
+                tv += ((err ** 2) * m.to(err.dtype)).sum() / cnt[1] * smooth_grad_tv
             else:
-                err = err ** 2
-            tv += err.mean() * smooth_grad_tv
+                tv += (err ** 2).mean() * smooth_grad_tv
         return tv
 
     def k0_total_variation(self, k0_tv=1., k0_grad_tv=0.):

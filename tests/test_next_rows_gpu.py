@@ -99,3 +99,37 @@ def test_training_steps_do_not_leak_device_memory(dev, stage):
     finally:
         gc.enable()
     assert marks[30] - marks[6] < (8 << 20), marks
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_density_total_variation_smooth_term(dev, oracle, masked):
+    """density_total_variation(smooth_grad_tv) of the fine stage (model/nerf.py:430-447; the shipped fine config adds it
+    every third iteration): lazily built gradient volume + HIP 3^3 smoothing + masked mean, value and sdf gradient
+    against the reference expression written out in torch on the CPU."""
+    import torch.nn.functional as F
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.nerf import MaskCache
+    model = synth.build_model(40, synth.FINE_MODEL, device=dev)
+    with torch.no_grad():
+        model.sdf.grid += 0.05 * torch.randn(model.sdf.grid.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    if masked:
+        sdf_mask = ((model.sdf.grid.detach() < 0.25) * 1e-3).float()
+        model.mask_cache = MaskCache(path=None, mask_cache_thres=1e-3 * 0.5, sdf_mask=sdf_mask.cpu(),
+                                     xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1]).to(dev)
+        model._set_nonempty_mask()
+        assert 0.05 < float(model.nonempty_mask.float().mean()) < 0.95
+    rays = tuple(r.to(dev) for r in synth.random_rays(64, seed=2))
+    model(*rays, global_step=10, **synth.RENDER_KWARGS)          # forward_fine marks model.gradient pending (:856)
+    tv = model.density_total_variation(sdf_tv=0, smooth_grad_tv=0.05)
+    model.sdf.grid.grad = None
+    tv.backward()
+    s = model.sdf.grid.detach().cpu().clone().requires_grad_(True)
+    gv = oracle.neus_sdf_gradient(s, model.voxel_size.cpu()).permute(1, 0, 2, 3, 4)
+    sm = F.conv3d(F.pad(gv, (1,) * 6, mode='replicate'), model.tv_smooth_conv.weight.detach().cpu())
+    err = sm.detach() - gv
+    if masked:
+        err = err[model.nonempty_mask.cpu().repeat(3, 1, 1, 1, 1)]
+    ref = (err ** 2).mean() * 0.05
+    ref.backward()
+    assert abs(float(tv) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_l2(model.sdf.grid.grad, s.grad) < 1e-5
