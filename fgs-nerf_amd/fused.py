@@ -267,6 +267,10 @@ class _FusedFine(torch.autograd.Function):
         g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
             c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
 
+        if M == 0:   # no sample survived (every ray missed the volume): all gradients are exactly zero
+            return (None, torch.zeros_like(sdf_grid),
+                    torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_(),
+                    *[torch.zeros_like(t) for t in mlp])
         # 1. compositing
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
@@ -467,6 +471,11 @@ class _FusedCoarse(torch.autograd.Function):
             return None if t is None else t.contiguous()
         g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
             c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
+        if M == 0:   # no kept sample: all gradients are exactly zero
+            return (None, torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev),
+                    torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev),
+                    torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_(),
+                    *[torch.zeros_like(t) for t in mlp])
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
         call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),

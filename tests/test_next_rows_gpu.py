@@ -133,3 +133,41 @@ def test_density_total_variation_smooth_term(dev, oracle, masked):
     ref.backward()
     assert abs(float(tv) - float(ref)) < 1e-5 * abs(float(ref))
     assert rel_l2(model.sdf.grid.grad, s.grad) < 1e-5
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_degenerate_batches(dev, stage, fused):
+    """Edge cases a training run meets: a batch whose rays all miss the volume (no sample survives: every per-sample
+    list is empty, the pixels are background, backward still runs), a single ray, and an eval-mode call (global_step=None)."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    cfg, lossw = (synth.FINE_MODEL, synth.FINE_LOSS) if stage == "fine" else (synth.COARSE_MODEL, synth.COARSE_LOSS)
+    model = synth.build_model(32, cfg, device=dev, fused=None if fused else False)
+    n = 37
+    ro = torch.tensor([[0.0, 0.0, 4.0]], device=dev).repeat(n, 1)
+    rd = torch.tensor([[0.0, 0.0, 1.0]], device=dev).repeat(n, 1)          # looking away from the [-1,1]^3 box
+    vd = rd.clone()
+    target = torch.rand(n, 3, device=dev)
+    res = model(ro, rd, vd, global_step=100, **synth.RENDER_KWARGS)
+    assert res['weights'].numel() == 0 and res['ray_id'].numel() == 0 and res['raw_rgb'].shape == (0, 3)
+    assert torch.allclose(res['rgb_marched'], torch.ones(n, 3, device=dev))          # bg = 1
+    assert torch.allclose(res['alphainv_cum'], torch.ones(n, device=dev))
+    for p in model.parameters():
+        p.grad = None
+    fused_render_losses(res, target, lossw, model).backward()
+    assert float(model.k0.grid.grad.abs().sum()) == 0.0 and float(model.sdf.grid.grad.abs().sum()) == 0.0
+    assert res['mask'] is None or res['mask'].numel() == 0 or not bool(res['mask'].any())
+    # one ray through the centre
+    res1 = model(torch.tensor([[0.0, 0.0, 4.0]], device=dev), torch.tensor([[0.0, 0.0, -1.0]], device=dev),
+                 torch.tensor([[0.0, 0.0, -1.0]], device=dev), global_step=100, **synth.RENDER_KWARGS)
+    assert res1['rgb_marched'].shape == (1, 3) and res1['weights'].numel() > 0
+    assert float(res1['weights'].sum() + res1['alphainv_cum'][0]) <= 1.0 + 1e-5
+    # eval mode: no s_val update, no autograd
+    with torch.no_grad():
+        rays = tuple(r.to(dev) for r in synth.random_rays(200, seed=4))
+        a = model(*rays, global_step=None, **synth.RENDER_KWARGS)
+        b = model(*rays, global_step=None, **synth.RENDER_KWARGS)
+    # the fused compositing is a fixed-order per-ray reduction; the operator form sums with atomics (index_add_)
+    same = torch.equal if fused else (lambda x, y: torch.allclose(x, y, atol=1e-6))
+    assert same(a['rgb_marched'], b['rgb_marched']) and bool(torch.isfinite(a['rgb_marched']).all())
