@@ -292,11 +292,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int
 
 // One workgroup per output tile (EPI_STORE) or per (tile, K slice) (EPI_ATOMIC).
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) LdsImage lds;
-
+__device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &lds) {
   // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
-  const int b = blockIdx.x;
   int tile_m, tile_n;
   int64_t k_begin = 0, k_end = g.K;
   if (EPI == EPI_ATOMIC) {
@@ -321,6 +318,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   acc_zero(acc);
   tile_mainloop<A_KC, B_KC>(g, m0, n0, k_begin, k_end, acc, lds);
   tile_epilogue<EPI>(g, m0, n0, acc, lds);
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) LdsImage lds;
+  gemm_block<A_KC, B_KC, EPI>(g, (int)blockIdx.x, lds);
+}
+
+// Backward of one Linear layer in ONE launch: the data-gradient product (NN, store epilogue with ReLU mask / column sums)
+// and the weight-gradient product (TN, split-K atomics) both depend only on dY.  Launched separately each pays its own
+// launch gap, first-chunk latency and partially filled last round of tiles (780 tiles on 512 slots = 1.52 rounds for the
+// price of 2); launched together the split-K workgroups of the weight gradient, dealt after the data-gradient tiles,
+// fill that round.
+__global__ __launch_bounds__(256, 2) void k_linear_bwd(GemmArgs nn, GemmArgs tn, int nn_blocks) {
+  __shared__ __attribute__((aligned(16))) LdsImage lds;
+  const int b = (int)blockIdx.x;
+  if (b < nn_blocks) gemm_block<true, false, EPI_STORE>(nn, b, lds);
+  else gemm_block<false, false, EPI_ATOMIC>(tn, b - nn_blocks, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -443,6 +458,29 @@ int resident_slots() {  // 2 workgroups of k_gemm_sk per CU (73.7 KB LDS each, <
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// split the long reduction of a weight-gradient product so that ~2 workgroups per CU are in flight; returns the splits
+// (measured on MI355X at M_s = 64 K, 256x256 outputs: 256-512 workgroups 96 us, 128: 159 us, 2048: 147 us)
+unsigned setup_splitk(GemmArgs &g) {
+  const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
+  static const int target_wgs = getenv("FGS_TN_WGS") ? atoi(getenv("FGS_TN_WGS")) : 512;
+  int64_t want = (target_wgs + tiles - 1) / tiles;
+  const int64_t chunks = (g.K + BK - 1) / BK;
+  if (want > chunks) want = chunks;
+  if (want < 1) want = 1;
+  g.k_per_split = ((chunks + want - 1) / want) * BK;
+  return (unsigned)((g.K + g.k_per_split - 1) / g.k_per_split);
+}
+
+GemmArgs make_args(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
+                   int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum) {
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.colsum = colsum; g.k_per_split = 0;
+  g.tiles_m = (int)((M + BM - 1) / BM);
+  g.tiles_n = (int)((N + BN - 1) / BN);
+  return g;
+}
+
 }  // namespace
 
 // Bytes of scratch the stream-K form wants: G partial-tile slots of 64 KB + G flags (the flag words must be ZERO when
@@ -468,11 +506,7 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
   if (op == FGS_GEMM_NN) FGS_REQUIRE(K % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(NN): K and N must be multiples of 4");
   if (op == FGS_GEMM_TN) FGS_REQUIRE(M % 4 == 0 && N % 4 == 0, FGS_E_INVALID, "fgs_gemm_f32(TN): M and N must be multiples of 4");
 
-  GemmArgs g;
-  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-  g.bias = bias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.colsum = colsum; g.k_per_split = 0;
-  g.tiles_m = (int)((M + BM - 1) / BM);
-  g.tiles_n = (int)((N + BN - 1) / BN);
+  GemmArgs g = make_args(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm, colsum);
   hipStream_t st = fgs_s(stream);
   if (op != FGS_GEMM_TN && workspace) {
     // the caller asked for stream-K (by passing a workspace); used when it can balance: more than a handful of tiles,
@@ -499,17 +533,32 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
     case FGS_GEMM_NT: return launch<true, true, EPI_STORE>(g, 1, st);
     case FGS_GEMM_NN: return launch<true, false, EPI_STORE>(g, 1, st);
     default: {
-      // split the long reduction so that ~4 workgroups per CU are in flight (256 CUs)
-      const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
-      // measured on MI355X at M_s = 64 K, 256x256 outputs: 256-512 workgroups 96 us, 128: 159 us, 2048: 147 us
-      static const int target_wgs = getenv("FGS_TN_WGS") ? atoi(getenv("FGS_TN_WGS")) : 512;
-      int64_t want = (target_wgs + tiles - 1) / tiles;
-      const int64_t chunks = (K + BK - 1) / BK;
-      if (want > chunks) want = chunks;
-      if (want < 1) want = 1;
-      g.k_per_split = ((chunks + want - 1) / want) * BK;
-      const unsigned splits = (unsigned)((K + g.k_per_split - 1) / g.k_per_split);
+      const unsigned splits = setup_splitk(g);
       return launch<false, false, EPI_ATOMIC>(g, splits, st);
     }
   }
+}
+
+// Backward of y = x W^T (+ b) for one Linear layer, both products in one launch (k_linear_bwd):
+//   dX[M, K_in]      = (dY[M, N_out] . W[N_out, K_in]) * (mask[M, K_in] > 0)        (+ colsum[K_in] += column sums)
+//   dW[N_out, K_in] += dY^T . X[M, K_in]                                            (fp32 atomics: dW zero-initialised)
+FGS_API int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const float *dY, int64_t lddy, const float *W,
+                               int64_t ldw, const float *X, int64_t ldx, float *dX, int64_t lddx, const float *mask,
+                               int64_t ldm, float *colsum, float *dW, int64_t lddw, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && N_out > 0 && K_in > 0 && M < ((int64_t)1 << 31) && N_out < ((int64_t)1 << 31) && K_in < ((int64_t)1 << 31),
+              FGS_E_RANGE, "fgs_linear_bwd_f32: M=%lld N_out=%lld K_in=%lld", (long long)M, (long long)N_out, (long long)K_in);
+  if (M == 0) return 0;
+  FGS_REQUIRE(dY && W && X && dX && dW, FGS_E_INVALID, "fgs_linear_bwd_f32: null pointer");
+  FGS_REQUIRE(aligned16(dY) && aligned16(W) && aligned16(X) && aligned16(dX) && (!mask || aligned16(mask)) && (lddy % 4) == 0 &&
+                  (ldw % 4) == 0 && (ldx % 4) == 0 && (lddx % 4) == 0 && (!mask || (ldm % 4) == 0) && (N_out % 4) == 0 &&
+                  (K_in % 4) == 0,
+              FGS_E_INVALID, "fgs_linear_bwd_f32: operands must be 16-byte aligned; sizes and leading dimensions multiples of 4");
+  GemmArgs nn = make_args(M, K_in, N_out, dY, lddy, W, ldw, dX, lddx, nullptr, 0, mask, ldm, colsum);
+  GemmArgs tn = make_args(N_out, K_in, M, dY, lddy, X, ldx, dW, lddw, nullptr, 0, nullptr, 0, nullptr);
+  const unsigned splits = setup_splitk(tn);
+  const unsigned nn_blocks = (unsigned)((nn.tiles_m + 7) / 8) * 8 * (unsigned)nn.tiles_n;
+  const unsigned tn_blocks = (unsigned)(tn.tiles_m * tn.tiles_n) * splits;
+  hipLaunchKernelGGL(k_linear_bwd, dim3(nn_blocks + tn_blocks), dim3(256), 0, fgs_s(stream), nn, tn, (int)nn_blocks);
+  FGS_LAUNCH_OK("fgs_linear_bwd_f32");
+  return 0;
 }

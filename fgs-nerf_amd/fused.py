@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -147,6 +148,24 @@ def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
         lm, ln, lk = logical or (M, N, K)
         grp[0] += 1
         grp[1] += 2.0 * lm * ln * lk
+
+
+_LINEAR_BWD_ONE_LAUNCH = os.environ.get("FGS_LINEAR_BWD_SPLIT") != "1"
+
+
+def _linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=None, colsum=None, logical_k_in=None):
+    """Data- and weight-gradient product of one Linear layer: one k_linear_bwd launch (default) or the two k_gemm launches
+    (FGS_LINEAR_BWD_SPLIT=1, for A/B timing).  `logical_k_in`: un-padded input width for the algorithmic FLOP count."""
+    lk = logical_k_in or k_in
+    if not _LINEAR_BWD_ONE_LAUNCH:
+        _gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M, logical=(n_out, lk, M))
+        _gemm(fo.GEMM_NN, dY, W, dX, M, k_in, n_out, mask=mask, colsum=colsum, logical=(M, lk, n_out))
+        return
+    fo.linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=mask, colsum=colsum)
+    grp = PROFILE.get("open")
+    if grp is not None:
+        grp[0] += 1
+        grp[1] += 4.0 * M * n_out * lk
 
 
 class _FusedFine(torch.autograd.Function):
@@ -299,20 +318,18 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_ref[-1]),
              ptr(gb_ref[-1]), ptr(gb_ref[n_ref - 2]), st)
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
-        grp = _gemm_group("backward chain (TN/NN alternating: k_gemm<false,false,1>, k_gemm<true,false,0>)").__enter__()
+        grp = _gemm_group("backward chain (k_linear_bwd: data-grad + weight-grad per layer)").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts_ref[i]                      # input of layer i: Z for i == 0
             if i == 0:
-                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldz, M, logical=(fw, ref_w[0].shape[1], M))
                 dZ = torch.empty(M, ldz, dtype=F32, device=dev)
                 # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
                 # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
-                _gemm(fo.GEMM_NN, dY, S['V0p'], dZ, M, ldz, fw, colsum=cs, logical=(M, ref_w[0].shape[1], fw))
+                _linear_bwd(dY, S['V0p'], a_in, dZ, gV0p, M, fw, ldz, colsum=cs, logical_k_in=ref_w[0].shape[1])
                 gb_rgb[-1] = cs[:rw]
             else:
-                _gemm(fo.GEMM_TN, dY, a_in, gw_ref[i], fw, fw, M)
                 d_in = torch.empty(M, fw, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, ref_w[i], d_in, M, fw, fw, mask=a_in, colsum=gb_ref[i - 1])
+                _linear_bwd(dY, ref_w[i], a_in, d_in, gw_ref[i], M, fw, fw, mask=a_in, colsum=gb_ref[i - 1])
                 dY = d_in
         gw_ref[0] = gV0p[:, :ref_w[0].shape[1]]
         # 4. rgbnet layers n_rgb-1 .. 0 ; dY of the last layer is dZ[:, :rw] (a strided view, ld = ldz)
@@ -320,13 +337,11 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_rgb - 1, -1, -1):
             a_in = acts_rgb[i]                      # X0 for i == 0
             if i == 0:
-                _gemm(fo.GEMM_TN, dY, a_in, gW0p, rw, ldx0, M, logical=(rw, rgb_w[0].shape[1], M))
                 dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, S['W0p'], dX0, M, ldx0, rw, logical=(M, rgb_w[0].shape[1], rw))
+                _linear_bwd(dY, S['W0p'], a_in, dX0, gW0p, M, rw, ldx0, logical_k_in=rgb_w[0].shape[1])
             else:
-                _gemm(fo.GEMM_TN, dY, a_in, gw_rgb[i], rw, rw, M)
                 d_in = torch.empty(M, rw, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, rgb_w[i], d_in, M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
+                _linear_bwd(dY, rgb_w[i], a_in, d_in, gw_rgb[i], M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
                 dY = d_in
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
@@ -494,17 +509,15 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
              ptr(gb[-1]), ptr(gb[n_ref - 2]), st)
         dX0 = None
-        grp = _gemm_group("backward chain (TN/NN alternating: k_gemm<false,false,1>, k_gemm<true,false,0>)").__enter__()
+        grp = _gemm_group("backward chain (k_linear_bwd: data-grad + weight-grad per layer)").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts[i]
             if i == 0:
-                _gemm(fo.GEMM_TN, dY, a_in, gV0p, fw, ldx0, M, logical=(fw, ref_w[0].shape[1], M))
                 dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
+                _linear_bwd(dY, S['V0p'], a_in, dX0, gV0p, M, fw, ldx0, logical_k_in=ref_w[0].shape[1])
             else:
-                _gemm(fo.GEMM_TN, dY, a_in, gw[i], fw, fw, M)
                 d_in = torch.empty(M, fw, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dY, ref_w[i], d_in, M, fw, fw, mask=a_in, colsum=gb[i - 1])
+                _linear_bwd(dY, ref_w[i], a_in, d_in, gw[i], M, fw, fw, mask=a_in, colsum=gb[i - 1])
                 dY = d_in
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()

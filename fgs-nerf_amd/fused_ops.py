@@ -38,3 +38,14 @@ def gemm(op: int, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: 
          int(bool(relu)), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(ws),
          0 if ws is None else ws.numel(), stream())
     return C
+
+
+def linear_bwd(dY: torch.Tensor, W: torch.Tensor, X: torch.Tensor, dX: torch.Tensor, dW: torch.Tensor, M: int, N_out: int,
+               K_in: int, mask=None, colsum=None) -> None:
+    """Backward of a Linear layer in one launch (include/fgs_hip.h fgs_linear_bwd_f32): dX = (dY W) * (mask > 0),
+    colsum += column sums of dX, dW += dY^T X.  All 2-D row-major float32 views; dW must start at zero."""
+    for t in (dY, W, X, dX, dW) + ((mask,) if mask is not None else ()):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+            raise RuntimeError("linear_bwd operands must be 2-D float32 CUDA tensors with unit column stride")
+    call("fgs_linear_bwd_f32", M, N_out, K_in, ptr(dY), dY.stride(0), ptr(W), W.stride(0), ptr(X), X.stride(0), ptr(dX),
+         dX.stride(0), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(dW), dW.stride(0), stream())

@@ -216,6 +216,15 @@ int fgs_sdf_taps_bwd(float *grad_grid, int64_t X, int64_t Y, int64_t Z, const fl
 #define FGS_GEMM_NT 0
 #define FGS_GEMM_NN 1
 #define FGS_GEMM_TN 2
+/* Backward of one Linear layer y = x W^T (+ b) in ONE launch (both products depend only on dY; together the split-K
+ * workgroups of the weight gradient fill the partially occupied last round of data-gradient tiles):
+ *   dX[M, K_in]      = (dY[M, N_out] . W[N_out, K_in]) zeroed where mask[M, K_in] <= 0 (mask may be NULL);
+ *                      colsum[K_in] += column sums of dX (may be NULL)         -- FGS_GEMM_NN semantics
+ *   dW[N_out, K_in] += dY^T . X[M, K_in]  (fp32 atomics: zero-initialise dW)   -- FGS_GEMM_TN semantics
+ * Alignment rules as for fgs_gemm_f32; N_out and K_in multiples of 4. */
+int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const float *dY, int64_t lddy, const float *W, int64_t ldw,
+                       const float *X, int64_t ldx, float *dX, int64_t lddx, const float *mask, int64_t ldm, float *colsum,
+                       float *dW, int64_t lddw, fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,
