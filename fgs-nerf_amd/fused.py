@@ -126,17 +126,21 @@ class _gemm_group:
     def __enter__(self):
         if PROFILE["enabled"]:
             self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            PROFILE["open"] = [0, 0.0]
+            PROFILE["open"] = [0, 0.0, None]     # launches, algorithmic FLOP, side stream used by the chain (or None)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
         if PROFILE["enabled"] and PROFILE.get("open") is not None:
             self.e1.record()
-            n, fl = PROFILE["open"]
+            n, fl, side = PROFILE["open"]
             PROFILE["open"] = None
+            e1s = None
+            if side is not None:                 # the chain also ran launches on a side stream: it ends when both ends do
+                e1s = torch.cuda.Event(enable_timing=True)
+                e1s.record(side)
             if n:
-                PROFILE["gemm_events"].append((self.e0, self.e1, self.label, n, fl))
+                PROFILE["gemm_events"].append((self.e0, self.e1, e1s, self.label, n, fl))
         return False
 
 
@@ -150,22 +154,82 @@ def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
         grp[1] += 2.0 * lm * ln * lk
 
 
-_LINEAR_BWD_ONE_LAUNCH = os.environ.get("FGS_LINEAR_BWD_SPLIT") != "1"
+# How the two products of a Linear layer's backward are issued (FGS_LINEAR_BWD), measured ms/step fine / coarse:
+#   "one"     (default) both products in one k_linear_bwd launch: the split-K weight-gradient workgroups fill the partly
+#             occupied last round of data-gradient tiles                                              2.58 / 1.65
+#   "split"   two k_gemm launches on the main stream                                                  2.63 / 1.60
+#   "overlap" data gradient on the main stream, weight gradient on a side stream as soon as its dY exists: the two
+#             launches of a layer run concurrently (each ~175 us instead of 98 + 89)                  2.55 / 1.62
+#   "late"    weight gradients on the side stream after the whole data-gradient chain, under the atomics-bound scatter
+#             kernels of the feature / march backward                                                 2.61-2.9 / 1.52
+# The differences are within 3 %; "one" is the default because every launch then runs alone and per-kernel durations
+# in a trace mean what they say.
+_LINEAR_BWD_MODE = os.environ.get("FGS_LINEAR_BWD", "one")
+_SIDE = {}   # device index -> (side stream, list of tensors to keep alive until the join)
+
+
+def _side(dev):
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = (torch.cuda.Stream(device=dev), [])
+        _SIDE[dev.index] = st
+    return st
 
 
 def _linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=None, colsum=None, logical_k_in=None):
-    """Data- and weight-gradient product of one Linear layer: one k_linear_bwd launch (default) or the two k_gemm launches
-    (FGS_LINEAR_BWD_SPLIT=1, for A/B timing).  `logical_k_in`: un-padded input width for the algorithmic FLOP count."""
+    """Data- and weight-gradient product of one Linear layer (see _LINEAR_BWD_MODE).  `logical_k_in`: un-padded input
+    width for the algorithmic FLOP count of the roofline report."""
     lk = logical_k_in or k_in
-    if not _LINEAR_BWD_ONE_LAUNCH:
-        _gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M, logical=(n_out, lk, M))
-        _gemm(fo.GEMM_NN, dY, W, dX, M, k_in, n_out, mask=mask, colsum=colsum, logical=(M, lk, n_out))
+    if _LINEAR_BWD_MODE == "one":
+        fo.linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=mask, colsum=colsum)
+        grp = PROFILE.get("open")
+        if grp is not None:
+            grp[0] += 1
+            grp[1] += 4.0 * M * n_out * lk
         return
-    fo.linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=mask, colsum=colsum)
-    grp = PROFILE.get("open")
-    if grp is not None:
-        grp[0] += 1
-        grp[1] += 4.0 * M * n_out * lk
+    if _LINEAR_BWD_MODE == "overlap":
+        side, keep = _side(dY.device)
+        ready = torch.cuda.Event()
+        ready.record()                         # dY (and the zero-filled dW) exist on the main stream from here on
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            fo.gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M)
+        keep.extend((dY, X, dW))
+        grp = PROFILE.get("open")
+        if grp is not None:                      # counted in the chain; the chain's end is the later of the two streams
+            grp[0] += 1
+            grp[1] += 2.0 * n_out * lk * M
+            grp[2] = side
+    elif _LINEAR_BWD_MODE == "late":
+        _side(dY.device)[1].append((dY, X, dW, n_out, k_in, M))   # issued by _flush_tn() after the data-gradient chain
+    else:
+        _gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M, logical=(n_out, lk, M))
+    _gemm(fo.GEMM_NN, dY, W, dX, M, k_in, n_out, mask=mask, colsum=colsum, logical=(M, lk, n_out))
+
+
+def _flush_tn(dev) -> None:
+    """"late" mode: all weight-gradient products on the side stream, started when the data-gradient chain is done, so
+    that they run under the atomics-bound scatter kernels that follow on the main stream."""
+    if _LINEAR_BWD_MODE != "late":
+        return
+    side, jobs = _side(dev)
+    ready = torch.cuda.Event()
+    ready.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        for dY, X, dW, n_out, k_in, M in jobs:
+            fo.gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M)
+
+
+def _join_side(dev) -> None:
+    """Main stream waits for the weight-gradient launches on the side stream (before the gradients are handed back)."""
+    if _LINEAR_BWD_MODE not in ("overlap", "late"):
+        return
+    side, keep = _side(dev)
+    done = torch.cuda.Event()
+    done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    keep.clear()
 
 
 class _FusedFine(torch.autograd.Function):
@@ -318,7 +382,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_ref[-1]),
              ptr(gb_ref[-1]), ptr(gb_ref[n_ref - 2]), st)
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
-        grp = _gemm_group("backward chain (k_linear_bwd: data-grad + weight-grad per layer)").__enter__()
+        grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts_ref[i]                      # input of layer i: Z for i == 0
             if i == 0:
@@ -345,6 +409,7 @@ class _FusedFine(torch.autograd.Function):
                 dY = d_in
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
+        _flush_tn(dev)
 
         # 5. features -> grids
         grad_sdf = torch.zeros_like(sdf_grid)
@@ -367,6 +432,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
              run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
 
+        _join_side(dev)
         grads: List[Optional[torch.Tensor]] = [None, grad_sdf, grad_k0]
         for i in range(n_rgb):
             grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
@@ -509,7 +575,7 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
              ptr(gb[-1]), ptr(gb[n_ref - 2]), st)
         dX0 = None
-        grp = _gemm_group("backward chain (k_linear_bwd: data-grad + weight-grad per layer)").__enter__()
+        grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
         for i in range(n_ref - 2, -1, -1):
             a_in = acts[i]
             if i == 0:
@@ -521,6 +587,7 @@ class _FusedCoarse(torch.autograd.Function):
                 dY = d_in
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
+        _flush_tn(dev)
         grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
@@ -536,6 +603,7 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), st)
         d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
         d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
+        _join_side(dev)
         grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]
         for i in range(n_ref):
             grads += [gw[i].contiguous(), gb[i].contiguous()]
@@ -738,8 +806,10 @@ def roofline_report():
         return None
     per = {}
     tot_ms, tot_fl, tot_n = 0.0, 0.0, 0
-    for e0, e1, label, n, fl in ev:
+    for e0, e1, e1s, label, n, fl in ev:
         ms = e0.elapsed_time(e1)
+        if e1s is not None:
+            ms = max(ms, e0.elapsed_time(e1s))
         d = per.setdefault(label, [0, 0.0, 0.0])
         d[0] += n
         d[1] += ms

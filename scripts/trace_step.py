@@ -1,0 +1,19 @@
+"""Timeline of one training step from a rocprofv3 kernel trace: start offset, duration, stream/queue, kernel.
+
+    python scripts/trace_step.py gpurun_out/prof_x [step_index]
+"""
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"))[-1]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "k_march_fine_fwd" in r["Kernel_Name"] or "k_march_coarse_fwd" in r["Kernel_Name"]]
+seg = rows[starts[which]:starts[which + 1]]
+t0 = int(seg[0]["Start_Timestamp"])
+qk = "Queue_Id" if "Queue_Id" in seg[0] else ("Stream_Id" if "Stream_Id" in seg[0] else None)
+end_prev = t0
+for r in seg:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60]
+    print(f"{s/1e3:9.1f} us  +{(e-s)/1e3:7.1f}  q={r.get(qk, '?') if qk else '?':>3}  {name}")
+print("span %.1f us" % ((int(rows[starts[which + 1]]["Start_Timestamp"]) - t0) / 1e3))
