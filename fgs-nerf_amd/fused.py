@@ -250,6 +250,18 @@ class _FusedFine(torch.autograd.Function):
              ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']), ptr(ws['n_alive']),
              ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        # everything that does not need the survivor count is issued BEFORE the host read, off the post-sync path:
+        # first-layer weights are copied into K-padded operands (their row length is not a multiple of 4)
+        n_rgb, n_ref = run.n_rgb, run.n_ref
+        rgb_w = [mlp[2 * i] for i in range(n_rgb)]
+        rgb_b = [mlp[2 * i + 1] for i in range(n_rgb)]
+        ref_w = [mlp[2 * (n_rgb + i)] for i in range(n_ref)]
+        ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
+        rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
+        ldx0, ldz = run.ldx0, run.ldz
+        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
+        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
+        kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         M = int(ws['surv_off'][N].item())          # the one host read of the step
         run.M = M
         # 2. survivors
@@ -274,15 +286,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_feat_fine_fwd", M, ptr(ray_id), ptr(pts), ptr(sdf), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c,
              g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
              ptr(X0), ptr(Z), ptr(normal), st)
-        # 4. MLPs.  First-layer weights are copied into K-padded operands (their row length is not a multiple of 4).
-        n_rgb, n_ref = run.n_rgb, run.n_ref
-        rgb_w = [mlp[2 * i] for i in range(n_rgb)]
-        rgb_b = [mlp[2 * i + 1] for i in range(n_rgb)]
-        ref_w = [mlp[2 * (n_rgb + i)] for i in range(n_ref)]
-        ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
-        rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
-        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
-        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
+        # 4. MLPs
         grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
         acts_rgb = [X0]                                    # input of each rgbnet layer
         a = X0
@@ -360,27 +364,39 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
              ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
 
-        # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised)
-        # one zero fill for all of them: views of a flat buffer, each 16-byte aligned
-        shapes = ([tuple(w.shape) for w in rgb_w] + [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in rgb_w] +
-                  [(w.shape[0],) for w in ref_w] + [(rw, ldx0), (fw, ldz), (ldz,)])
-        sizes = [(int(np.prod(s)) + 3) // 4 * 4 for s in shapes]
-        flat = torch.zeros(sum(sizes), dtype=F32, device=dev)
-        views, off = [], 0
-        for s, n in zip(shapes, sizes):
-            views.append(flat[off:off + int(np.prod(s))].view(*s))
-            off += n
-        gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
-        gb_rgb = views[n_rgb + n_ref:2 * n_rgb + n_ref]
-        gb_ref = views[2 * n_rgb + n_ref:2 * (n_rgb + n_ref)]
-        gW0p, gV0p, cs = views[-3], views[-2], views[-1]
+        # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised): one zero fill for all of
+        # them, views of a flat buffer, each 16-byte aligned.  The layout is cached; only the three views the head kernel
+        # needs are made before its launch, the rest while it runs (the GPU is idle at the start of a backward pass).
+        lay = run.cache.get('grad_layout')
+        if lay is None:
+            shapes = ([tuple(w.shape) for w in rgb_w] + [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in rgb_w] +
+                      [(w.shape[0],) for w in ref_w] + [(rw, ldx0), (fw, ldz), (ldz,)])
+            items, off = [], 0
+            for sh in shapes:
+                n = int(np.prod(sh))
+                items.append((sh, n, off))
+                off += (n + 3) // 4 * 4
+            lay = run.cache['grad_layout'] = (items, off)
+        items, total = lay
+        flat = torch.zeros(total, dtype=F32, device=dev)
+
+        def view(i):
+            sh, n, off = items[i]
+            return flat[off:off + n].view(sh)
+        i_gw_ref, i_gb_rgb, i_gb_ref = n_rgb, n_rgb + n_ref, 2 * n_rgb + n_ref
 
         # 2. head: d_out -> dY of refnet layer n_ref-2 (masked), dV_last, dc_last, bias grad of layer n_ref-2
         acts_ref, acts_rgb = S['acts_ref'], S['acts_rgb']
         a_last = acts_ref[n_ref - 1]
         dY = torch.empty(M, fw, dtype=F32, device=dev)
-        call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_ref[-1]),
-             ptr(gb_ref[-1]), ptr(gb_ref[n_ref - 2]), st)
+        gw_last, gb_last, gb_prev = view(i_gw_ref + n_ref - 1), view(i_gb_ref + n_ref - 1), view(i_gb_ref + n_ref - 2)
+        call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_last),
+             ptr(gb_last), ptr(gb_prev), st)
+        views = [view(i) for i in range(len(items))]
+        gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
+        gb_rgb = views[i_gb_rgb:i_gb_rgb + n_rgb]
+        gb_ref = views[i_gb_ref:i_gb_ref + n_ref]
+        gW0p, gV0p, cs = views[-3], views[-2], views[-1]
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
         for i in range(n_ref - 2, -1, -1):
@@ -481,6 +497,12 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
              ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        n_ref = run.n_ref                           # issued before the host read: K-padded first-layer weights
+        ref_w = [mlp[2 * i] for i in range(n_ref)]
+        ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
+        fw, ldx0 = ref_w[0].shape[0], run.ldx0
+        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
+        kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         M = int(ws['surv_off'][N].item())          # the one host read of the step
         run.M = M
         ray_id = torch.empty(M, dtype=I64, device=dev)
@@ -501,11 +523,6 @@ class _FusedCoarse(torch.autograd.Function):
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         call("fgs_feat_coarse_fwd", M, ptr(ray_id), ptr(pts), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c, g.X, g.Y,
              g.Z, run.layout_i, ptr(k0_grid), ksC, ksX, ksY, ksZ, ptr(X0), ptr(normal), st)
-        n_ref = run.n_ref
-        ref_w = [mlp[2 * i] for i in range(n_ref)]
-        ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
-        fw = ref_w[0].shape[0]
-        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
         grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
         acts = [X0]
         a = X0
@@ -652,6 +669,7 @@ class LazyResult(dict):
 def _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, default_depth):
     """The per-call scalars both stages share; returns (run, s_val)."""
     run = _Run()
+    run.cache = model.__dict__.setdefault('_fused_cache', {})    # per-model host-side constants (layouts, ...)
     run.geom = _geom(model)
     run.n_rays = N = len(rays_o)
     run.rays_o, run.rays_d = rays_o.contiguous().float(), rays_d.contiguous().float()

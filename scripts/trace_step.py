@@ -11,9 +11,14 @@ starts = [i for i, r in enumerate(rows) if "k_march_fine_fwd" in r["Kernel_Name"
 seg = rows[starts[which]:starts[which + 1]]
 t0 = int(seg[0]["Start_Timestamp"])
 qk = "Queue_Id" if "Queue_Id" in seg[0] else ("Stream_Id" if "Stream_Id" in seg[0] else None)
-end_prev = t0
+end_prev = 0
+idle = 0.0
 for r in seg:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60]
-    print(f"{s/1e3:9.1f} us  +{(e-s)/1e3:7.1f}  q={r.get(qk, '?') if qk else '?':>3}  {name}")
+    gap = (s - end_prev) / 1e3
+    idle += max(gap, 0.0)
+    print(f"{s/1e3:9.1f} us  +{(e-s)/1e3:7.1f}  gap {gap:6.1f}  q={r.get(qk, '?') if qk else '?':>3}  {name}")
+    end_prev = max(end_prev, e)
+print("GPU idle inside the step: %.1f us" % idle)
 print("span %.1f us" % ((int(rows[starts[which + 1]]["Start_Timestamp"]) - t0) / 1e3))
