@@ -1,0 +1,226 @@
+// mlp_fused.hip -- the whole forward chain of the two tiny MLPs (rgbnet 106 -> 256^3 -> 256, refnet 307 -> 256^3,
+// model/nerf.py:125-142,877,884) as ONE persistent kernel.
+//
+// Why: launched layer by layer (fgs_gemm_f32) every product is a short kernel -- K = 256 is 8 chunks of MFMA work per
+// tile -- that pays its own launch gap, first-chunk latency, 64 KB-per-tile epilogue and partially filled last round
+// of tiles (measured: 84 us per layer at M_s = 50 K where the steady-state K loop would need 51).  Here a 512-thread
+// workgroup (8 waves, two per SIMD, one workgroup per CU) owns a block of 64 samples and walks ALL layers with the
+// activation block resident in LDS:
+//   * H [64][324] (83 KB): the current layer's input rows; a layer's output overwrites columns 0..255 in place once its
+//     K loop is done; columns 256..319 hold the reflection encoding the second network appends (refnet input =
+//     [rgbnet output | reflect PE], model/nerf.py:883), loaded once per block;
+//   * the weight chunks stream through a double-buffered [256][36] image (74 KB) with register-staged prefetch two chunks
+//     ahead that runs ACROSS layer boundaries, so the matrix cores never wait for a layer's first operand;
+//   * every layer's output is also written to HBM (coalesced float4 rows) because the backward pass needs it.
+// Per accumulator the k order is exactly fgs_gemm_f32's (chunks ascending, within a chunk the k pairs (s, 16+s) of the
+// first then of the second half), so the results are bit-identical to the layer-by-layer path.
+#include "fgs_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int MB = 64;          // sample rows per block
+constexpr int NW = 256;         // width of every layer
+constexpr int LDH = 324;        // floats per H row: 320 columns + 4 (rows land 4 banks apart: conflict-free ds_read_b128)
+constexpr int LDK = 36;         // floats per staged weight row
+constexpr int BK = 32;
+constexpr int MAXL = 8;
+constexpr int THREADS = 512;
+
+struct MlpLayer {
+  const float *W;      // [NW][ldw], K valid columns
+  const float *bias;   // [NW]
+  float *out;          // [M][ldo] activation as the next layer / the backward sees it
+  int64_t ldw, ldo;
+  int K, relu;
+};
+
+struct MlpArgs {
+  int64_t M;
+  int n_layers;
+  const float *X0; int64_t ldx0; int k0;               // layer-0 input rows -> H[:, 0:k0)
+  const float *T; int64_t ldt; int t_cols;             // appended columns -> H[:, 256:256+t_cols) (NULL: none)
+  MlpLayer L[MAXL];
+};
+
+struct WStage {
+  float4 v[4];
+};
+
+// weight chunk c of layer l: rows n = (tid>>3) + 64 p, k = 32 c + 4 (tid & 7)
+__device__ __forceinline__ void w_load(WStage &s, const MlpLayer &L, int c, int tid) {
+  const int k = c * BK + 4 * (tid & 7);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int n = (tid >> 3) + 64 * p;
+    s.v[p] = (k < L.K) ? *reinterpret_cast<const float4 *>(L.W + (int64_t)n * L.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__device__ __forceinline__ void w_store(const WStage &s, float *__restrict__ wst, int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    *reinterpret_cast<float4 *>(wst + ((tid >> 3) + 64 * p) * LDK + 4 * (tid & 7)) = s.v[p];
+}
+
+// 8 operand values k = 16 h + 8 half .. + 7 of row `row` (pitch ld) starting at column k0
+__device__ __forceinline__ void half8(float (&f)[8], const float *__restrict__ base, int row, int ld, int k0, int h, int half) {
+  const float4 *p = reinterpret_cast<const float4 *>(base + row * ld + k0 + 16 * h + 8 * half);
+  const float4 u = p[0], v = p[1];
+  f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w;
+  f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+}
+
+__global__ __launch_bounds__(THREADS, 1) void k_mlp_fwd(MlpArgs a) {
+  __shared__ __attribute__((aligned(16))) float H[MB * LDH];
+  __shared__ __attribute__((aligned(16))) float Wst[2][NW * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
+  const int arow = wm * 32 + l31;            // this lane's A row inside the block
+  const int bcol0 = wn * 64 + l31;           // this lane's weight rows (= output columns) bcol0, bcol0 + 32
+  const int64_t n_blocks = (a.M + MB - 1) / MB;
+
+  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int64_t m0 = blk * MB;
+    // ---- block inputs -> H (previous block's readers are past the trailing barrier)
+    for (int q = tid; q < MB * 32; q += THREADS) {            // columns 0..127: layer-0 input, zero padded
+      const int row = q >> 5, c4 = q & 31;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + row < a.M && 4 * c4 < a.k0) v = *reinterpret_cast<const float4 *>(a.X0 + (m0 + row) * a.ldx0 + 4 * c4);
+      *reinterpret_cast<float4 *>(H + row * LDH + 4 * c4) = v;
+    }
+    for (int q = tid; q < MB * 16; q += THREADS) {            // columns 256..319: appended encoding, zero padded
+      const int row = q >> 4, c4 = q & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.T && m0 + row < a.M && 4 * c4 < a.t_cols) v = *reinterpret_cast<const float4 *>(a.T + (m0 + row) * a.ldt + 4 * c4);
+      *reinterpret_cast<float4 *>(H + row * LDH + NW + 4 * c4) = v;
+    }
+    // ---- weight stream: chunk (0,0) into the image, chunk +1 into the staging registers
+    WStage sw;
+    w_load(sw, a.L[0], 0, tid);
+    w_store(sw, Wst[0], tid);
+    {
+      const int nch0 = (a.L[0].K + BK - 1) / BK;
+      if (nch0 > 1) w_load(sw, a.L[0], 1, tid);
+      else if (a.n_layers > 1) w_load(sw, a.L[1], 0, tid);
+    }
+    __syncthreads();
+    int buf = 0;
+
+    for (int l = 0; l < a.n_layers; ++l) {
+      const MlpLayer &L = a.L[l];
+      const int nch = (L.K + BK - 1) / BK;
+      const bool more_layers = l + 1 < a.n_layers;
+      const int nch_next = more_layers ? (a.L[l + 1].K + BK - 1) / BK : 0;
+      floatx16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      float f0a[8], f1a[8], f0b[2][8], f1b[2][8];
+      half8(f0a, H, arow, LDH, 0, h, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) half8(f0b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 0);
+
+      for (int c = 0; c < nch; ++c) {
+        // chunk +1 (already in registers) -> the other image; chunk +2 -> registers.  "+1/+2" run across the layer end.
+        const bool has1 = (c + 1 < nch) || more_layers;
+        if (has1) {
+          w_store(sw, Wst[buf ^ 1], tid);
+          if (c + 2 < nch) w_load(sw, L, c + 2, tid);
+          else if (more_layers) {
+            const int c2 = c + 2 - nch;                      // 0 or 1 in the next layer
+            if (c2 < nch_next) w_load(sw, a.L[l + 1], c2, tid);
+            else if (l + 2 < a.n_layers) w_load(sw, a.L[l + 2], 0, tid);   // next layer has a single chunk
+          }
+        }
+        half8(f1a, H, arow, LDH, c * BK, h, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) half8(f1b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[s], f0b[j][s], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 1 < nch) {
+          half8(f0a, H, arow, LDH, (c + 1) * BK, h, 0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) half8(f0b[j], Wst[buf ^ 1], bcol0 + 32 * j, LDK, 0, h, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[s], f1b[j][s], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+      }
+      // ---- layer output: nobody reads H any more in this layer (every wave's last fragments were fetched before the last
+      // barrier), so the tile goes straight back into columns 0..255; bias + ReLU on the way
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = bcol0 + 32 * j;
+        const float b = L.bias ? L.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[j][r] + b;
+          if (L.relu) v = fmaxf(v, 0.f);
+          H[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDH + col] = v;
+        }
+      }
+      __syncthreads();
+      // HBM copy for the backward pass: 64 rows x 1 KB, float4, coalesced
+      for (int q = tid; q < MB * (NW / 4); q += THREADS) {
+        const int row = q >> 6, c4 = q & 63;
+        if (m0 + row < a.M)
+          *reinterpret_cast<float4 *>(L.out + (m0 + row) * L.ldo + 4 * c4) = *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
+      }
+    }
+    __syncthreads();   // H and the weight image are free for the next block
+  }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Forward of a stack of Linear(+ReLU) layers of width 256 over M sample rows in one launch.
+//   layer 0 input  : X0[M, k0]                                   (k0 <= 128, multiple of 4)
+//   layer l input  : output of layer l-1 (256 columns) followed by T[M, t_cols] when K_l > 256   (t_cols <= 64)
+//   outs[l][M, ld] : the activation of layer l (after bias / ReLU), as the backward pass and the next consumer need it.
+// Arrays are HOST arrays of n_layers entries; W[l] is [256, ldw[l]] with K[l] valid columns, bias[l] [256] (may be NULL).
+FGS_API int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int k0, const float *T, int64_t ldt,
+                            int t_cols, const float *const *W, const int64_t *ldw, const int *K, const float *const *bias,
+                            const int *relu, float *const *outs, const int64_t *ldo, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_layers >= 1 && n_layers <= MAXL, FGS_E_RANGE,
+              "fgs_mlp_fwd_f32: M=%lld n_layers=%d (1..%d)", (long long)M, n_layers, MAXL);
+  if (M == 0) return 0;
+  FGS_REQUIRE(X0 && W && ldw && K && bias && relu && outs && ldo, FGS_E_INVALID, "fgs_mlp_fwd_f32: null pointer");
+  FGS_REQUIRE(k0 > 0 && k0 <= 128 && (k0 % 4) == 0 && (ldx0 % 4) == 0 && aligned16(X0) && K[0] == k0, FGS_E_INVALID,
+              "fgs_mlp_fwd_f32: layer-0 input must have k0 = K[0] <= 128 columns, multiple of 4, 16-byte aligned rows");
+  FGS_REQUIRE(t_cols >= 0 && t_cols <= 64 && (t_cols % 4) == 0 && (!T || ((ldt % 4) == 0 && aligned16(T))), FGS_E_INVALID,
+              "fgs_mlp_fwd_f32: appended columns: at most 64, multiple of 4, 16-byte aligned rows");
+  MlpArgs a;
+  a.M = M; a.n_layers = n_layers; a.X0 = X0; a.ldx0 = ldx0; a.k0 = k0; a.T = T; a.ldt = ldt; a.t_cols = t_cols;
+  for (int l = 0; l < n_layers; ++l) {
+    FGS_REQUIRE(W[l] && outs[l] && aligned16(W[l]) && aligned16(outs[l]) && (ldw[l] % 4) == 0 && (ldo[l] % 4) == 0 &&
+                    ldo[l] >= NW && (!bias[l] || aligned16(bias[l])),
+                FGS_E_INVALID, "fgs_mlp_fwd_f32: layer %d: bad pointer / alignment / leading dimension", l);
+    FGS_REQUIRE(K[l] > 0 && (K[l] % 4) == 0 && ldw[l] >= K[l] && (l == 0 || K[l] == NW || (T && K[l] == NW + t_cols)),
+                FGS_E_INVALID, "fgs_mlp_fwd_f32: layer %d: K=%d (expected %d or %d)", l, K[l], NW, NW + t_cols);
+    a.L[l].W = W[l]; a.L[l].bias = bias[l]; a.L[l].out = outs[l]; a.L[l].ldw = ldw[l]; a.L[l].ldo = ldo[l];
+    a.L[l].K = K[l]; a.L[l].relu = relu[l];
+  }
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  const int64_t n_blocks = (M + MB - 1) / MB;
+  const unsigned grid = (unsigned)(n_blocks < cus ? n_blocks : cus);
+  hipLaunchKernelGGL(k_mlp_fwd, dim3(grid), dim3(THREADS), 0, fgs_s(stream), a);
+  FGS_LAUNCH_OK("fgs_mlp_fwd_f32");
+  return 0;
+}

@@ -165,6 +165,8 @@ def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
 # The differences are within 3 %; "one" is the default because every launch then runs alone and per-kernel durations
 # in a trace mean what they say.
 _LINEAR_BWD_MODE = os.environ.get("FGS_LINEAR_BWD", "one")
+# forward chain of the fine stage: one persistent k_mlp_fwd launch (default) or one k_gemm launch per layer (FGS_MLP_FWD=layers)
+_MLP_FWD_ONE_LAUNCH = os.environ.get("FGS_MLP_FWD", "one") == "one"
 _SIDE = {}   # device index -> (side stream, list of tensors to keep alive until the join)
 
 
@@ -287,27 +289,41 @@ class _FusedFine(torch.autograd.Function):
              g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
              ptr(X0), ptr(Z), ptr(normal), st)
         # 4. MLPs
-        grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
-        acts_rgb = [X0]                                    # input of each rgbnet layer
-        a = X0
-        for i in range(n_rgb):
-            last = i == n_rgb - 1
-            out = Z if last else torch.empty(M, rw, dtype=F32, device=dev)   # last layer writes Z[:, :rw] (no ReLU)
-            B = W0p if i == 0 else rgb_w[i].detach()
-            _gemm(fo.GEMM_NT, a, B, out, M, rw, a.shape[1] if i else ldx0, bias=rgb_b[i].detach(), relu=not last,
-                  logical=(M, rw, rgb_w[i].shape[1]))
-            a = out
-            if not last:
-                acts_rgb.append(out)
-        acts_ref = [Z]                                     # input of each refnet layer
-        a = Z
-        for i in range(n_ref - 1):
-            out = torch.empty(M, fw, dtype=F32, device=dev)
-            B = V0p if i == 0 else ref_w[i].detach()
-            _gemm(fo.GEMM_NT, a, B, out, M, fw, ldz if i == 0 else fw, bias=ref_b[i].detach(), relu=True,
-                  logical=(M, fw, ref_w[i].shape[1]))
-            a = out
-            acts_ref.append(out)
+        one_launch = (_MLP_FWD_ONE_LAUNCH and rw == 256 and fw == 256 and ldx0 <= 128 and 0 < ldz - rw <= 64 and
+                      n_rgb + n_ref - 1 <= 8)
+        grp = _gemm_group("forward chain (" + ("k_mlp_fwd: all layers in one launch" if one_launch
+                                               else "NT: k_gemm<true,true,0>") + ")").__enter__()
+        acts_rgb = [X0] + [torch.empty(M, rw, dtype=F32, device=dev) for _ in range(n_rgb - 1)]   # input of each rgbnet layer
+        acts_ref = [Z] + [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]    # input of each refnet layer
+        if one_launch:
+            layers = []
+            for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
+                layers.append((W0p if i == 0 else rgb_w[i].detach(), ldx0 if i == 0 else rw, rgb_b[i].detach(),
+                               i < n_rgb - 1, Z if i == n_rgb - 1 else acts_rgb[i + 1]))
+            for i in range(n_ref - 1):
+                layers.append((V0p if i == 0 else ref_w[i].detach(), ldz if i == 0 else fw, ref_b[i].detach(), True,
+                               acts_ref[i + 1]))
+            fo.mlp_fwd(M, X0, ldx0, Z[:, rw:], ldz - rw, layers)
+            if PROFILE.get("open") is not None:
+                PROFILE["open"][0] += 1
+                PROFILE["open"][1] += 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
+        else:
+            a = X0
+            for i in range(n_rgb):
+                last = i == n_rgb - 1
+                out = Z if last else acts_rgb[i + 1]
+                B = W0p if i == 0 else rgb_w[i].detach()
+                _gemm(fo.GEMM_NT, a, B, out, M, rw, a.shape[1] if i else ldx0, bias=rgb_b[i].detach(), relu=not last,
+                      logical=(M, rw, rgb_w[i].shape[1]))
+                a = out
+            a = Z
+            for i in range(n_ref - 1):
+                out = acts_ref[i + 1]
+                B = V0p if i == 0 else ref_w[i].detach()
+                _gemm(fo.GEMM_NT, a, B, out, M, fw, ldz if i == 0 else fw, bias=ref_b[i].detach(), relu=True,
+                      logical=(M, fw, ref_w[i].shape[1]))
+                a = out
+        a = acts_ref[n_ref - 1]
         grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
         call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)

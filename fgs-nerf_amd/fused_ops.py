@@ -49,3 +49,20 @@ def linear_bwd(dY: torch.Tensor, W: torch.Tensor, X: torch.Tensor, dX: torch.Ten
             raise RuntimeError("linear_bwd operands must be 2-D float32 CUDA tensors with unit column stride")
     call("fgs_linear_bwd_f32", M, N_out, K_in, ptr(dY), dY.stride(0), ptr(W), W.stride(0), ptr(X), X.stride(0), ptr(dX),
          dX.stride(0), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(dW), dW.stride(0), stream())
+
+
+def mlp_fwd(M: int, X0: torch.Tensor, k0: int, T, t_cols: int, layers) -> None:
+    """Whole forward chain of width-256 Linear(+ReLU) layers in one persistent launch (include/fgs_hip.h fgs_mlp_fwd_f32).
+    `layers`: list of (W [256, ldw], K, bias [256] or None, relu, out [M, >=256]); X0 [M, ldx0]; T [M, ldt] view or None."""
+    import ctypes
+    n = len(layers)
+    PtrArr, I64Arr, IntArr = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    W = PtrArr(*[ptr(l[0]) for l in layers])
+    ldw = I64Arr(*[l[0].stride(0) for l in layers])
+    K = IntArr(*[int(l[1]) for l in layers])
+    bias = PtrArr(*[ptr(l[2]) for l in layers])
+    relu = IntArr(*[int(bool(l[3])) for l in layers])
+    outs = PtrArr(*[ptr(l[4]) for l in layers])
+    ldo = I64Arr(*[l[4].stride(0) for l in layers])
+    call("fgs_mlp_fwd_f32", M, n, ptr(X0), X0.stride(0), k0, ptr(T), 0 if T is None else T.stride(0), t_cols, W, ldw, K,
+         bias, relu, outs, ldo, stream())

@@ -225,6 +225,18 @@ int fgs_sdf_taps_bwd(float *grad_grid, int64_t X, int64_t Y, int64_t Z, const fl
 int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const float *dY, int64_t lddy, const float *W, int64_t ldw,
                        const float *X, int64_t ldx, float *dX, int64_t lddx, const float *mask, int64_t ldm, float *colsum,
                        float *dW, int64_t lddw, fgs_stream_t stream);
+/* The whole forward chain of width-256 Linear(+ReLU) layers (rgbnet followed by refnet, model/nerf.py:877-884) in ONE
+ * persistent launch: a 512-thread workgroup per CU owns blocks of 64 sample rows and walks all layers with the activation
+ * block resident in LDS, weight chunks prefetched across layer boundaries; every layer's output is also written to
+ * outs[l] for the backward pass.  Bit-identical to issuing the layers one by one through fgs_gemm_f32 (same k order).
+ *   layer 0 input : X0[M, k0]   (k0 = K[0] <= 128, multiple of 4)
+ *   layer l input : the previous output (256 columns), followed by T[M, t_cols] for a layer with K[l] = 256 + t_cols
+ *                   (t_cols <= 64, multiple of 4; T may be NULL when no layer appends)
+ * W, ldw, K, bias, relu, outs, ldo: HOST arrays of n_layers (<= 8) entries; W[l] is [256, ldw[l]], bias[l] [256] or NULL,
+ * outs[l] [M, ldo[l] >= 256]. */
+int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int k0, const float *T, int64_t ldt, int t_cols,
+                    const float *const *W, const int64_t *ldw, const int *K, const float *const *bias, const int *relu,
+                    float *const *outs, const int64_t *ldo, fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,

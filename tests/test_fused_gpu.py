@@ -228,3 +228,34 @@ def test_gemm_stream_k_matches_fp64(dev, M, K, N):
     ws = fo.gemm_workspace(X.device)
     n_flags = 4 * 2 * torch.cuda.get_device_properties(dev).multi_processor_count
     assert int(ws[-n_flags:].view(torch.int32).abs().sum()) == 0          # every flag consumed and reset
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 1000, 16384, 49920])
+def test_mlp_forward_one_launch_is_bit_identical_to_per_layer(dev, M):
+    """fgs_mlp_fwd_f32 (all seven 256-wide layers of rgbnet + refnet in one persistent launch, activations resident in
+    LDS) against the same layers issued one by one through fgs_gemm_f32: every saved activation bit for bit."""
+    from fgs_nerf_amd import fused_ops as fo
+    torch.manual_seed(M)
+    Ks, relu = [108, 256, 256, 256, 308, 256, 256], [1, 1, 1, 0, 1, 1, 1]
+    X0 = torch.randn(M, 108, device=dev)
+    Z = torch.randn(M, 308, device=dev)
+    Ws = [torch.randn(256, k, device=dev) * 0.05 for k in Ks]
+    bs = [torch.randn(256, device=dev) * 0.1 for _ in Ks]
+    outs = [torch.empty(M, 256, device=dev) for _ in Ks]
+    outs[3] = Z                                                # the last rgbnet layer writes Z[:, :256]
+    a = X0
+    for i in range(7):
+        fo.gemm(fo.GEMM_NT, a, Ws[i], outs[i], M, 256, Ks[i], bias=bs[i], relu=bool(relu[i]))
+        a = outs[i]
+    ref = [o.clone() for o in outs]
+    for o in outs:
+        o[:, :256] = float('nan')
+    Z[:, 256:] = ref[3][:, 256:]
+    fo.mlp_fwd(M, X0, 108, Z[:, 256:], 52, [(Ws[i], Ks[i], bs[i], relu[i], outs[i]) for i in range(7)])
+    for i in range(7):
+        assert torch.equal(outs[i], ref[i]), i
+    x = X0.double()
+    for i in range(4):                                         # and against fp64 for the first network
+        x = x @ Ws[i].double().T + bs[i].double()
+        x = torch.relu(x) if relu[i] else x
+    assert rel_l2(outs[3][:, :256], x) < 1e-5
