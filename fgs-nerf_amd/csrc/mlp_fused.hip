@@ -41,6 +41,7 @@ struct MlpArgs {
   int n_layers;
   const float *X0; int64_t ldx0; int k0;               // layer-0 input rows -> H[:, 0:k0)
   const float *T; int64_t ldt; int t_cols;             // appended columns -> H[:, 256:256+t_cols) (NULL: none)
+  int64_t rows_per_wg;                                 // contiguous rows per workgroup (multiple of 32)
   MlpLayer L[MAXL];
 };
 
@@ -72,114 +73,131 @@ __device__ __forceinline__ void half8(float (&f)[8], const float *__restrict__ b
   f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
 }
 
+// One block of `ROWS` (64 or 32) sample rows through all layers.  TN = MFMA column tiles per wave:
+//   TN = 2: 64 rows, waves 2 (rows) x 4 (columns), a wave owns 32 rows x 64 columns;
+//   TN = 1: 32 rows, waves 1 x 8, a wave owns 32 rows x 32 columns -- the half-size block that ends a workgroup's row range,
+//           so that the ranges can be balanced to 32 rows instead of 64 (M = 49 920 on 256 CUs: 3.5 block-times, not 4).
+template <int TN>
+__device__ __forceinline__ void mlp_block(const MlpArgs &a, int64_t m0, float *__restrict__ H, float (*Wst)[NW * LDK]) {
+  constexpr int ROWS = 32 * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (TN == 2) ? wave >> 2 : 0, h = lane >> 5, l31 = lane & 31;
+  const int arow = wm * 32 + l31;                                      // this lane's A row inside the block
+  const int bcol0 = ((TN == 2) ? (wave & 3) * 64 : wave * 32) + l31;   // this lane's output columns bcol0 (+ 32)
+
+  // ---- block inputs -> H (previous block's readers are past its trailing barrier)
+  for (int q = tid; q < ROWS * 32; q += THREADS) {             // columns 0..127: layer-0 input, zero padded
+    const int row = q >> 5, c4 = q & 31;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + row < a.M && 4 * c4 < a.k0) v = *reinterpret_cast<const float4 *>(a.X0 + (m0 + row) * a.ldx0 + 4 * c4);
+    *reinterpret_cast<float4 *>(H + row * LDH + 4 * c4) = v;
+  }
+  for (int q = tid; q < ROWS * 16; q += THREADS) {             // columns 256..319: appended encoding, zero padded
+    const int row = q >> 4, c4 = q & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.T && m0 + row < a.M && 4 * c4 < a.t_cols) v = *reinterpret_cast<const float4 *>(a.T + (m0 + row) * a.ldt + 4 * c4);
+    *reinterpret_cast<float4 *>(H + row * LDH + NW + 4 * c4) = v;
+  }
+  // ---- weight stream: chunk (0,0) into the image, chunk +1 into the staging registers
+  WStage sw;
+  w_load(sw, a.L[0], 0, tid);
+  w_store(sw, Wst[0], tid);
+  {
+    const int nch0 = (a.L[0].K + BK - 1) / BK;
+    if (nch0 > 1) w_load(sw, a.L[0], 1, tid);
+    else if (a.n_layers > 1) w_load(sw, a.L[1], 0, tid);
+  }
+  __syncthreads();
+  int buf = 0;
+
+  for (int l = 0; l < a.n_layers; ++l) {
+    const MlpLayer &L = a.L[l];
+    const int nch = (L.K + BK - 1) / BK;
+    const bool more_layers = l + 1 < a.n_layers;
+    const int nch_next = more_layers ? (a.L[l + 1].K + BK - 1) / BK : 0;
+    floatx16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float f0a[8], f1a[8], f0b[TN][8], f1b[TN][8];
+    half8(f0a, H, arow, LDH, 0, h, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) half8(f0b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 0);
+
+    for (int c = 0; c < nch; ++c) {
+      // chunk +1 (already in registers) -> the other image; chunk +2 -> registers.  "+1/+2" run across the layer end.
+      const bool has1 = (c + 1 < nch) || more_layers;
+      if (has1) {
+        w_store(sw, Wst[buf ^ 1], tid);
+        if (c + 2 < nch) w_load(sw, L, c + 2, tid);
+        else if (more_layers) {
+          const int c2 = c + 2 - nch;                      // 0 or 1 in the next layer
+          if (c2 < nch_next) w_load(sw, a.L[l + 1], c2, tid);
+          else if (l + 2 < a.n_layers) w_load(sw, a.L[l + 2], 0, tid);   // next layer has a single chunk
+        }
+      }
+      half8(f1a, H, arow, LDH, c * BK, h, 1);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) half8(f1b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[s], f0b[j][s], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (c + 1 < nch) {
+        half8(f0a, H, arow, LDH, (c + 1) * BK, h, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) half8(f0b[j], Wst[buf ^ 1], bcol0 + 32 * j, LDK, 0, h, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[s], f1b[j][s], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf ^= 1;
+    }
+    // ---- layer output: nobody reads H any more in this layer (every wave's last fragments were fetched before the last
+    // barrier), so the tile goes straight back into columns 0..255; bias + ReLU on the way
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = bcol0 + 32 * j;
+      const float b = L.bias ? L.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[j][r] + b;
+        if (L.relu) v = fmaxf(v, 0.f);
+        H[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDH + col] = v;
+      }
+    }
+    __syncthreads();
+    // HBM copy for the backward pass: ROWS x 1 KB, float4, coalesced
+    for (int q = tid; q < ROWS * (NW / 4); q += THREADS) {
+      const int row = q >> 6, c4 = q & 63;
+      if (m0 + row < a.M)
+        *reinterpret_cast<float4 *>(L.out + (m0 + row) * L.ldo + 4 * c4) = *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
+    }
+  }
+  __syncthreads();   // H and the weight image are free for the next block
+}
+
 __global__ __launch_bounds__(THREADS, 1) void k_mlp_fwd(MlpArgs a) {
   __shared__ __attribute__((aligned(16))) float H[MB * LDH];
   __shared__ __attribute__((aligned(16))) float Wst[2][NW * LDK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
-  const int arow = wm * 32 + l31;            // this lane's A row inside the block
-  const int bcol0 = wn * 64 + l31;           // this lane's weight rows (= output columns) bcol0, bcol0 + 32
-  const int64_t n_blocks = (a.M + MB - 1) / MB;
-
-  for (int64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-    const int64_t m0 = blk * MB;
-    // ---- block inputs -> H (previous block's readers are past the trailing barrier)
-    for (int q = tid; q < MB * 32; q += THREADS) {            // columns 0..127: layer-0 input, zero padded
-      const int row = q >> 5, c4 = q & 31;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + row < a.M && 4 * c4 < a.k0) v = *reinterpret_cast<const float4 *>(a.X0 + (m0 + row) * a.ldx0 + 4 * c4);
-      *reinterpret_cast<float4 *>(H + row * LDH + 4 * c4) = v;
+  // contiguous row range per workgroup, a multiple of 32 rows: 64-row blocks, then at most one 32-row block
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_wg;
+  const int64_t r1 = (r0 + a.rows_per_wg < a.M) ? r0 + a.rows_per_wg : a.M;
+  for (int64_t m0 = r0; m0 < r1;) {
+    if (r1 - m0 > 32) {
+      mlp_block<2>(a, m0, H, Wst);
+      m0 += 64;
+    } else {
+      mlp_block<1>(a, m0, H, Wst);
+      m0 += 32;
     }
-    for (int q = tid; q < MB * 16; q += THREADS) {            // columns 256..319: appended encoding, zero padded
-      const int row = q >> 4, c4 = q & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.T && m0 + row < a.M && 4 * c4 < a.t_cols) v = *reinterpret_cast<const float4 *>(a.T + (m0 + row) * a.ldt + 4 * c4);
-      *reinterpret_cast<float4 *>(H + row * LDH + NW + 4 * c4) = v;
-    }
-    // ---- weight stream: chunk (0,0) into the image, chunk +1 into the staging registers
-    WStage sw;
-    w_load(sw, a.L[0], 0, tid);
-    w_store(sw, Wst[0], tid);
-    {
-      const int nch0 = (a.L[0].K + BK - 1) / BK;
-      if (nch0 > 1) w_load(sw, a.L[0], 1, tid);
-      else if (a.n_layers > 1) w_load(sw, a.L[1], 0, tid);
-    }
-    __syncthreads();
-    int buf = 0;
-
-    for (int l = 0; l < a.n_layers; ++l) {
-      const MlpLayer &L = a.L[l];
-      const int nch = (L.K + BK - 1) / BK;
-      const bool more_layers = l + 1 < a.n_layers;
-      const int nch_next = more_layers ? (a.L[l + 1].K + BK - 1) / BK : 0;
-      floatx16 acc[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-      float f0a[8], f1a[8], f0b[2][8], f1b[2][8];
-      half8(f0a, H, arow, LDH, 0, h, 0);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) half8(f0b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 0);
-
-      for (int c = 0; c < nch; ++c) {
-        // chunk +1 (already in registers) -> the other image; chunk +2 -> registers.  "+1/+2" run across the layer end.
-        const bool has1 = (c + 1 < nch) || more_layers;
-        if (has1) {
-          w_store(sw, Wst[buf ^ 1], tid);
-          if (c + 2 < nch) w_load(sw, L, c + 2, tid);
-          else if (more_layers) {
-            const int c2 = c + 2 - nch;                      // 0 or 1 in the next layer
-            if (c2 < nch_next) w_load(sw, a.L[l + 1], c2, tid);
-            else if (l + 2 < a.n_layers) w_load(sw, a.L[l + 2], 0, tid);   // next layer has a single chunk
-          }
-        }
-        half8(f1a, H, arow, LDH, c * BK, h, 1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) half8(f1b[j], Wst[buf], bcol0 + 32 * j, LDK, 0, h, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[s], f0b[j][s], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 1 < nch) {
-          half8(f0a, H, arow, LDH, (c + 1) * BK, h, 0);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) half8(f0b[j], Wst[buf ^ 1], bcol0 + 32 * j, LDK, 0, h, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[s], f1b[j][s], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        buf ^= 1;
-      }
-      // ---- layer output: nobody reads H any more in this layer (every wave's last fragments were fetched before the last
-      // barrier), so the tile goes straight back into columns 0..255; bias + ReLU on the way
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = bcol0 + 32 * j;
-        const float b = L.bias ? L.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[j][r] + b;
-          if (L.relu) v = fmaxf(v, 0.f);
-          H[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDH + col] = v;
-        }
-      }
-      __syncthreads();
-      // HBM copy for the backward pass: 64 rows x 1 KB, float4, coalesced
-      for (int q = tid; q < MB * (NW / 4); q += THREADS) {
-        const int row = q >> 6, c4 = q & 63;
-        if (m0 + row < a.M)
-          *reinterpret_cast<float4 *>(L.out + (m0 + row) * L.ldo + 4 * c4) = *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
-      }
-    }
-    __syncthreads();   // H and the weight image are free for the next block
   }
 }
 
@@ -220,6 +238,7 @@ FGS_API int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ld
     cus = 256;
   const int64_t n_blocks = (M + MB - 1) / MB;
   const unsigned grid = (unsigned)(n_blocks < cus ? n_blocks : cus);
+  a.rows_per_wg = ((M + grid - 1) / grid + 31) / 32 * 32;
   hipLaunchKernelGGL(k_mlp_fwd, dim3(grid), dim3(THREADS), 0, fgs_s(stream), a);
   FGS_LAUNCH_OK("fgs_mlp_fwd_f32");
   return 0;
