@@ -853,28 +853,41 @@ def roofline_report():
         tot_n += n
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = 157.3
-    traffic = _pmc_traffic()
+    traffic = _pmc_traffic(per)
     return _roofline_dict(achieved, peak, traffic, tot_n, tot_ms, tot_fl, per)
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    collected and corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_gemm.json), averaged over the three
-    template instances.  PMC collection needs the profiler, so bench.py reports the committed measurement."""
+def _pmc_traffic(per=None):
+    """HBM bytes per launch of the MLP matrix-core kernels from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+    collected separately and corrected as MI355X_MICROARCH.md prescribes: profiles/r01_pmc_mlp.json for the default launch
+    forms k_mlp_fwd / k_linear_bwd, profiles/r01_pmc_gemm.json for the per-product k_gemm launches), weighted by how often
+    each kernel was launched in this run.  PMC collection needs the profiler, so bench.py reports the committed measurement."""
     import json
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_gemm.json")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     try:
-        ks = json.load(open(path))["kernels"]
-        return round(sum(k["traffic_bytes_per_launch"] for k in ks.values()) / len(ks))
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        mlp = json.load(open(os.path.join(root, "r01_pmc_mlp.json")))["kernels"]
+        gem = json.load(open(os.path.join(root, "r01_pmc_gemm.json")))["kernels"]
+    except (OSError, KeyError, ValueError):
         return None
+    g_avg = sum(k["traffic_bytes_per_launch"] for k in gem.values()) / max(len(gem), 1)
+    tot, n = 0.0, 0
+    for label, (launches, _ms, _fl) in (per or {}).items():
+        if "k_mlp_fwd" in label and "k_mlp_fwd" in mlp:
+            t = mlp["k_mlp_fwd"]["traffic_bytes_per_launch"]
+        elif "(one)" in label and "k_linear_bwd" in mlp:
+            t = mlp["k_linear_bwd"]["traffic_bytes_per_launch"]
+        else:
+            t = g_avg
+        tot += t * launches
+        n += launches
+    return round(tot / n) if n else None
 
 
 def _roofline_dict(achieved, peak, traffic, n_launches, tot_ms, tot_fl, per):
-    return {"bound": "mfma", "kernel": "k_gemm (fp32 v_mfma_f32_32x32x2_f32; rgbnet/refnet forward, data-grad, weight-grad)",
+    return {"bound": "mfma", "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_fwd (rgbnet + refnet forward, "
+                                       "one launch), k_linear_bwd (data + weight gradient of a layer, one launch) / k_gemm",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_gemm.json)",
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_mlp.json / r01_pmc_gemm.json)",
             "launches": n_launches, "avg_launch_us": round(tot_ms * 1e3 / n_launches, 2),
             "algorithmic_gflop_per_launch": round(tot_fl / n_launches / 1e9, 3),
             "timing": "HIP events on the launch stream around each uninterrupted k_gemm chain in the timed region",
