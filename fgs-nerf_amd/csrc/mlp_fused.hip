@@ -109,6 +109,12 @@ __device__ __forceinline__ void mlp_block(const MlpArgs &a, int64_t m0, float *_
   }
   __syncthreads();
   int buf = 0;
+  // The HBM copy of a layer's output (needed by the backward pass) is not issued in one burst after the layer -- written
+  // that way the seven 64-row x 1 KB copies of all workgroups hit HBM at the same moments and cost 56 us of a 586 us launch
+  // (measured by removing them) -- but one 512-float4 slice per K chunk of the NEXT layer, whose K loop only reads H.
+  constexpr int COPY_SLICES = ROWS * (NW / 4) / THREADS;   // 8 (64 rows) or 4 (32 rows); every later layer has >= 8 chunks
+  float *pend_out = nullptr;
+  int64_t pend_ldo = 0;
 
   for (int l = 0; l < a.n_layers; ++l) {
     const MlpLayer &L = a.L[l];
@@ -136,6 +142,12 @@ __device__ __forceinline__ void mlp_block(const MlpArgs &a, int64_t m0, float *_
           if (c2 < nch_next) w_load(sw, a.L[l + 1], c2, tid);
           else if (l + 2 < a.n_layers) w_load(sw, a.L[l + 2], 0, tid);   // next layer has a single chunk
         }
+      }
+      if (pend_out && c < COPY_SLICES) {                   // slice c of the previous layer's output -> HBM
+        const int q = tid + THREADS * c, row = q >> 6, c4 = q & 63;
+        if (m0 + row < a.M)
+          *reinterpret_cast<float4 *>(pend_out + (m0 + row) * pend_ldo + 4 * c4) =
+              *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
       }
       half8(f1a, H, arow, LDH, c * BK, h, 1);
 #pragma unroll
@@ -174,11 +186,17 @@ __device__ __forceinline__ void mlp_block(const MlpArgs &a, int64_t m0, float *_
       }
     }
     __syncthreads();
-    // HBM copy for the backward pass: ROWS x 1 KB, float4, coalesced
-    for (int q = tid; q < ROWS * (NW / 4); q += THREADS) {
-      const int row = q >> 6, c4 = q & 63;
-      if (m0 + row < a.M)
-        *reinterpret_cast<float4 *>(L.out + (m0 + row) * L.ldo + 4 * c4) = *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
+    const int nch_after = more_layers ? nch_next : 0;
+    if (nch_after >= COPY_SLICES) {          // deferred: trickles out under the next layer's K loop
+      pend_out = L.out;
+      pend_ldo = L.ldo;
+    } else {                                 // last layer (or a short next layer): ROWS x 1 KB, float4, coalesced, now
+      pend_out = nullptr;
+      for (int q = tid; q < ROWS * (NW / 4); q += THREADS) {
+        const int row = q >> 6, c4 = q & 63;
+        if (m0 + row < a.M)
+          *reinterpret_cast<float4 *>(L.out + (m0 + row) * L.ldo + 4 * c4) = *reinterpret_cast<const float4 *>(H + row * LDH + 4 * c4);
+      }
     }
   }
   __syncthreads();   // H and the weight image are free for the next block
