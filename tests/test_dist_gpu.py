@@ -86,3 +86,61 @@ def test_hinted_exchange_matches_gradient_occupancy(dev):
             assert 0 < avg.last_sparse_fill < 0.5
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)                       # both ranks share the one GPU of the box
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fgs_nerf_amd import synth
+        from fgs_nerf_amd.dist import GradAverager, shard_rays
+        from fgs_nerf_amd.losses import fused_render_losses
+        model = synth.build_model(64, synth.FINE_MODEL, device=dev)
+        ro, rd, vd = synth.random_rays(2048, seed=8)
+        sl = shard_rays(2048, rank, world)
+        rays = tuple(t[sl].to(dev) for t in (ro, rd, vd))
+        target = torch.rand(2048, 3, generator=torch.Generator().manual_seed(2))[sl].to(dev)
+        avg = GradAverager(model.parameters(), sparse_min_numel=1 << 16)
+        res = model(*rays, global_step=1000, **synth.RENDER_KWARGS)
+        avg.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
+        fused_render_losses(res, target, synth.FINE_LOSS, model).backward()
+        params = [p for p in model.parameters() if p.grad is not None]
+        local = [p.grad.detach().clone() for p in params]
+        avg.average()
+        worst = 0.0
+        for p, g in zip(params, local):                  # dense reference: plain all-reduce of the local copies
+            ref = g.contiguous().cpu()
+            dist.all_reduce(ref)
+            ref = ref / world
+            got = p.grad.detach().cpu()
+            worst = max(worst, float((got - ref).norm() / ref.norm().clamp_min(1e-30)))
+            assert torch.equal(got != 0, ref != 0) or p.grad.dim() != 5     # the union of touched voxels is preserved
+        fill = avg.last_sparse_fill
+        out_q.put((rank, worst, fill))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_a_dense_all_reduce(dev):
+    """Two ranks (gloo, both on the box's single GPU) with different ray shards: the hinted brick-sparse exchange of
+    k0.grad, the dense sdf exchange and the MLP bucket must equal a plain dense all-reduce of the local gradients."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    results = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, worst, fill in results:
+        assert worst < 1e-6, results
+        assert fill is not None and 0 < fill < 0.6, results
