@@ -337,6 +337,12 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
         alphainv_last = ws['alphainv_last'].clone()
+        # The big zero fills of the backward pass are issued HERE: when loss.backward() starts, the autograd engine needs
+        # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
+        run.pre = None
+        if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
+            run.pre = (torch.zeros_like(sdf_grid),
+                       torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
 
         # Tensors this function RETURNS must not be reachable from ctx through plain attributes: output -> grad_fn -> ctx
         # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
@@ -444,8 +450,12 @@ class _FusedFine(torch.autograd.Function):
         _flush_tn(dev)
 
         # 5. features -> grids
-        grad_sdf = torch.zeros_like(sdf_grid)
-        grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+        if run.pre is not None:
+            grad_sdf, grad_k0 = run.pre           # zero-filled at the end of the forward pass
+            run.pre = None
+        else:
+            grad_sdf = torch.zeros_like(sdf_grid)
+            grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
         g_sdf_s = torch.empty(M, dtype=F32, device=dev)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         tot_sdf = torch.empty(M, dtype=F32, device=dev)
@@ -560,6 +570,10 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
         alphainv_last = ws['alphainv_last'].clone()
+        run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
+        if any(ctx.needs_input_grad) and M > 0:
+            run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
+                       torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
                                    V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
@@ -621,15 +635,19 @@ class _FusedCoarse(torch.autograd.Function):
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
-        grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+        if run.pre is not None:
+            d4, grad_k0 = run.pre
+            run.pre = None
+        else:
+            d4 = torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev)
+            grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
         call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
              g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
              ptr(g_grad_s), st)
-        # voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of it
-        # in place through element strides
-        d4 = torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev)
+        # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
+        # it in place through element strides
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['n_alive']), ptr(ws['n_surv']),
