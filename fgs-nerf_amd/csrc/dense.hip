@@ -28,10 +28,24 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // (dx, dy, dz) fmaf chain, the same order the one-thread-per-voxel form used.
 constexpr int CT_X = 8, CT_Y = 8, CT_Z = 32, CT_ZPT = 8;
 
-template <int K, bool REPL>
+// EPI = 1 turns the store into the smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446) for
+// channel blockIdx.y of a [3,X,Y,Z] gradient volume:  err = conv(g).detach() - g,  loss += weight / count * sum(m err^2),
+// out = d loss / d g = -2 weight / count * m * err   (the smoothed volume is detached in the reference).
+struct TvEpi {
+  const uint8_t *mask;      // [X,Y,Z] nonempty mask or null
+  const float *inv_count;   // device scalar 1 / (number of elements in the mean)
+  float weight;
+  float *loss;              // device scalar, accumulated atomically
+};
+
+template <int K, bool REPL, int EPI = 0>
 __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restrict__ in, int nx, int ny, int nz,
                                                             Conv3 c /* X,Y,Z = OUTPUT dims */, int shift, int64_t es,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, TvEpi tv) {
+  if (EPI == 1) {   // one channel per grid row
+    in += (int64_t)blockIdx.y * nx * ny * nz;
+    out += (int64_t)blockIdx.y * nx * ny * nz;
+  }
   constexpr int LX = CT_X + K - 1, LY = CT_Y + K - 1, LZU = CT_Z + K - 1;
   constexpr int LZ = LZU | 1;  // odd row pitch: the 8 (y) x 4 (z-group) lanes of a wave hit distinct banks
   __shared__ float tile[LX * LY * LZ];
@@ -74,12 +88,35 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restr
     }
   }
   const int x = ox0 + tx, y = oy0 + ty, z0 = oz0 + tz * CT_ZPT;
+  if (EPI == 0) {
+    if (x < c.X && y < c.Y) {
+      float *o = out + ((int64_t)x * c.Y + y) * c.Z;
+#pragma unroll
+      for (int j = 0; j < CT_ZPT; ++j)
+        if (z0 + j < c.Z) o[z0 + j] = acc[j];
+    }
+    return;
+  }
+  // smooth-gradient TV: the centre value g sits in the halo tile at offset K/2 on every axis
+  float part = 0.f;
   if (x < c.X && y < c.Y) {
-    float *o = out + ((int64_t)x * c.Y + y) * c.Z;
+    const float ic = *tv.inv_count;
+    const float ds = -2.f * tv.weight * ic;
+    const float *crow = tile + ((tx + K / 2) * LY + (ty + K / 2)) * LZ + tz * CT_ZPT + K / 2;
+    const int64_t base = ((int64_t)x * c.Y + y) * c.Z;
 #pragma unroll
     for (int j = 0; j < CT_ZPT; ++j)
-      if (z0 + j < c.Z) o[z0 + j] = acc[j];
+      if (z0 + j < c.Z) {
+        const float m = (tv.mask && !tv.mask[base + z0 + j]) ? 0.f : 1.f;
+        const float e = acc[j] - crow[j];
+        out[base + z0 + j] = ds * m * e;
+        part = fmaf(m * e, e, part);
+      }
   }
+  // block reduction of the loss contribution: wave shuffle, then one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+  if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(tv.loss, part * tv.weight * *tv.inv_count);
 }
 
 // Fold the adjoint computed on the padded domain [(n + 2r)^3, index p = q + r] back onto the grid:
@@ -108,10 +145,10 @@ void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int sh
   const int64_t tiles = (int64_t)((c.X + CT_X - 1) / CT_X) * ((c.Y + CT_Y - 1) / CT_Y) * ((c.Z + CT_Z - 1) / CT_Z);
   const dim3 grid((unsigned)tiles), block(FGS_BLOCK);
   switch (c.k) {
-    case 1: hipLaunchKernelGGL((k_conv3d_tiled<1, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
-    case 3: hipLaunchKernelGGL((k_conv3d_tiled<3, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
-    case 5: hipLaunchKernelGGL((k_conv3d_tiled<5, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
-    default: hipLaunchKernelGGL((k_conv3d_tiled<7, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out); break;
+    case 1: hipLaunchKernelGGL((k_conv3d_tiled<1, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out, TvEpi{}); break;
+    case 3: hipLaunchKernelGGL((k_conv3d_tiled<3, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out, TvEpi{}); break;
+    case 5: hipLaunchKernelGGL((k_conv3d_tiled<5, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out, TvEpi{}); break;
+    default: hipLaunchKernelGGL((k_conv3d_tiled<7, REPL>), grid, block, 0, st, in, nx, ny, nz, c, shift, es, out, TvEpi{}); break;
   }
 }
 
@@ -206,5 +243,23 @@ FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64
   hipLaunchKernelGGL(k_gradvol_bwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
                      chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
   FGS_LAUNCH_OK("fgs_sdf_gradvol_bwd");
+  return 0;
+}
+
+// Smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446) over a gradient volume g3 [3,X,Y,Z]:
+//   loss_accum += weight * mean_masked((conv3(g).detach() - g)^2),   d_g3 = d loss / d g3   (fully written)
+// taps_host: the 27 taps of tv_smooth_conv (replicate padding); mask [X,Y,Z] uint8 or NULL; inv_count_dev = 1 / (number
+// of elements the mean runs over: 3 * mask.sum(), or 3 X Y Z), a DEVICE scalar so that no host read is needed.
+FGS_API int fgs_smooth_tv_loss(const float *g3, int X, int Y, int Z, const float *taps_host, const uint8_t *mask,
+                               const float *inv_count_dev, float weight, float *loss_accum, float *d_g3,
+                               fgs_stream_t stream) {
+  Conv3 c;
+  if (int e = make_conv("fgs_smooth_tv_loss", X, Y, Z, 3, taps_host, &c)) return e;
+  FGS_REQUIRE(g3 && inv_count_dev && loss_accum && d_g3 && g3 != d_g3, FGS_E_INVALID, "fgs_smooth_tv_loss: null or aliased pointers");
+  const int64_t tiles = (int64_t)((X + CT_X - 1) / CT_X) * ((Y + CT_Y - 1) / CT_Y) * ((Z + CT_Z - 1) / CT_Z);
+  TvEpi tv{mask, inv_count_dev, weight, loss_accum};
+  hipLaunchKernelGGL((k_conv3d_tiled<3, true, 1>), dim3((unsigned)tiles, 3), dim3(FGS_BLOCK), 0, fgs_s(stream), g3, X, Y, Z, c,
+                     1, (int64_t)1, d_g3, tv);
+  FGS_LAUNCH_OK("fgs_smooth_tv_loss");
   return 0;
 }

@@ -90,3 +90,31 @@ class _GradVol(torch.autograd.Function):
 
 def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float) -> torch.Tensor:
     return _GradVol.apply(grid, float(voxel_size))
+
+
+class _SmoothTV(torch.autograd.Function):
+    """weight * mean_masked((tv_smooth_conv(g).detach() - g)^2) over a [1,3,X,Y,Z] gradient volume: value and d/dg in one
+    HIP pass per channel (include/fgs_hip.h fgs_smooth_tv_loss)."""
+
+    @staticmethod
+    def forward(ctx, grad3, taps_c, mask_u8, inv_count, weight):
+        if not (grad3.is_cuda and grad3.dtype == torch.float32 and grad3.dim() == 5 and grad3.shape[:2] == (1, 3)):
+            raise RuntimeError("expected a float32 CUDA gradient volume of shape [1,3,X,Y,Z]")
+        g = grad3.contiguous()
+        X, Y, Z = (int(v) for v in g.shape[2:])
+        loss = torch.zeros((), dtype=torch.float32, device=g.device)
+        d_g = torch.empty_like(g)
+        call("fgs_smooth_tv_loss", ptr(g), X, Y, Z, taps_c, ptr(mask_u8), ptr(inv_count), float(weight), ptr(loss), ptr(d_g),
+             stream())
+        ctx.save_for_backward(d_g)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        (d_g,) = ctx.saved_tensors
+        return d_g * g_loss, None, None, None, None
+
+
+def smooth_tv_loss(grad3: torch.Tensor, taps_c, mask_u8, inv_count: torch.Tensor, weight: float) -> torch.Tensor:
+    return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight))

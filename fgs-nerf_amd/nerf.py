@@ -340,31 +340,30 @@ class nerf(torch.nn.Module):
         if smooth_grad_tv > 0:
             grad = self.gradient                                     # [1,3,X,Y,Z]
             if grad.is_cuda and grad.is_contiguous():
-                # tv_smooth_conv(g).detach(): the detached 3^3 binomial smoothing of each component, HIP stencil
+                # value and gradient of the term in one LDS-tiled HIP pass per component (csrc/dense.hip); the element
+                # count of the (masked) mean is a cached DEVICE scalar, so nothing here reads back to the host
                 from . import dense
                 w = self.tv_smooth_conv.weight
                 taps = self.__dict__.get('_tv_taps_c')
                 if taps is None or taps[0] is not w:                 # host copy of the frozen taps, made once
                     taps = (w, dense._taps_c(w))
                     self.__dict__['_tv_taps_c'] = taps
-                with torch.no_grad():
-                    gd = grad.detach()
-                    sm = torch.cat([dense.smooth3d(gd[:, c:c + 1], w, taps[1]) for c in range(3)], dim=1)
-                err = (sm - grad).permute(1, 0, 2, 3, 4)
+                m = self.nonempty_mask
+                cnt = self.__dict__.get('_nonempty_count')
+                if cnt is None or cnt[0] is not m or cnt[2] != tuple(grad.shape):
+                    n = (3.0 * m.sum().to(torch.float32)) if m is not None else torch.tensor(float(grad.numel()), device=grad.device)
+                    mask_u8 = None if m is None else m.reshape(m.shape[-3:]).contiguous().view(torch.uint8)
+                    cnt = (m, (1.0 / n).reshape(1).contiguous(), tuple(grad.shape), mask_u8)
+                    self.__dict__['_nonempty_count'] = cnt
+                tv += dense.smooth_tv_loss(grad, taps[1], cnt[3], cnt[1], smooth_grad_tv)
             else:
                 g = grad.permute(1, 0, 2, 3, 4)
                 err = self.tv_smooth_conv(g).detach() - g
-            if self.nonempty_mask is not None:
-                # mean over the masked elements, written as a masked sum / count: the reference's boolean index
-                # (`err[mask.repeat(3,...)] ** 2).mean()`) is a nonzero() host sync plus a gather of the 3 volumes
-                m = self.nonempty_mask
-                cnt = self.__dict__.get('_nonempty_count')
-                if cnt is None or cnt[0] is not m:
-                    cnt = (m, 3.0 * m.sum().to(torch.float32))
-                    self.__dict__['_nonempty_count'] = cnt
-                tv += ((err ** 2) * m.to(err.dtype)).sum() / cnt[1] * smooth_grad_tv
-            else:
-                tv += (err ** 2).mean() * smooth_grad_tv
+                if self.nonempty_mask is not None:
+                    err = err[self.nonempty_mask.repeat(3, 1, 1, 1, 1)] ** 2
+                else:
+                    err = err ** 2
+                tv += err.mean() * smooth_grad_tv
         return tv
 
     def k0_total_variation(self, k0_tv=1., k0_grad_tv=0.):

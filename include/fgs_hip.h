@@ -364,6 +364,14 @@ int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size,
 int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
                         float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream);
 
+/* Smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446; the shipped fine config adds it every
+ * third iteration) over the gradient volume g3 [3,X,Y,Z], value and gradient in one LDS-tiled pass per channel:
+ *   *loss_accum += weight * mean_masked((tv_smooth_conv(g3).detach() - g3)^2),    d_g3 = d(that term) / d g3.
+ * taps_host: the 27 taps of tv_smooth_conv (HOST, replicate padding); mask [X,Y,Z] uint8 (nonempty_mask) or NULL;
+ * inv_count_dev: DEVICE scalar 1 / (elements in the mean) -- 3 * mask.sum() or 3 X Y Z -- so no host read is needed. */
+int fgs_smooth_tv_loss(const float *g3, int X, int Y, int Z, const float *taps_host, const uint8_t *mask,
+                       const float *inv_count_dev, float weight, float *loss_accum, float *d_g3, fgs_stream_t stream);
+
 /* Fused front half of forward_coarse (model/nerf.py:946-990), one wavefront per ray: sample_pts_on_rays, optional mask
  * cache (stage 'coarse' only, :952-959) and voxel-increment MaskGrid (:962-967; inc_world uint8 [iX,iY,iZ] with the
  * MaskGrid's xyz2ijk scale / shift on the host, NULL = none), trilinear lookups of the smoothed SDF grid [X,Y,Z] and of
