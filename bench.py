@@ -135,6 +135,7 @@ def main():
                               fused=False if args.composed else None)
     opt = make_optimizer(model)
     averager = GradAverager(model.parameters(), force=force_dist)
+    averager.attach(model)          # gradients are handed to the exchange from inside the backward pass (N > 1)
     n_global = RAYS_PER_GPU * world
 
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)

@@ -80,27 +80,34 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_brick_flags_pts(const float *__re
 
 // Ordered compaction of the set flags into idx[0..count) on the device (one workgroup; the brick count of a 320^3 grid
 // is 512 K).  No host involvement: the count is fetched asynchronously by whoever sizes the exchange buffer.
+// Tiles of 1024 flags, coalesced loads: rank inside a wave by ballot / popcount, wave offsets through 16 LDS words, the
+// running base carried in a register -- 63 short iterations for 160^3 (the first version, a per-thread sequential scan of
+// 63 strided flags plus a 1024-wide Hillis-Steele scan, took 92 us).
 constexpr int COMPACT_THREADS = 1024;
 __global__ __launch_bounds__(COMPACT_THREADS) void k_brick_compact(const int *__restrict__ flags, int64_t total,
                                                                    int64_t *__restrict__ idx, int64_t *__restrict__ count) {
-  __shared__ int64_t part[COMPACT_THREADS];
-  const int t = threadIdx.x;
-  const int64_t per = (total + COMPACT_THREADS - 1) / COMPACT_THREADS;
-  const int64_t lo = t * per, hi = (lo + per < total) ? lo + per : total;
-  int64_t c = 0;
-  for (int64_t i = lo; i < hi; ++i) c += flags[i] != 0;
-  part[t] = c;
-  __syncthreads();
-  for (int off = 1; off < COMPACT_THREADS; off <<= 1) {   // Hillis-Steele inclusive scan
-    const int64_t v = (t >= off) ? part[t - off] : 0;
+  __shared__ int wave_cnt[COMPACT_THREADS / FGS_WAVE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int64_t base = 0;
+  for (int64_t tile0 = 0; tile0 < total; tile0 += COMPACT_THREADS) {
+    const int64_t i = tile0 + t;
+    const bool f = i < total && flags[i] != 0;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
     __syncthreads();
-    part[t] += v;
-    __syncthreads();
+    int woff = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < COMPACT_THREADS / FGS_WAVE; ++w) {
+      const int c = wave_cnt[w];
+      woff += (w < wave) ? c : 0;
+      tile_total += c;
+    }
+    if (f) idx[base + woff + __popcll(bal & lt_mask)] = i;
+    base += tile_total;
+    __syncthreads();   // wave_cnt is rewritten by the next tile
   }
-  int64_t w = part[t] - c;
-  for (int64_t i = lo; i < hi; ++i)
-    if (flags[i] != 0) idx[w++] = i;
-  if (t == COMPACT_THREADS - 1) *count = part[t];
+  if (t == 0) *count = base;
 }
 
 int make_grid(const char *who, int C, int X, int Y, int Z, BrickGrid *g) {

@@ -180,6 +180,50 @@ class GradAverager:
         bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
         return True
 
+    def attach(self, model) -> None:
+        """Let the fused backward pass of `model` (fused.py) hand gradients over as soon as they are final (see `early`)."""
+        if self.world_size > 1 or self.force:
+            model.__dict__.setdefault('_fused_cache', {})['grad_hook'] = self.early
+
+    # ------------------------------------------------------------------------------------------------ early exchange
+    def early(self, kind: str, params, tensor: Optional[torch.Tensor] = None) -> None:
+        """Called from INSIDE the fused backward pass (fused.py) as soon as a group of gradients is final, so that its
+        exchange runs on a side stream under the kernels the backward pass still has to launch:
+          early('k0',  [k0 param],  grad)  after the feature-grid scatter; ~175 us of sdf scatter kernels follow;
+          early('mlp', mlp params,  flat)  after the MLP chain; `flat` is the one buffer all MLP gradients are views of,
+                                           so a single in-place all-reduce replaces the bucket pack / unpack;
+          early('join', ...)               before the backward pass copies anything out of `flat`.
+        `average()` then skips these parameters and only makes the main stream wait for the side stream."""
+        if (self.world_size == 1 and not self.force) or tensor is None and kind != 'join':
+            return
+        inv = 1.0 / self.world_size
+        st = self.__dict__.setdefault('_early', dict(stream=None, done=None, params=set()))
+        if kind == 'join':
+            if st['done'] is not None:
+                torch.cuda.current_stream().wait_event(st['done'])
+            return
+        if not tensor.is_cuda:
+            return
+        if st['stream'] is None:
+            st['stream'] = torch.cuda.Stream(device=tensor.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.no_grad(), torch.cuda.stream(st['stream']):
+            st['stream'].wait_event(ready)
+            if kind == 'k0':
+                g = tensor
+                ok = (g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1 and self._sparse(g, inv, params[0]))
+                if not ok:
+                    _, flat = self._dense(g, async_op=False)
+                    self._post_scale(flat, inv)
+            else:
+                dist.all_reduce(tensor, op=self._op(), group=self.group)
+                self._post_scale(tensor, inv)
+            st['done'] = torch.cuda.Event()
+            st['done'].record()
+        tensor.record_stream(st['stream'])
+        st['params'].update(id(p) for p in params)
+
     # ------------------------------------------------------------------------------------------------ driver
     @torch.no_grad()
     def average(self) -> None:
@@ -188,9 +232,15 @@ class GradAverager:
         inv = 1.0 / self.world_size
         handles, small, sparse_later = [], [], []
         owner = {}
+        early = self.__dict__.get('_early')
+        skip = set()
+        if early is not None and early['params']:
+            skip, early['params'] = early['params'], set()
+            if early['done'] is not None:
+                torch.cuda.current_stream().wait_event(early['done'])
         for p in self.params:
             g = p.grad
-            if g is None:
+            if g is None or id(p) in skip:
                 continue
             if g.numel() >= self.big_numel:
                 if not (g.is_contiguous() or (g.dim() == 5 and g.is_contiguous(memory_format=torch.channels_last_3d))):

@@ -448,6 +448,9 @@ class _FusedFine(torch.autograd.Function):
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
+        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split") else None   # dist.GradAverager.early
+        if hook is not None:
+            hook('mlp', mlp, flat)               # every MLP gradient is a view of `flat`, final from here on
 
         # 5. features -> grids
         if run.pre is not None:
@@ -464,6 +467,8 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
              g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
              ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
+        if hook is not None:
+            hook('k0', [k0_grid], grad_k0)       # final: its exchange runs under the sdf scatter kernels below
         # 6. march backward
         call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
@@ -475,6 +480,8 @@ class _FusedFine(torch.autograd.Function):
              run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
 
         _join_side(dev)
+        if hook is not None:
+            hook('join', None)
         grads: List[Optional[torch.Tensor]] = [None, grad_sdf, grad_k0]
         for i in range(n_rgb):
             grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
@@ -635,6 +642,9 @@ class _FusedCoarse(torch.autograd.Function):
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
+        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split") else None   # dist.GradAverager.early
+        if hook is not None:
+            hook('mlp', mlp, flat)
         if run.pre is not None:
             d4, grad_k0 = run.pre
             run.pre = None
@@ -646,6 +656,8 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
              g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
              ptr(g_grad_s), st)
+        if hook is not None:
+            hook('k0', [k0_grid], grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
         # it in place through element strides
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
@@ -655,6 +667,8 @@ class _FusedCoarse(torch.autograd.Function):
         d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
         d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
         _join_side(dev)
+        if hook is not None:
+            hook('join', None)
         grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]
         for i in range(n_ref):
             grads += [gw[i].contiguous(), gb[i].contiguous()]

@@ -123,6 +123,8 @@ class TrainStepper:
         self.rgb_tr, self.rays_o_tr, self.rays_d_tr, self.viewdirs_tr = rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr
         self.optimizer = optimizer or create_optimizer_or_freeze_model(model, self.cfg_train, global_step=0)
         self.averager = averager
+        if averager is not None:
+            averager.attach(model)
         self.poses_train, self.near = poses_train, near
         if self.cfg_train.get('ray_sampler', 'flatten') not in ('flatten', 'in_maskcache', 'random'):
             raise NotImplementedError(self.cfg_train.ray_sampler)

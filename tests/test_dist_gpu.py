@@ -104,12 +104,17 @@ def _two_rank_worker(rank, world, port, out_q):
         sl = shard_rays(2048, rank, world)
         rays = tuple(t[sl].to(dev) for t in (ro, rd, vd))
         target = torch.rand(2048, 3, generator=torch.Generator().manual_seed(2))[sl].to(dev)
+        # reference: the local gradients of this rank, from an identical model with no exchange attached
+        twin = synth.build_model(64, synth.FINE_MODEL, device=dev)
+        fused_render_losses(twin(*rays, global_step=1000, **synth.RENDER_KWARGS), target, synth.FINE_LOSS, twin).backward()
         avg = GradAverager(model.parameters(), sparse_min_numel=1 << 16)
+        avg.attach(model)                                # k0 and the MLP gradients are exchanged from inside the backward pass
         res = model(*rays, global_step=1000, **synth.RENDER_KWARGS)
         avg.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
         fused_render_losses(res, target, synth.FINE_LOSS, model).backward()
         params = [p for p in model.parameters() if p.grad is not None]
-        local = [p.grad.detach().clone() for p in params]
+        local = [p.grad.detach().clone() for p in twin.parameters() if p.grad is not None]
+        assert len(local) == len(params)
         avg.average()
         worst = 0.0
         for p, g in zip(params, local):                  # dense reference: plain all-reduce of the local copies
