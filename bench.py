@@ -30,6 +30,7 @@ GRID = 160
 RAYS_PER_GPU = 4096
 N_BATCHES = 8          # distinct ray batches cycled through, so consecutive steps touch different voxels
 GLOBAL_STEP = 1000
+STEP_STATS = {"survivors": 0}   # survivors (samples that reach the MLPs) summed over the timed steps of this rank
 
 
 def make_optimizer(model):
@@ -59,6 +60,7 @@ def train_step(model, opt, averager, batch, n_rays_global):
     # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)
     model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)
     opt.step()
+    STEP_STATS["survivors"] += int(res['weights'].shape[0])     # a host number already (the forward read it)
     return loss
 
 
@@ -92,7 +94,14 @@ def cpu_baseline(n_rays=1024, iters=3):
             times.append(time.perf_counter() - t0)
         n_in = res['n_inbbox']
     med = sorted(times)[len(times) // 2]
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": round(n_in / med / 1e6, 4), "unit": "M ray-samples/s", "cores": torch.get_num_threads(),
+            "cpu_model": cpu_model,
             "kind": "port", "sample": f"{n_rays} rays x {iters} fwd+bwd iterations of the same 160^3 workload "
                                       f"({n_in} in-bbox samples/iter, median {med * 1e3:.0f} ms), torch CPU + C oracle"}
 
@@ -139,7 +148,7 @@ def main():
     n_global = RAYS_PER_GPU * world
 
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)
-    batches, n_inbbox = [], []
+    batches, n_inbbox, n_total = [], [], []
     for b in range(N_BATCHES):
         ro, rd, vd = synth.random_rays(RAYS_PER_GPU, seed=synth.SEED + 97 * b + 10007 * rank)
         target = torch.rand(RAYS_PER_GPU, 3, generator=torch.Generator().manual_seed(b + 1000 * rank))
@@ -147,6 +156,7 @@ def main():
         out = render_utils_cuda.sample_pts_on_rays(batch[0], batch[1], model.xyz_min, model.xyz_max, 2.0, 1e9,
                                                    float(0.5 * model.voxel_size))
         n_inbbox.append(int((~out[1]).sum().item()))
+        n_total.append(int(out[1].numel()))
         batches.append(batch)
     del out
 
@@ -161,6 +171,7 @@ def main():
     from fgs_nerf_amd import fused
     fused.PROFILE["gemm_events"].clear()
     fused.PROFILE["enabled"] = (rank == 0) and not args.composed
+    STEP_STATS["survivors"] = 0
     t0 = time.perf_counter()
     samples = 0
     for i in range(args.steps):
@@ -193,9 +204,24 @@ def main():
                        ("configs[2] path at the bench size: 160^3 coarse-stage training step (5^3 smoothing + gradient "
                         "volume + forward_coarse + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step"),
                        "grid": GRID, "rays_per_gpu": RAYS_PER_GPU, "inbbox_samples_per_step_per_gpu": int(sum(n_inbbox) / len(n_inbbox)),
+                       "emitted_samples_per_step_per_gpu": int(sum(n_total) / len(n_total)),
+                       "mlp_survivors_per_step_per_gpu": int(STEP_STATS["survivors"] / max(args.steps, 1)),
                        "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
         }
         line["roofline"] = fused.roofline_report()
+        if line["roofline"] is not None and args.stage == "fine":
+            # the path is NOT HBM-bound -- both HBM fractions, for the record (the claimed bound is "mfma" above).
+            # sampled path: 688 + 3456 rho algorithmic bytes per in-bbox sample; whole step adds the dense per-step streams
+            # (sdf TV 3*4*G^3, dense Adam on sdf 7*4*G^3, masked Adam on k0 <= 7*4*12*G^3, zero fill of both gradients)
+            n_in = sum(n_inbbox) / len(n_inbbox)
+            rho = STEP_STATS["survivors"] / max(args.steps, 1) / n_in
+            step_s = elapsed / args.steps
+            sampled = (688.0 + 3456.0 * rho) * n_in
+            dense = (3 * 4 + 7 * 4 + 7 * 4 * 12 + 4 * 13) * float(GRID) ** 3
+            line["roofline"]["hbm_fraction_for_reference"] = {
+                "rho_survivors_per_inbbox_sample": round(rho, 4),
+                "sampled_path": round(sampled / step_s / 8e12, 4), "whole_step": round((sampled + dense) / step_s / 8e12, 4),
+                "note": "algorithmic bytes / step time / 8 TB/s; the step is bound by fp32 matrix throughput and atomics"}
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine") else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
