@@ -13,7 +13,6 @@ from types import SimpleNamespace
 
 import torch
 
-from . import _lib
 from ._lib import call, check_input, ptr, stream
 
 F32, I64, BOOL = torch.float32, torch.int64, torch.bool
