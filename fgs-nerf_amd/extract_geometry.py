@@ -1,31 +1,39 @@
 """SDF field extraction for mesh export (reference ``model/extract_geometry.py``).
 
 ``extract_fields`` evaluates ``query_func`` (for the SDF model: the trilinear lookup of ``-sdf``, model/nerf.py:1163) on a
-``resolution``^3 lattice in 64^3 blocks, exactly as model/extract_geometry.py:5-19 does; the lookups run on the HIP
-trilerp kernel.  ``extract_geometry`` hands the volume to PyMCubes' marching cubes (third-party, CPU) when that package
-is installed; it is not part of this image, so only the field half is exercised by the tests.
+``resolution``^3 lattice spanning the bounding box.  Same values and the same query granularity as the reference (at most
+``N``^3 points per ``query_func`` call, model/extract_geometry.py:5-19), organised for the device: the lattice lives on
+the accelerator, every block's result lands in one resident volume, and a single device->host copy ends the function
+(the reference copies each block back as it goes).  ``extract_geometry`` hands the volume to PyMCubes' marching cubes
+(third-party, CPU) when that package is installed; it is not part of this image, so only the field half is exercised by
+the tests.
 """
 from __future__ import annotations
+
+import itertools
 
 import numpy as np
 import torch
 
 
+def _axis(lo, hi, resolution, device):
+    return torch.linspace(float(lo), float(hi), resolution, device=device)
+
+
 def extract_fields(bound_min, bound_max, resolution, query_func, N=64):
-    dev = bound_min.device if isinstance(bound_min, torch.Tensor) else 'cpu'
-    X = torch.linspace(float(bound_min[0]), float(bound_max[0]), resolution, device=dev).split(N)
-    Y = torch.linspace(float(bound_min[1]), float(bound_max[1]), resolution, device=dev).split(N)
-    Z = torch.linspace(float(bound_min[2]), float(bound_max[2]), resolution, device=dev).split(N)
-    u = np.zeros([resolution, resolution, resolution], dtype=np.float32)
+    """float32 numpy volume [resolution]^3 of ``query_func`` over the lattice; ``query_func`` sees [n,3] points, n <= N^3."""
+    device = bound_min.device if isinstance(bound_min, torch.Tensor) else torch.device('cpu')
+    axes = [_axis(bound_min[a], bound_max[a], resolution, device) for a in range(3)]
+    starts = range(0, resolution, N)
+    field = torch.empty(resolution, resolution, resolution, dtype=torch.float32, device=device)
     with torch.no_grad():
-        for xi, xs in enumerate(X):
-            for yi, ys in enumerate(Y):
-                for zi, zs in enumerate(Z):
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing='ij')
-                    pts = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    val = query_func(pts).reshape(len(xs), len(ys), len(zs)).detach().cpu().numpy()
-                    u[xi * N: xi * N + len(xs), yi * N: yi * N + len(ys), zi * N: zi * N + len(zs)] = val
-    return u
+        for i0, j0, k0 in itertools.product(starts, starts, starts):
+            sub = [axes[0][i0:i0 + N], axes[1][j0:j0 + N], axes[2][k0:k0 + N]]
+            shape = tuple(len(s) for s in sub)
+            pts = torch.stack(torch.meshgrid(*sub, indexing='ij'), dim=-1).reshape(-1, 3)
+            block = query_func(pts).reshape(shape)
+            field[i0:i0 + shape[0], j0:j0 + shape[1], k0:k0 + shape[2]] = block.to(device=device, dtype=torch.float32)
+    return field.cpu().numpy()
 
 
 def extract_geometry(bound_min, bound_max, resolution, threshold, query_func, N=64):
@@ -34,9 +42,9 @@ def extract_geometry(bound_min, bound_max, resolution, threshold, query_func, N=
         import mcubes
     except ImportError as e:  # PyMCubes is a third-party CPU dependency of the reference, absent from this image
         raise ImportError("extract_geometry needs PyMCubes (mcubes); extract_fields works without it") from e
-    u = extract_fields(bound_min, bound_max, resolution, query_func, N)
-    vertices, triangles = mcubes.marching_cubes(u, threshold)
-    b_max_np = np.asarray(bound_max.detach().cpu() if isinstance(bound_max, torch.Tensor) else bound_max)
-    b_min_np = np.asarray(bound_min.detach().cpu() if isinstance(bound_min, torch.Tensor) else bound_min)
-    vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
-    return vertices, triangles
+    field = extract_fields(bound_min, bound_max, resolution, query_func, N)
+    vertices, triangles = mcubes.marching_cubes(field, threshold)
+    lo = np.asarray(torch.as_tensor(bound_min).detach().cpu(), dtype=np.float64)
+    hi = np.asarray(torch.as_tensor(bound_max).detach().cpu(), dtype=np.float64)
+    world = lo[None, :] + vertices * ((hi - lo) / (resolution - 1.0))[None, :]
+    return world, triangles
