@@ -1,15 +1,20 @@
-"""Fused MI355X path for ``nerf.forward_fine`` (model/nerf.py:776-941): one autograd node, ~25 HIP launches.
+"""Fused MI355X path for ``nerf.forward_fine`` / ``nerf.forward_coarse`` (model/nerf.py:776-941, 943-1075): one autograd
+node per forward, ~20 HIP launches each way.
 
-Forward:   march (1 wave / ray: sampling + SDF + 6-tap gradient + NeuS alpha + exact early-terminating scan)
+Forward:   march (1 wave / ray: sampling + SDF + 6-tap gradient + NeuS alpha + exact early-terminating scan; coarse: two
+           trilinear lookups in the dense smoothed / gradient volumes and both Alphas2Weights passes)
            -> scan of per-ray survivor counts -> ONE device->host read (M_s, needed to size the result tensors the
            reference API returns) -> survivor compaction -> feature kernels (k0 trilerp, 24 SDF taps, encodings,
-           reflection) writing straight into the MLP operand buffers -> fp32-MFMA GEMM chain (rgbnet, refnet) ->
-           3-wide head + sigmoid -> per-ray compositing.
-Backward:  compositing -> head -> GEMM chain (data + split-K weight gradients, bias gradients in the epilogues)
-           -> feature scatter (k0.grad, sdf.grad) -> march backward (alpha2weight + NeuS alpha, sdf.grad scatter).
+           reflection) writing straight into the MLP operand buffers -> the whole MLP chain in one persistent fp32-MFMA
+           launch (k_mlp_fwd; per-layer k_gemm launches for widths other than 256) -> 3-wide head + sigmoid -> per-ray
+           compositing.  The backward pass's big zero fills are issued here, at the end.
+Backward:  compositing -> head -> per layer ONE launch with the data-gradient tiles and the split-K weight-gradient
+           workgroups (k_linear_bwd; bias gradients in the epilogues) -> feature scatter (k0.grad) -> march backward
+           (alpha2weight + NeuS alpha) -> all sdf.grad contributions combined per survivor in LDS bricks.
+           With a dist.GradAverager attached, the MLP gradients and k0.grad are handed to the exchange from in here.
 
 The reference touches the host ~10 times per forward (`.item()`, seven boolean-mask compactions, `unique`); this
-path does it once.  Configurations outside ``supports`` run the operator-at-a-time kernels of render.py.
+path does it once.  Configurations outside ``supports`` / ``supports_coarse`` run the operator-at-a-time kernels.
 """
 from __future__ import annotations
 
