@@ -40,6 +40,8 @@ _SIGNATURES = {
     "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P, I64, P],
     "fgs_linear_bwd_f32": [I64, I64, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, P, I64, P],
     "fgs_mlp_fwd_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P],
+    "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],

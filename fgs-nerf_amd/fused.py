@@ -167,7 +167,10 @@ def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
 #             launches of a layer run concurrently (each ~175 us instead of 98 + 89)                  2.55 / 1.62
 #   "late"    weight gradients on the side stream after the whole data-gradient chain, under the atomics-bound scatter
 #             kernels of the feature / march backward                                                 2.61-2.9 / 1.52
-# The differences are within 3 %; "one" is the default because every launch then runs alone and per-kernel durations
+#   "chain"   (fine stage) every data gradient in ONE persistent k_mlp_fwd<true> launch on transposed weights (ReLU masks
+#             and bias-gradient column sums in its epilogues), then 7 weight-gradient k_gemm launches: the chain takes
+#             655 us and each weight gradient 91 us (1340 us with the encodings' columns, vs 7 x 181 = 1266)  2.65 / -
+# The differences are within 4 %; "one" is the default because every launch then runs alone and per-kernel durations
 # in a trace mean what they say.
 _LINEAR_BWD_MODE = os.environ.get("FGS_LINEAR_BWD", "one")
 # forward chain of the fine stage: one persistent k_mlp_fwd launch (default) or one k_gemm launch per layer (FGS_MLP_FWD=layers)
@@ -212,6 +215,52 @@ def _linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=None, colsum=None, logica
     else:
         _gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M, logical=(n_out, lk, M))
     _gemm(fo.GEMM_NN, dY, W, dX, M, k_in, n_out, mask=mask, colsum=colsum, logical=(M, lk, n_out))
+
+
+
+def _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
+                    gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs):
+    """FGS_LINEAR_BWD=chain: every data gradient of the two MLPs in ONE persistent launch (fgs_mlp_chain_f32: ReLU masks
+    and bias-gradient column sums in the epilogues, the intermediate dY tensors written out for the weight gradients),
+    then the positional-encoding columns of dZ and the 7 weight-gradient products as plain GEMMs."""
+    S = run.saved
+    dev = dY.device
+    WT = S['WT']                                   # transposed weights in chain order (built in forward)
+    layers, k = [], 0
+    spec = []                                      # (dY_in, a_in, dW, n_out, k_in, logical k_in) per chain layer
+    cur = dY
+    for i in range(n_ref - 2, 0, -1):
+        out = torch.empty(M, fw, dtype=F32, device=dev)
+        layers.append(dict(W=WT[k], K=fw, mask=acts_ref[i], colsum=gb_ref[i - 1], out=out)); k += 1
+        spec.append((cur, acts_ref[i], gw_ref[i], fw, fw, fw))
+        cur = out
+    dZ = torch.empty(M, ldz, dtype=F32, device=dev)
+    layers.append(dict(W=WT[k], K=fw, colsum=cs, out=dZ)); k += 1
+    spec.append((cur, acts_ref[0], gV0p, fw, ldz, ref_w[0].shape[1]))
+    dY_ref0 = cur
+    cur = dZ[:, :rw]
+    for i in range(n_rgb - 1, 0, -1):
+        out = torch.empty(M, rw, dtype=F32, device=dev)
+        layers.append(dict(W=WT[k], K=rw, mask=acts_rgb[i], colsum=gb_rgb[i - 1], out=out)); k += 1
+        spec.append((cur, acts_rgb[i], gw_rgb[i], rw, rw, rw))
+        cur = out
+    dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+    layers.append(dict(W=WT[k], K=rw, n_rows=ldx0, n_store=ldx0, out=dX0))
+    spec.append((cur, acts_rgb[0], gW0p, rw, ldx0, rgb_w[0].shape[1]))
+    fo.mlp_chain(M, dY, fw, layers)
+    grp = PROFILE.get("open")
+    if grp is not None:
+        grp[0] += 1
+        grp[1] += sum(2.0 * M * n_out * min(lk, 256) for _, _, _, n_out, _, lk in spec)
+    # encodings' columns of dZ (refnet layer 0 has ldz > 256 inputs)
+    if ldz > 256:
+        _gemm(fo.GEMM_NN, dY_ref0, S['V0p'][:, 256:], dZ[:, 256:], M, ldz - 256, fw,
+              logical=(M, ref_w[0].shape[1] - 256, fw))
+    gb_rgb[-1] = cs[:rw]
+    gw_ref[0] = gV0p[:, :ref_w[0].shape[1]]
+    for dy_in, a_in, dW, n_out, k_in, lk in spec:
+        _gemm(fo.GEMM_TN, dy_in, a_in, dW, n_out, k_in, M, logical=(n_out, lk, M))
+    return dZ, dX0
 
 
 def _flush_tn(dev) -> None:
@@ -348,12 +397,17 @@ class _FusedFine(torch.autograd.Function):
         if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
             run.pre = (torch.zeros_like(sdf_grid),
                        torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
+        WT = None
+        if run.pre is not None and _LINEAR_BWD_MODE == "chain" and rw == 256 and fw == 256 and n_ref - 1 + n_rgb <= 8:
+            # transposed weights in the order the backward chain walks the layers (dX = dY . W as a forward-shaped product)
+            WT = fo.transpose_multi([ref_w[i].detach() for i in range(n_ref - 2, 0, -1)] + [V0p[:, :rw]] +
+                                    [rgb_w[i].detach() for i in range(n_rgb - 1, 0, -1)] + [W0p])
 
         # Tensors this function RETURNS must not be reachable from ctx through plain attributes: output -> grad_fn -> ctx
         # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
-                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig,
+                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, WT=WT, pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
@@ -426,34 +480,38 @@ class _FusedFine(torch.autograd.Function):
         gW0p, gV0p, cs = views[-3], views[-2], views[-1]
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
-        for i in range(n_ref - 2, -1, -1):
-            a_in = acts_ref[i]                      # input of layer i: Z for i == 0
-            if i == 0:
-                dZ = torch.empty(M, ldz, dtype=F32, device=dev)
-                # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
-                # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
-                _linear_bwd(dY, S['V0p'], a_in, dZ, gV0p, M, fw, ldz, colsum=cs, logical_k_in=ref_w[0].shape[1])
-                gb_rgb[-1] = cs[:rw]
-            else:
-                d_in = torch.empty(M, fw, dtype=F32, device=dev)
-                _linear_bwd(dY, ref_w[i], a_in, d_in, gw_ref[i], M, fw, fw, mask=a_in, colsum=gb_ref[i - 1])
-                dY = d_in
-        gw_ref[0] = gV0p[:, :ref_w[0].shape[1]]
-        # 4. rgbnet layers n_rgb-1 .. 0 ; dY of the last layer is dZ[:, :rw] (a strided view, ld = ldz)
-        dY = dZ[:, :rw]
-        for i in range(n_rgb - 1, -1, -1):
-            a_in = acts_rgb[i]                      # X0 for i == 0
-            if i == 0:
-                dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _linear_bwd(dY, S['W0p'], a_in, dX0, gW0p, M, rw, ldx0, logical_k_in=rgb_w[0].shape[1])
-            else:
-                d_in = torch.empty(M, rw, dtype=F32, device=dev)
-                _linear_bwd(dY, rgb_w[i], a_in, d_in, gw_rgb[i], M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
-                dY = d_in
+        if S.get('WT') is not None and ldx0 <= 256:
+            dZ, dX0 = _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
+                                      gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs)
+        else:
+            for i in range(n_ref - 2, -1, -1):
+                a_in = acts_ref[i]                      # input of layer i: Z for i == 0
+                if i == 0:
+                    dZ = torch.empty(M, ldz, dtype=F32, device=dev)
+                    # no activation between the rgbnet output / encodings and refnet layer 0: no mask;
+                    # column sums of dZ[:, :rw] are the bias gradient of the last rgbnet layer
+                    _linear_bwd(dY, S['V0p'], a_in, dZ, gV0p, M, fw, ldz, colsum=cs, logical_k_in=ref_w[0].shape[1])
+                    gb_rgb[-1] = cs[:rw]
+                else:
+                    d_in = torch.empty(M, fw, dtype=F32, device=dev)
+                    _linear_bwd(dY, ref_w[i], a_in, d_in, gw_ref[i], M, fw, fw, mask=a_in, colsum=gb_ref[i - 1])
+                    dY = d_in
+            gw_ref[0] = gV0p[:, :ref_w[0].shape[1]]
+            # 4. rgbnet layers n_rgb-1 .. 0 ; dY of the last layer is dZ[:, :rw] (a strided view, ld = ldz)
+            dY = dZ[:, :rw]
+            for i in range(n_rgb - 1, -1, -1):
+                a_in = acts_rgb[i]                      # X0 for i == 0
+                if i == 0:
+                    dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+                    _linear_bwd(dY, S['W0p'], a_in, dX0, gW0p, M, rw, ldx0, logical_k_in=rgb_w[0].shape[1])
+                else:
+                    d_in = torch.empty(M, rw, dtype=F32, device=dev)
+                    _linear_bwd(dY, rgb_w[i], a_in, d_in, gw_rgb[i], M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
+                    dY = d_in
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
-        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split") else None   # dist.GradAverager.early
+        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split", "chain") else None   # dist.GradAverager.early
         if hook is not None:
             hook('mlp', mlp, flat)               # every MLP gradient is a view of `flat`, final from here on
 
@@ -647,7 +705,7 @@ class _FusedCoarse(torch.autograd.Function):
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
-        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split") else None   # dist.GradAverager.early
+        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split", "chain") else None   # dist.GradAverager.early
         if hook is not None:
             hook('mlp', mlp, flat)
         if run.pre is not None:

@@ -66,3 +66,33 @@ def mlp_fwd(M: int, X0: torch.Tensor, k0: int, T, t_cols: int, layers) -> None:
     ldo = I64Arr(*[l[4].stride(0) for l in layers])
     call("fgs_mlp_fwd_f32", M, n, ptr(X0), X0.stride(0), k0, ptr(T), 0 if T is None else T.stride(0), t_cols, W, ldw, K,
          bias, relu, outs, ldo, stream())
+
+
+def mlp_chain(M: int, X0: torch.Tensor, k0: int, layers) -> None:
+    """General one-launch chain (include/fgs_hip.h fgs_mlp_chain_f32), used for the backward data gradients.
+    `layers`: list of dicts with W [n_rows, ldw], K, out [M, >= n_store] and optional bias, relu, mask [M, ldm], colsum [256],
+    n_rows (default 256), n_store (default 256)."""
+    import ctypes
+    n = len(layers)
+    PtrArr, I64Arr, IntArr = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    g = lambda l, k, d=None: l.get(k, d)
+    call("fgs_mlp_chain_f32", M, n, ptr(X0), X0.stride(0), k0, None, 0, 0,
+         PtrArr(*[ptr(l['W']) for l in layers]), I64Arr(*[l['W'].stride(0) for l in layers]),
+         IntArr(*[int(l['K']) for l in layers]), IntArr(*[int(g(l, 'n_rows', 256)) for l in layers]),
+         PtrArr(*[ptr(g(l, 'bias')) for l in layers]), IntArr(*[int(bool(g(l, 'relu', False))) for l in layers]),
+         PtrArr(*[ptr(g(l, 'mask')) for l in layers]),
+         I64Arr(*[0 if g(l, 'mask') is None else l['mask'].stride(0) for l in layers]),
+         PtrArr(*[ptr(g(l, 'colsum')) for l in layers]), PtrArr(*[ptr(l['out']) for l in layers]),
+         I64Arr(*[l['out'].stride(0) for l in layers]), IntArr(*[int(g(l, 'n_store', 256)) for l in layers]), stream())
+
+
+def transpose_multi(mats) -> list:
+    """[W.t().contiguous() for W in mats] in one launch (W: 2-D float32 CUDA, unit column stride, at most 8 of them)."""
+    import ctypes
+    n = len(mats)
+    outs = [torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device) for w in mats]
+    PtrArr, I64Arr, IntArr = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    call("fgs_transpose_multi", n, PtrArr(*[ptr(w) for w in mats]), IntArr(*[w.shape[0] for w in mats]),
+         IntArr(*[w.shape[1] for w in mats]), I64Arr(*[w.stride(0) for w in mats]), PtrArr(*[ptr(o) for o in outs]),
+         I64Arr(*[o.stride(0) for o in outs]), stream())
+    return outs

@@ -237,6 +237,18 @@ int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const float *dY, 
 int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int k0, const float *T, int64_t ldt, int t_cols,
                     const float *const *W, const int64_t *ldw, const int *K, const float *const *bias, const int *relu,
                     float *const *outs, const int64_t *ldo, fgs_stream_t stream);
+/* The general form of the one-launch chain, also used for the BACKWARD data gradients (dY of the top layer in, transposed
+ * weights, per layer the ReLU mask of the layer below = its saved input, and the column sums = that layer's bias gradient):
+ *   W[l] [n_rows[l] <= 256, ldw[l]]: output column n uses weight row n (only the last layer may have fewer than 256 rows);
+ *   mask[l] [M, ldm[l]] or NULL: output (m, n) is zeroed where mask <= 0;   colsum[l] [256] or NULL: += column sums;
+ *   outs[l] receives the first n_store[l] columns (multiple of 4).  k0 <= 256 here. */
+int fgs_mlp_chain_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int k0, const float *T, int64_t ldt, int t_cols,
+                      const float *const *W, const int64_t *ldw, const int *K, const int *n_rows, const float *const *bias,
+                      const int *relu, const float *const *mask, const int64_t *ldm, float *const *colsum,
+                      float *const *outs, const int64_t *ldo, const int *n_store, fgs_stream_t stream);
+/* dst[i] [cols[i], ld_dst[i]] = transpose of src[i] [rows[i], ld_src[i]], i < n <= 8, one launch (HOST arrays). */
+int fgs_transpose_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
+                        float *const *dst, const int64_t *ld_dst, fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,

@@ -297,3 +297,55 @@ def test_config4_shape_320_grid_forward(dev, oracle):
     assert abs(res["ray_id"].shape[0] - ref["ray_id"].shape[0]) <= 16
     w_sum = torch.zeros(4096, device=dev).index_add_(0, res["ray_id"], res["weights"])
     assert float((w_sum + res["alphainv_cum"]).max()) <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("M", [1, 65, 1000, 49920])
+def test_mlp_chain_backward_data_gradients_match_per_layer_gemms(dev, M):
+    """fgs_mlp_chain_f32 as the backward data-gradient chain (ReLU masks, column sums, narrow last layer, transposed weights
+    from fgs_transpose_multi) against the same products issued one by one through fgs_gemm_f32 (GEMM_NN): every dX bit for
+    bit, column sums (atomics, order dependent) to 1e-5."""
+    from fgs_nerf_amd import fused_ops as fo
+    torch.manual_seed(M + 7)
+    dY = torch.randn(M, 256, device=dev)
+    Ws = [torch.randn(256, 256, device=dev) * 0.05 for _ in range(3)] + [torch.randn(256, 108, device=dev) * 0.05]
+    big = torch.randn(256, 308, device=dev) * 0.05
+    Ws[1] = big[:, :256]                                       # a strided weight (ld 308), like refnet layer 0
+    masks = [torch.relu(torch.randn(M, 256, device=dev)) for _ in range(2)] + [None, None]
+    WT = fo.transpose_multi(Ws)
+    for w, wt in zip(Ws, WT):
+        assert torch.equal(wt, w.t())
+    # reference: one GEMM per layer
+    ref_out, ref_cs, a = [], [], dY
+    for i, W in enumerate(Ws):
+        k_in = W.shape[1]
+        out = torch.empty(M, k_in, device=dev)
+        cs = torch.zeros(256, device=dev) if i < 3 else None
+        fo.gemm(fo.GEMM_NN, a, W, out, M, k_in, 256, mask=masks[i], colsum=cs)
+        ref_out.append(out); ref_cs.append(cs); a = out
+    outs = [torch.full((M, 256), float('nan'), device=dev) for _ in range(3)] + [torch.full((M, 108), float('nan'), device=dev)]
+    css = [torch.zeros(256, device=dev) for _ in range(3)] + [None]
+    layers = [dict(W=WT[i], K=256, mask=masks[i], colsum=css[i], out=outs[i]) for i in range(3)]
+    layers.append(dict(W=WT[3], K=256, n_rows=108, n_store=108, out=outs[3]))
+    fo.mlp_chain(M, dY, 256, layers)
+    for i in range(4):
+        assert torch.equal(outs[i], ref_out[i]), i
+        if css[i] is not None:
+            assert rel_l2(css[i], ref_cs[i]) < 1e-5, i
+
+
+def test_backward_chain_mode_matches_default_mode(dev, monkeypatch):
+    """FGS_LINEAR_BWD=chain (one persistent launch for all data gradients) against the default per-layer k_linear_bwd
+    launches on the same step: identical forward, gradients within the split-K / atomics order tolerance."""
+    from fgs_nerf_amd import fused, synth
+    rays = tuple(r.to(dev) for r in synth.random_rays(700, seed=5))
+    target = torch.rand(700, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    lossw = dict(synth.FINE_LOSS, weight_rgbper=0.05)
+    got = {}
+    for mode in ("one", "chain"):
+        monkeypatch.setattr(fused, "_LINEAR_BWD_MODE", mode)
+        model = synth.build_model(48, synth.FINE_MODEL, device=dev)
+        res, loss = run_step(model, rays, target, lossw)
+        got[mode] = (res["rgb_marched"].clone(), float(loss), {k: v.clone() for k, v in grads_of(model).items()})
+    assert torch.equal(got["one"][0], got["chain"][0]) and got["one"][1] == got["chain"][1]
+    for k, v in got["one"][2].items():
+        assert rel_l2(got["chain"][2][k], v) < 2e-5, k
