@@ -79,6 +79,8 @@ _SIGNATURES = {
                              P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_feat_coarse_fwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, I64, I64, I64, I64, P, P, P],
     "fgs_feat_coarse_bwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I64, I64, I64, I64, P, P],
+    "fgs_mc_count": [P, I32, I32, I32, F32, P, P, P, P, P],
+    "fgs_mc_emit": [P, I32, I32, I32, F32, P, P, P, P, P, P, I64, I64, P, P, P],
 }
 
 _lib = None
@@ -90,7 +92,8 @@ class FgsError(RuntimeError):
 
 def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
-    return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes"])
+    return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
+                                          "fgs_mc_num_blocks"])
 
 
 def lib() -> ctypes.CDLL:
@@ -110,6 +113,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_version.restype = c_int
         handle.fgs_gemm_workspace_bytes.restype = c_int64
         handle.fgs_gemm_workspace_bytes.argtypes = []
+        handle.fgs_mc_num_blocks.restype = c_int64
+        handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                                            ctypes.POINTER(c_int64)]
         handle.fgs_device_info.restype = c_int

@@ -426,6 +426,25 @@ int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *pts, cons
                         const float *X0, const float *dX0, const float *g_normal, float *k0_grad_grid, int64_t ksC,
                         int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient, fgs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * Marching cubes on a device-resident field -- replaces the host call mcubes.marching_cubes(u, threshold) of
+ * model/extract_geometry.py:24 (PyMCubes, third party): vertices in INDEX coordinates as float64 [V,3], shared between
+ * triangles; triangles int64 [T,3].  field: [X][Y][Z] float32; a corner is flagged when field < iso; triangle normals
+ * point towards decreasing field values.  Tables: fgs-nerf_amd/mc_tables.py (tri_table int8 [256][16], ntri uint8 [256]),
+ * device arrays.  Lattice points are handled 256 at a time (fgs_mc_num_blocks workgroups):
+ *   fgs_mc_count : vflags [X*Y*Z] (bit a: the +a edge of the point crosses iso), per-workgroup vertex / triangle totals
+ *   (caller)     : exclusive scans of the two total arrays (fgs_exclusive_scan_i64), totals read back, outputs allocated
+ *   fgs_mc_emit  : vbase [X*Y*Z] uint32 scratch, vertices, triangles.  Vertex ids follow (lattice point, axis) order,
+ *                  triangles follow cell order: the output is deterministic.
+ * ------------------------------------------------------------------------------ */
+int64_t fgs_mc_num_blocks(int X, int Y, int Z);
+int fgs_mc_count(const float *field, int X, int Y, int Z, float iso, const uint8_t *ntri_table, uint8_t *vflags,
+                 int64_t *block_vertices, int64_t *block_triangles, fgs_stream_t stream);
+int fgs_mc_emit(const float *field, int X, int Y, int Z, float iso, const int8_t *tri_table, const uint8_t *ntri_table,
+                const uint8_t *vflags, const int64_t *block_vertex_offset, const int64_t *block_triangle_offset,
+                uint32_t *vbase, int64_t n_vertices, int64_t n_triangles, double *vertices, int64_t *triangles,
+                fgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

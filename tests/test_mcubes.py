@@ -1,0 +1,114 @@
+"""Marching cubes (reference: mcubes.marching_cubes at model/extract_geometry.py:24).
+
+PyMCubes is not installed and the reference holds no mesh fixture (parity unpinned), so the surface is pinned three ways:
+the case table against the table-free CPU restatement (oracle/mcubes_ref.py), the device output bit for bit against that
+restatement on small fields, and known answers on analytic shapes (closed oriented manifold, Euler characteristic, area,
+distance of every vertex to the true surface)."""
+import numpy as np
+import pytest
+import torch
+
+
+def sphere(n, r=0.6, c=(0.0, 0.0, 0.0)):
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    x, y, z = np.meshgrid(ax, ax, ax, indexing='ij')
+    return np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2).astype(np.float32) - np.float32(r)
+
+
+def torus(n, R=0.55, r=0.22):
+    ax = np.linspace(-1, 1, n, dtype=np.float32)
+    x, y, z = np.meshgrid(ax, ax, ax, indexing='ij')
+    return (np.sqrt((np.sqrt(x * x + y * y) - R) ** 2 + z * z) - r).astype(np.float32)
+
+
+def noise(shape, seed):
+    f = np.random.default_rng(seed).standard_normal(shape).astype(np.float32)
+    f[0], f[-1], f[:, 0], f[:, -1], f[:, :, 0], f[:, :, -1] = (1.0,) * 6      # nothing flagged on the boundary: closed mesh
+    return f
+
+
+def test_case_table_matches_table_free_restatement():
+    from fgs_nerf_amd.mc_tables import tables
+    from oracle import mcubes_ref as R
+    tri, ntri = tables()
+    assert tri.shape == (256, 16) and ntri.max() == 5 and ntri[0] == 0 and ntri[255] == 0
+    for case in range(256):
+        ref = [R._edge_key(a, c) for t in R.cell_triangles(case) for a, c in t]
+        assert ntri[case] * 3 == len(ref)
+        assert tri[case, :len(ref)].tolist() == ref and (tri[case, len(ref):] == -1).all()
+        # a case and its complement cross the same edges
+        assert set(tri[case][tri[case] >= 0].tolist()) == set(tri[255 - case][tri[255 - case] >= 0].tolist())
+
+
+def test_restatement_known_answers_on_cpu():
+    from oracle import mcubes_ref as R
+    v, t = R.marching_cubes(sphere(20), 0.0)
+    rep = R.mesh_report(v, t)
+    assert rep['closed_oriented'] and rep['euler'] == 2 and rep['used_vertices'] == len(v)
+    world = v / 19.0 * 2.0 - 1.0
+    assert np.abs(np.linalg.norm(world, axis=1) - 0.6).max() < 2e-3
+    assert rep['signed_volume'] < 0                       # normals towards decreasing field = into the ball for a distance field
+    v, t = R.marching_cubes(noise((9, 10, 11), 3), 0.1)   # every ambiguous face configuration occurs in noise
+    rep = R.mesh_report(v, t)
+    assert rep['closed_oriented'] and len(t) > 200
+    v, t = R.marching_cubes(np.ones((4, 4, 4), np.float32), 0.0)
+    assert v.shape == (0, 3) and t.shape == (0, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,iso,seed", [((9, 10, 11), 0.1, 3), ((17, 5, 33), -0.2, 4), ((2, 2, 2), 0.0, 5), ((24, 24, 24), 0.0, 6)])
+def test_device_marching_cubes_is_bit_exact_against_restatement(dev, shape, iso, seed):
+    from fgs_nerf_amd.extract_geometry import marching_cubes
+    from oracle import mcubes_ref as R
+    f = np.random.default_rng(seed).standard_normal(shape).astype(np.float32) if seed != 6 else sphere(24)
+    v, t = marching_cubes(f, iso)
+    vr, tr = R.marching_cubes(f, iso)
+    assert v.dtype == np.float64 and v.shape == vr.shape and t.shape == tr.shape
+    assert np.array_equal(v, vr) and np.array_equal(t, tr)
+
+
+@pytest.mark.gpu
+def test_device_marching_cubes_known_answers(dev):
+    from fgs_nerf_amd.extract_geometry import marching_cubes, marching_cubes_device
+    from oracle import mcubes_ref as R
+    n = 192
+    v, t = marching_cubes(sphere(n), 0.0)
+    rep = R.mesh_report(v, t)
+    assert rep['closed_oriented'] and rep['euler'] == 2 and rep['used_vertices'] == len(v)
+    world = v / (n - 1.0) * 2.0 - 1.0
+    assert np.abs(np.linalg.norm(world, axis=1) - 0.6).max() < 1e-4
+    area = rep['area'] * (2.0 / (n - 1)) ** 2
+    assert abs(area / (4 * np.pi * 0.36) - 1) < 2e-3 and rep['signed_volume'] < 0
+    v, t = marching_cubes(torus(128), 0.0)
+    rep = R.mesh_report(v, t)
+    assert rep['closed_oriented'] and rep['euler'] == 0
+    v, t = marching_cubes(noise((64, 48, 80), 11), 0.3)
+    assert R.mesh_report(v, t)['closed_oriented'] and len(t) > 100000
+    # empty surface, device-resident input, the negated field gives the same surface with flipped triangles
+    v, t = marching_cubes(np.ones((8, 8, 8), np.float32), 0.0)
+    assert v.shape == (0, 3) and t.shape == (0, 3)
+    f = torch.from_numpy(sphere(64)).to(dev)
+    v1, t1 = marching_cubes_device(f, 0.0)
+    v2, t2 = marching_cubes_device(-f, 0.0)
+    assert v1.is_cuda and v1.shape == v2.shape and t1.shape == t2.shape
+    assert R.mesh_report(v2.cpu().numpy(), t2.cpu().numpy())['signed_volume'] > 0
+    with pytest.raises(RuntimeError):
+        marching_cubes_device(f.cpu(), 0.0)
+
+
+@pytest.mark.gpu
+def test_extract_geometry_on_the_sdf_model(dev):
+    """model.extract_geometry (model/nerf.py:1157-1170): -sdf at threshold 0 on a ball-initialised model -> a sphere in
+    world coordinates with outward normals."""
+    from fgs_nerf_amd import synth
+    from oracle import mcubes_ref as R
+    model = synth.build_model(48, synth.FINE_MODEL, device=dev)
+    with torch.no_grad():
+        ax = torch.linspace(-1, 1, 48, device=dev)
+        x, y, z = torch.meshgrid(ax, ax, ax, indexing='ij')
+        model.sdf.grid.data[0, 0] = torch.sqrt(x * x + y * y + z * z) - 0.6
+    verts, tris = model.extract_geometry(model.xyz_min.clone().float(), model.xyz_max.clone().float(), resolution=96, threshold=0.0)
+    assert verts.dtype == np.float64 and tris.shape[1] == 3
+    assert np.abs(np.linalg.norm(verts, axis=1) - 0.6).max() < 2e-3
+    rep = R.mesh_report(verts, tris)
+    assert rep['closed_oriented'] and rep['euler'] == 2 and rep['signed_volume'] > 0      # outward for the object (-sdf field)

@@ -35,8 +35,9 @@ def test_extract_fields_matches_grid_sample(dev, oracle):
     pts = torch.stack(torch.meshgrid(xs, xs, xs, indexing='ij'), -1).reshape(-1, 3)
     ref = oracle.dense_grid_forward(-m.sdf.grid.detach().cpu(), pts, lo, hi).reshape(70, 70, 70)
     assert rel_l2(u, ref) < 1e-6
-    with pytest.raises(ImportError):
-        m.extract_geometry(lo, hi, resolution=16)                     # PyMCubes is not part of this image
+    verts, tris = m.extract_geometry(lo, hi, resolution=70)            # device marching cubes (tests/test_mcubes.py)
+    assert verts.dtype == np.float64 and verts.shape[1] == 3 and tris.shape[1] == 3 and len(tris) > 0
+    assert verts.min() >= -1.0 and verts.max() <= 1.0 and int(tris.max()) == len(verts) - 1
 
 
 def test_stage_checkpoint_to_mask_cache_roundtrip(dev, tmp_path):
