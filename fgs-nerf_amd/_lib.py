@@ -79,6 +79,8 @@ _SIGNATURES = {
                              P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_feat_coarse_fwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, I64, I64, I64, I64, P, P, P],
     "fgs_feat_coarse_bwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I64, I64, I64, I64, P, P],
+    "fgs_ide_fwd": [P, P, P, P, I32, I32, I64, P, P],
+    "fgs_ide_bwd": [P, P, P, P, I32, I32, I64, P, P, P, P],
     "fgs_mc_count": [P, I32, I32, I32, F32, P, P, P, P, P],
     "fgs_mc_emit": [P, I32, I32, I32, F32, P, P, P, P, P, P, I64, I64, P, P, P],
 }

@@ -161,6 +161,8 @@ class nerf(torch.nn.Module):
         self.grad_mode = grad_mode
         self.init_gradient_conv()
         self.get_rays_of_a_view = nerf_ray.get_rays_of_a_view
+        from .ide import generate_ide_fn                          # model/nerf.py:179 (built, never evaluated there)
+        self.integrated_dir_enc = generate_ide_fn(sh_max_level)
         self.fused = fused
         self._gradient, self._gradient_pending = None, False
 

@@ -445,6 +445,17 @@ int fgs_mc_emit(const float *field, int X, int Y, int Z, float iso, const int8_t
                 uint32_t *vbase, int64_t n_vertices, int64_t n_triangles, double *vertices, int64_t *triangles,
                 fgs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * Integrated directional encoding -- generate_ide_fn / integrated_dir_enc_fn (model/utils.py:515-574; built at
+ * model/nerf.py:179, never evaluated by the reference's forward passes).  mat: [n_pow][n] coefficient matrix
+ * (n_pow = l_max + 1 <= 17), ml: int [2][n] rows (m, l), n <= 36; xyz [M,3], kappa_inv [M]; out / g_out [M][2n]
+ * (real parts, then imaginary parts).  All device pointers.
+ * ------------------------------------------------------------------------------ */
+int fgs_ide_fwd(const float *xyz, const float *kappa_inv, const float *mat, const int *ml, int n, int n_pow, int64_t M,
+                float *out, fgs_stream_t stream);
+int fgs_ide_bwd(const float *xyz, const float *kappa_inv, const float *mat, const int *ml, int n, int n_pow, int64_t M,
+                const float *g_out, float *g_xyz, float *g_kappa_inv, fgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

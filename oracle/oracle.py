@@ -580,3 +580,49 @@ def fine_losses(res: Dict, target: torch.Tensor, cfg: Dict) -> torch.Tensor:
     if cfg.get('sigmoid_rgb_loss', 0) > 0:
         loss = loss + cfg['sigmoid_rgb_loss'] * F.mse_loss(res['sigmoid_rgb'], target)
     return loss
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Integrated directional encoding: model/utils.py:168-210 (coefficients) and :515-574 (generate_ide_fn), restated with
+# the same torch calls on the CPU (`.cuda()` dropped, `np.math` -> `math`: numpy 2 removed the alias).  The reference never
+# evaluates it and holds no fixture: parity unpinned; tests/test_ide.py pins this restatement to scipy's Y_l^m instead.
+def generate_ide_fn(deg_view):
+    import math
+    if deg_view > 5:
+        raise ValueError('Only deg_view of at most 5 is numerically stable.')
+
+    def generalized_binomial_coeff(a, k):
+        return np.prod(a - np.arange(k)) / math.factorial(k)
+
+    def assoc_legendre_coeff(l, m, k):
+        return ((-1) ** m * 2 ** l * math.factorial(l) / math.factorial(k) / math.factorial(l - k - m) *
+                generalized_binomial_coeff(0.5 * (l + k + m - 1.0), l))
+
+    def sph_harm_coeff(l, m, k):
+        return (np.sqrt((2.0 * l + 1.0) * math.factorial(l - m) / (4.0 * np.pi * math.factorial(l + m))) *
+                assoc_legendre_coeff(l, m, k))
+
+    ml_list = []
+    for i in range(deg_view):
+        l = 2 ** i
+        for m in range(l + 1):
+            ml_list.append((m, l))
+    ml_array = np.array(ml_list).T
+    l_max = 2 ** (deg_view - 1)
+    mat = torch.zeros(l_max + 1, ml_array.shape[1])
+    for i, (m, l) in enumerate(ml_array.T):
+        for k in range(l - m + 1):
+            mat[k, i] = sph_harm_coeff(l, m, k)
+
+    def integrated_dir_enc_fn(xyz, kappa_inv):
+        x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
+        ml = torch.from_numpy(ml_array)
+        vmz = torch.cat([z ** i for i in range(mat.shape[0])], dim=-1)
+        vmxy = torch.cat([(x + 1j * y) ** m for m in ml[0, :]], dim=-1)
+        sph_harms = vmxy * (vmz @ mat.to(vmz.dtype))     # float32 inputs (the reference's case): mat as is
+        sigma = 0.5 * ml[1, :] * (ml[1, :] + 1)
+        ide = sph_harms * torch.exp(-sigma * kappa_inv)
+        return torch.cat([torch.real(ide), torch.imag(ide)], dim=-1)
+
+    integrated_dir_enc_fn.ml_array = ml_array
+    return integrated_dir_enc_fn
