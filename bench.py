@@ -36,11 +36,12 @@ STEP_STATS = {"survivors": 0}   # survivors (samples that reach the MLPs) summed
 def make_optimizer(model):
     """Stage param groups (config/shiny_blender.py:184-187,214-216; model/nerf_training.py:9-37)."""
     from fgs_nerf_amd.adam import MaskedAdam
-    groups = [{'params': [model.k0.grid], 'lr': 0.1, 'name': 'k0', 'skip_zero_grad': True},
-              {'params': [model.sdf.grid], 'lr': 0.005, 'name': 'sdf', 'skip_zero_grad': False}]
+    groups = [{'params': [model.sdf.grid], 'lr': 0.005, 'name': 'sdf', 'skip_zero_grad': False}]
     if model.rgbnet is not None:
         groups.append({'params': list(model.rgbnet.parameters()), 'lr': 1e-3, 'name': 'rgbnet', 'skip_zero_grad': False})
     groups.append({'params': list(model.refnet.parameters()), 'lr': 1e-3, 'name': 'refnet', 'skip_zero_grad': False})
+    # k0 last: on N > 1 GPUs its gradient exchange is the longest, and the other updates run while it finishes
+    groups.append({'params': [model.k0.grid], 'lr': 0.1, 'name': 'k0', 'skip_zero_grad': True})
     return MaskedAdam(groups, betas=(0.9, 0.99))
 
 
@@ -145,6 +146,7 @@ def main():
     opt = make_optimizer(model)
     averager = GradAverager(model.parameters(), force=force_dist)
     averager.attach(model)          # gradients are handed to the exchange from inside the backward pass (N > 1)
+    averager.attach_optimizer(opt)  # ... and the optimizer waits for k0's exchange only when it reaches k0
     n_global = RAYS_PER_GPU * world
 
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)

@@ -38,6 +38,7 @@ class MaskedAdam(torch.optim.Optimizer):
             if not ok:
                 raise ValueError(what)
         self.per_lr = None
+        self.before_param = None      # optional callable(param), invoked right before a parameter is updated (dist.py)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def set_pervoxel_lr(self, count):
@@ -74,6 +75,8 @@ class MaskedAdam(torch.optim.Optimizer):
             for p in group['params']:
                 if p.grad is None:
                     continue
+                if self.before_param is not None:       # dist.GradAverager.wait_for: this gradient's exchange is done
+                    self.before_param(p)
                 st = self._state_of(p)
                 st['step'] += 1
                 g = _as_layout_of(p.grad, p)

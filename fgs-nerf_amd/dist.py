@@ -63,6 +63,15 @@ class GradAverager:
         import os
         self.avg_in_collective = (dist.is_initialized() and dist.get_backend(group) == "nccl"
                                   and os.environ.get("FGS_DIST_SUM") != "1")
+        # The early exchanges (issued from inside the backward pass on a side stream) get a communicator of their own: with a
+        # single one, collectives execute in issue order, and the sdf all-reduce issued at the end of the backward pass
+        # would queue behind the much larger k0 exchange instead of running beside it.
+        self.early_group = group
+        if dist.is_initialized() and (self.world_size > 1 or self.force) and os.environ.get("FGS_DIST_ONE_COMM") != "1":
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.early_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+        self._deferred = {}               # id(param) -> event of its early exchange, waited on by wait_for()
+        self.defer_to_optimizer = False   # set by attach_optimizer(): the optimizer waits per parameter, not average()
         self._bucket = None
         self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
         self._hints = {}                  # id(param) -> state of hint_touched()
@@ -97,6 +106,9 @@ class GradAverager:
             h['box_key'] = (id(xyz_min), id(xyz_max))
         lo, hi = h['lo'], h['hi']
         pts = pts.detach().contiguous()
+        if h['armed'] and h.get('pts_key') == (pts.data_ptr(), pts.shape[0]):
+            return                                    # already hinted for this survivor list (from inside the forward pass)
+        h['pts_key'] = (pts.data_ptr(), pts.shape[0])
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(h['stream']):
@@ -111,9 +123,9 @@ class GradAverager:
         h['armed'] = True
 
     # ------------------------------------------------------------------------------------------------ pieces
-    def _dense(self, g: torch.Tensor, async_op: bool):
+    def _dense(self, g: torch.Tensor, async_op: bool, group=None):
         flat = g.as_strided((g.numel(),), (1,))       # the dense storage as a flat view (layout-agnostic, no copy)
-        return dist.all_reduce(flat, op=self._op(), group=self.group, async_op=async_op), flat
+        return dist.all_reduce(flat, op=self._op(), group=group or self.group, async_op=async_op), flat
 
     def _op(self):
         return dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
@@ -122,8 +134,9 @@ class GradAverager:
         if not self.avg_in_collective:
             t.mul_(inv)
 
-    def _sparse(self, g: torch.Tensor, inv: float, param=None) -> bool:
+    def _sparse(self, g: torch.Tensor, inv: float, param=None, group=None) -> bool:
         """Brick-sparse exchange of one multi-channel grid gradient.  Returns False if the dense path should be used."""
+        group = group or self.group
         bv = _brick_view(g)
         if bv is None:
             return False
@@ -146,7 +159,7 @@ class GradAverager:
             idx = h['idx'][:n]
             buf = torch.empty(n, BRICK ** 3 * C, dtype=g.dtype, device=g.device)
             call("fgs_brick_gather", ptr(g), *dims, ptr(idx), n, ptr(buf), stream())
-            dist.all_reduce(buf, op=self._op(), group=self.group)
+            dist.all_reduce(buf, op=self._op(), group=group)
             call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), 1.0 if self.avg_in_collective else float(inv),
                  stream())
             return True
@@ -156,7 +169,7 @@ class GradAverager:
             call("fgs_brick_flags", ptr(g), *dims, ptr(flags), stream())
         else:            # host tensors (gloo tests): the same thing with torch indexing
             flags = (bv != 0).any(dim=6).any(dim=5).any(dim=3).any(dim=1).to(torch.int32).reshape(-1)
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)                         # union of occupancy
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)                              # union of occupancy
         idx = flags.nonzero(as_tuple=False).squeeze(1)                                          # identical on all ranks
         n = int(idx.numel())
         self.last_sparse_fill = n / max(total, 1)
@@ -167,7 +180,7 @@ class GradAverager:
         if on_gpu:
             buf = torch.empty(n, BRICK ** 3 * C, dtype=g.dtype, device=g.device)
             call("fgs_brick_gather", ptr(g), *dims, ptr(idx), n, ptr(buf), stream())
-            dist.all_reduce(buf, op=self._op(), group=self.group)
+            dist.all_reduce(buf, op=self._op(), group=group)
             call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), 1.0 if self.avg_in_collective else float(inv),
                  stream())
             return True
@@ -175,7 +188,7 @@ class GradAverager:
         by = (idx // nbz) % nby
         bz = idx % nbz
         buf = bv[bx, :, by, :, bz, :, :].contiguous()                                           # [n,4,4,4,C] gather
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf.mul_(inv)
         bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
         return True
@@ -183,7 +196,26 @@ class GradAverager:
     def attach(self, model) -> None:
         """Let the fused backward pass of `model` (fused.py) hand gradients over as soon as they are final (see `early`)."""
         if self.world_size > 1 or self.force:
+            # (issuing hint_touched from inside the forward, right after the survivor list exists, was measured: its side
+            # stream then competes with the persistent MLP kernel and the step gets 0.09 ms slower, not faster)
             model.__dict__.setdefault('_fused_cache', {})['grad_hook'] = self.early
+
+    def attach_optimizer(self, optimizer) -> None:
+        """Let the optimizer wait for an early exchange only when it reaches that parameter (MaskedAdam.before_param):
+        the TV pass and the updates of the other parameters then run under the tail of the k0 exchange."""
+        if (self.world_size > 1 or self.force) and hasattr(optimizer, 'before_param'):
+            optimizer.before_param = self.wait_for
+            self.defer_to_optimizer = True
+
+    def wait_for(self, param) -> None:
+        ev = self._deferred.pop(id(param), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def wait_all(self) -> None:
+        for ev in self._deferred.values():
+            torch.cuda.current_stream().wait_event(ev)
+        self._deferred.clear()
 
     # ------------------------------------------------------------------------------------------------ early exchange
     def early(self, kind: str, params, tensor: Optional[torch.Tensor] = None) -> None:
@@ -192,15 +224,18 @@ class GradAverager:
           early('k0',  [k0 param],  grad)  after the feature-grid scatter; ~175 us of sdf scatter kernels follow;
           early('mlp', mlp params,  flat)  after the MLP chain; `flat` is the one buffer all MLP gradients are views of,
                                            so a single in-place all-reduce replaces the bucket pack / unpack;
-          early('join', ...)               before the backward pass copies anything out of `flat`.
-        `average()` then skips these parameters and only makes the main stream wait for the side stream."""
+          early('join', ...)               before the backward pass copies anything out of `flat`: waits for the 'mlp'
+                                           exchange only.
+        `average()` then skips these parameters; the main stream waits for the k0 exchange at the end of `average()`, or,
+        with `attach_optimizer`, when the optimizer reaches k0."""
         if (self.world_size == 1 and not self.force) or tensor is None and kind != 'join':
             return
         inv = 1.0 / self.world_size
-        st = self.__dict__.setdefault('_early', dict(stream=None, done=None, params=set()))
+        st = self.__dict__.setdefault('_early', dict(stream=None, mlp_done=None, params=set()))
         if kind == 'join':
-            if st['done'] is not None:
-                torch.cuda.current_stream().wait_event(st['done'])
+            if st['mlp_done'] is not None:
+                torch.cuda.current_stream().wait_event(st['mlp_done'])
+                st['mlp_done'] = None
             return
         if not tensor.is_cuda:
             return
@@ -212,17 +247,23 @@ class GradAverager:
             st['stream'].wait_event(ready)
             if kind == 'k0':
                 g = tensor
-                ok = (g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1 and self._sparse(g, inv, params[0]))
+                ok = (g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1
+                      and self._sparse(g, inv, params[0], group=self.early_group))
                 if not ok:
-                    _, flat = self._dense(g, async_op=False)
+                    _, flat = self._dense(g, async_op=False, group=self.early_group)
                     self._post_scale(flat, inv)
             else:
-                dist.all_reduce(tensor, op=self._op(), group=self.group)
+                dist.all_reduce(tensor, op=self._op(), group=self.early_group)
                 self._post_scale(tensor, inv)
-            st['done'] = torch.cuda.Event()
-            st['done'].record()
+            done = torch.cuda.Event()
+            done.record()
         tensor.record_stream(st['stream'])
         st['params'].update(id(p) for p in params)
+        if kind == 'mlp':
+            st['mlp_done'] = done                       # waited for by early('join') at the end of the backward pass
+        else:
+            for p in params:
+                self._deferred[id(p)] = done
 
     # ------------------------------------------------------------------------------------------------ driver
     @torch.no_grad()
@@ -236,8 +277,6 @@ class GradAverager:
         skip = set()
         if early is not None and early['params']:
             skip, early['params'] = early['params'], set()
-            if early['done'] is not None:
-                torch.cuda.current_stream().wait_event(early['done'])
         for p in self.params:
             g = p.grad
             if g is None or id(p) in skip:
@@ -272,3 +311,5 @@ class GradAverager:
         for h, flat in handles:
             h.wait()
             self._post_scale(flat, inv)
+        if not self.defer_to_optimizer:
+            self.wait_all()

@@ -125,6 +125,7 @@ class TrainStepper:
         self.averager = averager
         if averager is not None:
             averager.attach(model)
+            averager.attach_optimizer(self.optimizer)        # k0's exchange is waited for when the optimizer reaches k0
         self.poses_train, self.near = poses_train, near
         if self.cfg_train.get('ray_sampler', 'flatten') not in ('flatten', 'in_maskcache', 'random'):
             raise NotImplementedError(self.cfg_train.ray_sampler)
@@ -210,6 +211,8 @@ class TrainStepper:
             if ct.get('weight_tv_density', 0) > 0 and tv_terms.get('sdf_tv', 0) > 0:
                 model.sdf_total_variation_add_grad(ct.weight_tv_density * tv_terms.sdf_tv / n_rays, dense)
             if ct.get('weight_tv_k0', 0) > 0:
+                if self.averager is not None:
+                    self.averager.wait_for(model.k0.grid)    # the TV pass writes into k0.grad: its exchange must be done
                 model.k0_total_variation_add_grad(ct.weight_tv_k0 / n_rays, dense)
         opt.step()
         # statistics (:374-385), kept on the device
