@@ -288,6 +288,29 @@ def _join_side(dev) -> None:
     keep.clear()
 
 
+_PRE_FILL_AT_READ = os.environ.get("FGS_PRE_FILL", "read") == "read"
+
+
+def _read_count(run, offsets, n, k0_like):
+    """The one host read of a step: offsets[n] (the survivor count).  The copy goes to pinned memory, and the largest zero
+    fill of the backward pass (k0.grad, 197 MB at 160^3: ~55 us) is queued BEHIND it, so the device spends the ~50 us the
+    host needs to wake up and launch the next kernels on that fill instead of idling.  Returns (count, zeroed k0.grad or
+    None)."""
+    pre = None
+    if not _PRE_FILL_AT_READ:
+        return int(offsets[n].item()), None
+    host = run.cache.get('count_host')
+    if host is None:
+        host = run.cache['count_host'] = torch.empty(1, dtype=I64).pin_memory()
+    host.copy_(offsets[n:n + 1], non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    if k0_like is not None:
+        pre = torch.empty_strided(k0_like.shape, k0_like.stride(), dtype=F32, device=k0_like.device).zero_()
+    done.synchronize()
+    return int(host[0]), pre
+
+
 class _FusedFine(torch.autograd.Function):
     """inputs: sdf grid, k0 grid, then (weight, bias) of every rgbnet and refnet Linear; `run` carries the rest."""
 
@@ -318,7 +341,7 @@ class _FusedFine(torch.autograd.Function):
         W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M = int(ws['surv_off'][N].item())          # the one host read of the step
+        M, pre_k0 = _read_count(run, ws['surv_off'], N, k0_grid if any(ctx.needs_input_grad) else None)
         run.M = M
         # 2. survivors
         ray_id = torch.empty(M, dtype=I64, device=dev)
@@ -396,6 +419,7 @@ class _FusedFine(torch.autograd.Function):
         run.pre = None
         if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
             run.pre = (torch.zeros_like(sdf_grid),
+                       pre_k0 if pre_k0 is not None else
                        torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
         WT = None
         if run.pre is not None and _LINEAR_BWD_MODE == "chain" and rw == 256 and fw == 256 and n_ref - 1 + n_rgb <= 8:
@@ -599,7 +623,7 @@ class _FusedCoarse(torch.autograd.Function):
         fw, ldx0 = ref_w[0].shape[0], run.ldx0
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M = int(ws['surv_off'][N].item())          # the one host read of the step
+        M, pre_k0 = _read_count(run, ws['surv_off'], N, k0_grid if any(ctx.needs_input_grad) else None)
         run.M = M
         ray_id = torch.empty(M, dtype=I64, device=dev)
         step_id = torch.empty(M, dtype=I64, device=dev)
@@ -643,6 +667,7 @@ class _FusedCoarse(torch.autograd.Function):
         run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
+                       pre_k0 if pre_k0 is not None else
                        torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
                                    V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
