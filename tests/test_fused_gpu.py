@@ -349,3 +349,43 @@ def test_backward_chain_mode_matches_default_mode(dev, monkeypatch):
     assert torch.equal(got["one"][0], got["chain"][0]) and got["one"][1] == got["chain"][1]
     for k, v in got["one"][2].items():
         assert rel_l2(got["chain"][2][k], v) < 2e-5, k
+
+
+def test_fused_full_size_backward_properties(dev):
+    """BASELINE config 2 shape (160^3, 4096 rays), backward pass, through properties that need no oracle run of that size:
+    gradients are linear in the upstream gradient (2 x loss -> 2 x every gradient, to fp32 summation-order noise); the
+    integer outputs and the loss repeat bit for bit; k0.grad is supported only on the 8 trilinear corners of the survivors
+    (the occupancy the multi-GPU exchange relies on); the channels of a touched k0 voxel are all written."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    model = synth.build_model(160, synth.FINE_MODEL, device=dev)
+    rays = tuple(t.to(dev) for t in synth.random_rays(4096))
+    target = torch.rand(4096, 3, generator=torch.Generator().manual_seed(12)).to(dev)
+    lossw = dict(synth.FINE_LOSS, weight_rgbper=0.05)
+
+    def step(scale):
+        for p in model.parameters():
+            p.grad = None
+        res = model(*rays, global_step=1000, **synth.RENDER_KWARGS)
+        loss = render_losses(res, target, lossw, model)
+        (loss * scale).backward()
+        return res, float(loss), {k: v.clone() for k, v in grads_of(model).items()}
+    r1, l1, g1 = step(1.0)
+    r2, l2, g2 = step(2.0)
+    assert torch.equal(r1["ray_id"], r2["ray_id"]) and torch.equal(r1["step_id"], r2["step_id"]) and l1 == l2
+    assert torch.equal(r1["rgb_marched"], r2["rgb_marched"])
+    for k in g1:
+        assert rel_l2(g2[k], 2.0 * g1[k]) < 2e-5, k
+        assert bool(torch.isfinite(g1[k]).all()), k
+    # support of k0.grad: corners of the survivors' cells
+    pts = r1["survivor_pts"]
+    idx = (pts - model.xyz_min) / (model.xyz_max - model.xyz_min) * 159.0
+    base = idx.floor().long().clamp(0, 158)
+    touched = torch.zeros(160, 160, 160, dtype=torch.bool, device=dev)
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                touched[base[:, 0] + dx, base[:, 1] + dy, base[:, 2] + dz] = True
+    nz = (g1["k0"][0] != 0)
+    assert not bool((nz.any(dim=0) & ~touched).any())
+    assert int(nz.any(dim=0).sum()) > 100_000 and int(touched.sum()) < 2 * int(nz.any(dim=0).sum())
