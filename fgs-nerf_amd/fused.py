@@ -291,24 +291,32 @@ def _join_side(dev) -> None:
 _PRE_FILL_AT_READ = os.environ.get("FGS_PRE_FILL", "read") == "read"
 
 
-def _read_count(run, offsets, n, k0_like):
-    """The one host read of a step: offsets[n] (the survivor count).  The copy goes to pinned memory, and the largest zero
-    fill of the backward pass (k0.grad, 197 MB at 160^3: ~55 us) is queued BEHIND it, so the device spends the ~50 us the
-    host needs to wake up and launch the next kernels on that fill instead of idling.  Returns (count, zeroed k0.grad or
-    None)."""
-    pre = None
+def _count_begin(run, offsets, n):
+    """The one host read of a step, first half: offsets[n] (the survivor count) starts travelling to pinned memory.  Work
+    queued between _count_begin and _count_end sits BEHIND the copy in the stream: the device executes it during the
+    ~50 us the host needs to wake up from the wait and launch the next kernels, instead of idling -- the weight pads and
+    the largest zero fill of the backward pass (k0.grad, 197 MB at 160^3) go there."""
     if not _PRE_FILL_AT_READ:
-        return int(offsets[n].item()), None
+        return None, offsets, n
     host = run.cache.get('count_host')
     if host is None:
         host = run.cache['count_host'] = torch.empty(1, dtype=I64).pin_memory()
     host.copy_(offsets[n:n + 1], non_blocking=True)
     done = torch.cuda.Event()
     done.record()
-    if k0_like is not None:
-        pre = torch.empty_strided(k0_like.shape, k0_like.stride(), dtype=F32, device=k0_like.device).zero_()
+    return done, host, 0
+
+
+def _count_end(token) -> int:
+    done, src, i = token
+    if done is None:
+        return int(src[i].item())
     done.synchronize()
-    return int(host[0]), pre
+    return int(src[i])
+
+
+def _zeros_like_strided(t):
+    return torch.empty_strided(t.shape, t.stride(), dtype=F32, device=t.device).zero_()
 
 
 class _FusedFine(torch.autograd.Function):
@@ -316,6 +324,9 @@ class _FusedFine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run, sdf_grid, k0_grid, *mlp):
+        # outputs the loss does not use arrive as None in backward (the kernels take NULL) instead of as zero tensors that
+        # autograd would fill -- six launches of ~5 us at the head of the backward pass, one of them an int64 fill for ray_id
+        ctx.set_materialize_grads(False)
         dev = sdf_grid.device
         g, N, st = run.geom, run.n_rays, stream()
         ms = run.max_steps
@@ -338,10 +349,12 @@ class _FusedFine(torch.autograd.Function):
         ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
         rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
         ldx0, ldz = run.ldx0, run.ldz
-        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one copy+pad launch each
+        token = _count_begin(run, ws['surv_off'], N)
+        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one fill + one copy launch each
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
+        pre_k0 = _zeros_like_strided(k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M, pre_k0 = _read_count(run, ws['surv_off'], N, k0_grid if any(ctx.needs_input_grad) else None)
+        M = _count_end(token)                      # the one host read of the step
         run.M = M
         # 2. survivors
         ray_id = torch.empty(M, dtype=I64, device=dev)
@@ -419,8 +432,7 @@ class _FusedFine(torch.autograd.Function):
         run.pre = None
         if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
             run.pre = (torch.zeros_like(sdf_grid),
-                       pre_k0 if pre_k0 is not None else
-                       torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
+                       pre_k0 if pre_k0 is not None else _zeros_like_strided(k0_grid))
         WT = None
         if run.pre is not None and _LINEAR_BWD_MODE == "chain" and rw == 256 and fw == 256 and n_ref - 1 + n_rgb <= 8:
             # transposed weights in the order the backward chain walks the layers (dX = dY . W as a forward-shaped product)
@@ -604,6 +616,7 @@ class _FusedCoarse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run, sdf_smooth, gradvol, k0_grid, *mlp):
+        ctx.set_materialize_grads(False)              # see _FusedFine.forward
         dev = sdf_smooth.device
         g, N, st, ms, ws = run.geom, run.n_rays, stream(), run.max_steps, run.workspace
         sdf_smooth, gradvol = sdf_smooth.contiguous(), gradvol.contiguous()
@@ -617,13 +630,15 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
              ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
-        n_ref = run.n_ref                           # issued before the host read: K-padded first-layer weights
+        token = _count_begin(run, ws['surv_off'], N)
+        n_ref = run.n_ref                           # queued behind the count copy: K-padded first-layer weights, k0.grad fill
         ref_w = [mlp[2 * i] for i in range(n_ref)]
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
         fw, ldx0 = ref_w[0].shape[0], run.ldx0
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
+        pre_k0 = _zeros_like_strided(k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M, pre_k0 = _read_count(run, ws['surv_off'], N, k0_grid if any(ctx.needs_input_grad) else None)
+        M = _count_end(token)                      # the one host read of the step
         run.M = M
         ray_id = torch.empty(M, dtype=I64, device=dev)
         step_id = torch.empty(M, dtype=I64, device=dev)
@@ -667,8 +682,7 @@ class _FusedCoarse(torch.autograd.Function):
         run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
-                       pre_k0 if pre_k0 is not None else
-                       torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_())
+                       pre_k0 if pre_k0 is not None else _zeros_like_strided(k0_grid))
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
                                    V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
