@@ -216,82 +216,97 @@ __device__ __forceinline__ Normal3 normal_of(float gx, float gy, float gz) {
   return o;
 }
 
-// [x, sin(x f_i), cos(x f_i)] block of one component: row[3 + c*F + f], row[3 + 3F + c*F + f]
-__device__ __forceinline__ void write_pe_component(float *__restrict__ row, int c, float x, int F) {
-  row[c] = x;
-  float freq = 1.f;
-  for (int f = 0; f < F; ++f) {
-    const float arg = x * freq;
-    row[3 + c * F + f] = sinf(arg);
-    row[3 + 3 * F + c * F + f] = cosf(arg);
-    freq *= 2.f;
-  }
-}
-
+// 32 lanes per survivor.  The 3 (F_pos + F_view + F_ref) sin/cos pairs of a row are dealt round-robin to the lanes (two
+// sincosf per lane for the fine layout instead of a chain of eight), consecutive lanes write consecutive columns; the raw
+// components, the normal and the scalar columns are written by the first lanes / the last lane.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X0, float *Z /* == X0 in coarse mode */,
                                                             float *__restrict__ normal_out) {
-  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int slot = threadIdx.x & 15;
-  if (m >= S.M || slot > 9) return;
+  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int j = threadIdx.x & 31;
+  if (m >= S.M) return;
   const FeatLayout &L = S.L;
   float *x0 = X0 + m * L.ldx0;
-  if (slot < 3) {  // rays_xyz = (p - lo) / (hi - lo), model/nerf.py:837
-    const float u = (S.pts[3 * m + slot] - S.geom.lo[slot]) / (S.geom.hi[slot] - S.geom.lo[slot]);
-    write_pe_component(x0 + L.off_xyz, slot, u, L.n_posfreq);
-  } else if (slot < 6) {
-    if (L.use_viewdir) write_pe_component(x0 + L.off_view, slot - 3, S.viewdirs[3 * S.ray_id[m] + (slot - 3)], L.n_viewfreq);
-  } else if (slot < 9) {
-    const int c = slot - 6;
-    const int64_t r = S.ray_id[m];
-    const float v0 = S.viewdirs[3 * r], v1 = S.viewdirs[3 * r + 1], v2 = S.viewdirs[3 * r + 2];
-    const Normal3 nn = normal_of(S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]);
-    const float dot = (v0 * nn.n[0] + v1 * nn.n[1]) + v2 * nn.n[2];
-    const float vc = (c == 0) ? v0 : (c == 1 ? v1 : v2);
-    const float refl = vc - (2.f * dot) * nn.n[c];  // model/nerf.py:879
-    write_pe_component(Z + m * L.ldz + L.off_ref, c, refl, L.n_reffreq);
-    normal_out[3 * m + c] = nn.n[c];
-  } else {  // slot 9: scalar features and zero padding
-    if (L.center_sdf) x0[L.off_sdf] = S.sdf[m];
-    if (L.coarse) {
-      const Normal3 nn = normal_of(S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]);
-      x0[L.off_grad + 0] = nn.n[0];
-      x0[L.off_grad + 1] = nn.n[1];
-      x0[L.off_grad + 2] = nn.n[2];
-    } else {
-      x0[L.off_grad + 0] = S.gradient[3 * m + 0];
-      x0[L.off_grad + 1] = S.gradient[3 * m + 1];
-      x0[L.off_grad + 2] = S.gradient[3 * m + 2];
+  float *zr = Z + m * L.ldz;
+  const int64_t r = S.ray_id[m];
+  const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
+  const float g[3] = {S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]};
+  const Normal3 nn = normal_of(g[0], g[1], g[2]);
+  const float dot = (v[0] * nn.n[0] + v[1] * nn.n[1]) + v[2] * nn.n[2];
+  float u[3], refl[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    u[c] = (S.pts[3 * m + c] - S.geom.lo[c]) / (S.geom.hi[c] - S.geom.lo[c]);   // rays_xyz, model/nerf.py:837
+    refl[c] = v[c] - (2.f * dot) * nn.n[c];                                     // model/nerf.py:879
+  }
+  const int Fp = L.n_posfreq, Fv = L.use_viewdir ? L.n_viewfreq : 0, Fr = L.n_reffreq;
+  const int n_pairs = 3 * (Fp + Fv + Fr);
+  for (int p = j; p < n_pairs; p += 32) {
+    int q = p, F = Fp;
+    float *row = x0 + L.off_xyz;
+    const float *src = u;
+    if (q >= 3 * Fp) {
+      q -= 3 * Fp; F = Fv; row = x0 + L.off_view; src = v;
+      if (q >= 3 * Fv) { q -= 3 * Fv; F = Fr; row = zr + L.off_ref; src = refl; }
     }
+    const int c = q / F, f = q - c * F;
+    const float x = (c == 0) ? src[0] : (c == 1 ? src[1] : src[2]);
+    float sn, cs;
+    sincosf(x * (float)(1 << f), &sn, &cs);     // freq = 2^f exactly, as the repeated doubling gives
+    row[3 + c * F + f] = sn;
+    row[3 + 3 * F + c * F + f] = cs;
+  }
+  if (j < 3) {
+    x0[L.off_xyz + j] = (j == 0) ? u[0] : (j == 1 ? u[1] : u[2]);
+    normal_out[3 * m + j] = (j == 0) ? nn.n[0] : (j == 1 ? nn.n[1] : nn.n[2]);
+  } else if (j < 6) {
+    if (L.use_viewdir) x0[L.off_view + (j - 3)] = (j == 3) ? v[0] : (j == 4 ? v[1] : v[2]);
+  } else if (j < 9) {
+    zr[L.off_ref + (j - 6)] = (j == 6) ? refl[0] : (j == 7 ? refl[1] : refl[2]);
+  } else if (j == 31) {  // scalar features and zero padding
+    if (L.center_sdf) x0[L.off_sdf] = S.sdf[m];
+    x0[L.off_grad + 0] = L.coarse ? nn.n[0] : g[0];
+    x0[L.off_grad + 1] = L.coarse ? nn.n[1] : g[1];
+    x0[L.off_grad + 2] = L.coarse ? nn.n[2] : g[2];
     for (int c = L.x0_cols; c < L.ldx0; ++c) x0[c] = 0.f;
     if (!L.coarse)
-      for (int c = L.z_cols; c < L.ldz; ++c) Z[m * L.ldz + c] = 0.f;
+      for (int c = L.z_cols; c < L.ldz; ++c) zr[c] = 0.f;
   }
 }
 
-// One thread per survivor: gradients reaching sdf and the raw gradient vector through the feature columns,
-// the normal (orientation loss, reflection) and the reflection encoding.
+// 32 lanes per survivor: gradients reaching sdf and the raw gradient vector through the feature columns, the normal
+// (orientation loss, reflection) and the reflection encoding.  The 3 F_ref (sin, cos) column pairs are dealt to the lanes
+// and summed with shuffles; the short tail is computed by every lane and written by lane 0.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const float *__restrict__ Z,
                                                             const float *__restrict__ dX0, const float *__restrict__ dZ,
                                                             const float *__restrict__ g_normal, float *__restrict__ g_sdf,
                                                             float *__restrict__ g_gradient) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= S.M) return;
+  const int64_t m_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int j = threadIdx.x & 31;
+  const bool live = m_raw < S.M;
+  const int64_t m = live ? m_raw : 0;        // every lane takes part in the shuffles
   const FeatLayout &L = S.L;
   const int F = L.n_reffreq;
   const float *z = Z + m * L.ldz + L.off_ref;
   const float *dz = dZ + m * L.ldz + L.off_ref;
-  // d reflect_c = dE[c] + sum_f f (cos * dE_sin - sin * dE_cos)
-  float dr[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float acc = dz[c], freq = 1.f;
-    for (int f = 0; f < F; ++f) {
+  // d reflect_c = dE[c] + sum_f 2^f (cos * dE_sin - sin * dE_cos)
+  float part[3] = {0.f, 0.f, 0.f};
+  if (live)
+    for (int p = j; p < 3 * F; p += 32) {
+      const int c = p / F, f = p - c * F;
       const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
-      acc += freq * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
-      freq *= 2.f;
+      const float t = (float)(1 << f) * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
+      part[0] += (c == 0) ? t : 0.f;
+      part[1] += (c == 1) ? t : 0.f;
+      part[2] += (c == 2) ? t : 0.f;
     }
-    dr[c] = acc;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    part[0] += __shfl_xor(part[0], off, 32);
+    part[1] += __shfl_xor(part[1], off, 32);
+    part[2] += __shfl_xor(part[2], off, 32);
   }
+  if (!live || j != 0) return;
+  const float dr[3] = {dz[0] + part[0], dz[1] + part[1], dz[2] + part[2]};
   const int64_t r = S.ray_id[m];
   const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
   const float g[3] = {S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]};
@@ -611,7 +626,7 @@ FGS_API int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *p
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_fwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grid, kd, X0);
   FGS_LAUNCH_OK("fgs_feat_coarse_fwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 16)), dim3(FGS_BLOCK), 0, st, S, X0, X0, normal_out);
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, X0, normal_out);
   FGS_LAUNCH_OK("fgs_feat_coarse_fwd/enc");
   return 0;
 }
@@ -633,7 +648,7 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
                      (float *)nullptr, g_gradient);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/enc");
   return 0;
@@ -661,7 +676,7 @@ FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts
     hipLaunchKernelGGL(k_feat_taps_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, sdf_grid, X0);
     FGS_LAUNCH_OK("fgs_feat_fine_fwd/taps");
   }
-  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 16)), dim3(FGS_BLOCK), 0, st, S, X0, Zbuf, normal_out);
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, Zbuf, normal_out);
   FGS_LAUNCH_OK("fgs_feat_fine_fwd/enc");
   return 0;
 }
@@ -684,7 +699,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
                      g_gradient);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/enc");
   (void)sdf_grad_grid;  // the sdf.grad scatter of the survivors is fgs_sdf_scatter_surv (after fgs_march_fine_bwd)

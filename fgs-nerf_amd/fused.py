@@ -906,13 +906,14 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
         model.gradient = keep
         return mask
 
-    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id, 'viewdirs': run.viewdirs[ray_id],
+    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id,
              'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
              'survivor_pts': run.saved['pts']}
-    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox})
+    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox,
+                              'viewdirs': lambda: run.viewdirs[ray_id]})     # per-sample gather only when somebody reads it
 
 
 def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kwargs):
@@ -956,13 +957,13 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
         mask[off[ray_id] + ex['rec_idx'].long()] = True
         return mask
 
-    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id, 'viewdirs': run.viewdirs[ray_id],
+    eager = {'alphainv_cum': alphainv_last, 'weights': weights, 'ray_id': ray_id,
              'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': ex['normal_marched'],
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
              'survivor_pts': run.saved['pts']}
-    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks})
+    return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks, 'viewdirs': lambda: run.viewdirs[ray_id]})
 
 
 def roofline_report():

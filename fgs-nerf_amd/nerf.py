@@ -463,7 +463,7 @@ class nerf(torch.nn.Module):
         if self.s_learn:
             return self.s_val.item()
         s_val = 1. / (global_step + self.s_ratio / self.s_start - self.step_start) * self.s_ratio
-        self.s_val.data = torch.ones_like(self.s_val) * s_val
+        self.s_val.data.fill_(s_val)      # model/nerf.py:520 `torch.ones_like(self.s_val) * s_val`: same value, one launch
         return s_val
 
     def neus_alpha_from_sdf_scatter(self, viewdirs, ray_id, dist, sdf, gradients, global_step, is_train, use_mid=True):
