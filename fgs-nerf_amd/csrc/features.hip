@@ -92,10 +92,13 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_fwd(SurvArgs S, const f
   if (row_ok && j < 3 * K) X0[m * S.L.ldx0 + S.L.off_hgrad + j] = g;
 }
 
-constexpr int BRICK = 8;  // voxels per side of the per-survivor accumulation brick: floor(centre) - 3 .. + 4
+constexpr int BRICK = 10;      // voxels per side of the accumulation brick of a group: floor(first centre) - 4 .. + 5
+constexpr int BRICK_LO = 4;
+constexpr int TAPS_GROUP = 4;  // consecutive survivors per 32-lane group: neighbours on a ray sit 0.5 voxel apart, so the
+                               // footprints of four of them (+/-2 voxel taps, +1 corner) fit the brick of the first
 
-// trilinear scatter of `go` into the LDS brick (origin bx0,by0,bz0); a corner outside the brick (cannot happen for
-// displacements <= 2 voxels, kept for safety) goes straight to global memory
+// trilinear scatter of `go` into the LDS brick (origin bx0,by0,bz0); a corner outside the brick (a survivor of the group
+// that belongs to the next ray) goes straight to global memory
 __device__ __forceinline__ void brick_scatter(float *brick, int bx0, int by0, int bz0, float *__restrict__ grid,
                                               const GridDesc &d, const TriCorners &t, float go) {
 #pragma unroll
@@ -112,89 +115,95 @@ __device__ __forceinline__ void brick_scatter(float *brick, int bx0, int by0, in
 
 // Scatter of every sdf.grad contribution of the survivors: hierarchical taps (dX0 columns) plus, when tot_sdf /
 // tot_grad are given, the centre lookup and +/-1 taps whose gradients k_march_fine_bwd accumulated per survivor.
+// 32 lanes walk TAPS_GROUP consecutive survivors and sum everything they add to sdf.grad in one LDS brick, flushed
+// row-wise.  Memory-side float atomics are priced per 64-byte line per wave-instruction (MI355X_MICROARCH.md, global
+// float atomics): the ~30 trilinear footprints of one survivor (24 hierarchical taps, the centre lookup and its six
+// +/-1 taps) overlap heavily, and so do those of its neighbours on the ray -- ~250 line requests per survivor become
+// ~30 with a brick per survivor and ~12 with a brick per four.  (Timing, 50 K survivors: 103 us either way -- the kernel
+// is bound by the LDS float atomics of the 24 tap footprints, 55 us of it, not by the memory-side ones; removing the
+// flush entirely saves 3 us.)
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const float *__restrict__ X0,
                                                              const float *__restrict__ dX0,
                                                              const float *__restrict__ tot_sdf,
                                                              const float *__restrict__ tot_grad,
                                                              float *__restrict__ sdf_grad_grid) {
-  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
+  const int64_t m_first = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5) * TAPS_GROUP;
   const int j = threadIdx.x & 31;
   const int K = S.L.K;
-  const bool row_ok = m < S.M;
   const GridDesc gd = fgs_sdf_desc(S.geom);
-  const bool tap_lane = row_ok && j < 6 * K;
-  float f = 0.f, cl = 0.f, d_f = 0.f;
-  TapPoint tp = {0.f, 0.f, 0.f, 0.f};
-  if (tap_lane) {
-    const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
-    tp = fgs_tap_point(p, gd, j / K, S.L.disp[j % K]);
-    f = X0[m * S.L.ldx0 + S.L.off_feat + j];  // saved forward value
-    cl = tp.clamped;
-    d_f = dX0[m * S.L.ldx0 + S.L.off_feat + j];
-  }
-  // lanes j < 3K: gradient of the (optionally normalised) finite difference w.r.t. the raw difference
-  const int a = (j < 3 * K) ? j / K : 0, k = (j < 3 * K) ? j % K : 0;
-  const float fp = group_shfl(f, (2 * a + 1) * K + k), fm = group_shfl(f, (2 * a) * K + k);
-  const float cp = group_shfl(cl, (2 * a + 1) * K + k), cm = group_shfl(cl, (2 * a) * K + k);
-  const float diff = cp - cm;
-  const float g_raw = ((fp - fm) / diff) / S.geom.voxel_size;
-  float dy = (row_ok && j < 3 * K) ? dX0[m * S.L.ldx0 + S.L.off_hgrad + j] : 0.f;
-  float dg = dy;
-  if (S.L.use_grad_norm) {
-    const float g0 = group_shfl(g_raw, k), g1 = group_shfl(g_raw, K + k), g2 = group_shfl(g_raw, 2 * K + k);
-    const float y0 = group_shfl(dy, k), y1 = group_shfl(dy, K + k), y2 = group_shfl(dy, 2 * K + k);
-    const float r = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
-    const float dot = (y0 * g0 + y1 * g1) + y2 * g2;
-    dg = dy / (r + 1e-5f);
-    if (r > 0.f) dg -= dot / (r * (r + 1e-5f) * (r + 1e-5f)) * g_raw;
-  }
-  const float coef = (j < 3 * K && K > 0) ? (dg / S.geom.voxel_size) / diff : 0.f;
-  // back to the tap lanes: tap (pair, k) takes +/- coef of axis pair>>1
-  const int pair = (j < 6 * K) ? j / K : 0, kk = (j < 6 * K) ? j % K : 0;
-  const float c_axis = group_shfl(coef, (pair >> 1) * K + kk);
-
-  // ---- combine everything this survivor adds to sdf.grad in an 8x8x8 LDS brick, then flush row-wise ----------------
-  // Memory-side float atomics are priced per 64-byte line per wave-instruction (MI355X_MICROARCH.md, global float
-  // atomics): the ~30 trilinear footprints of one survivor (24 hierarchical taps, the centre lookup and its six
-  // +/-1 taps) overlap heavily, so they are summed on chip and leave as ~30 line requests instead of ~250.
-  __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
   float *brick = brick_all[threadIdx.x >> 5];
   int bx0 = 0, by0 = 0, bz0 = 0;
-  PointIdx pc = {0.f, 0.f, 0.f};
-  if (row_ok) {
-    pc = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
-    bx0 = (int)fgs_safe_floor(pc.fx) - 3;
-    by0 = (int)fgs_safe_floor(pc.fy) - 3;
-    bz0 = (int)fgs_safe_floor(pc.fz) - 3;
+  if (m_first < S.M) {
+    const PointIdx p0 = fgs_point_to_index(S.pts[3 * m_first], S.pts[3 * m_first + 1], S.pts[3 * m_first + 2], S.geom.lo,
+                                           S.geom.hi, gd);
+    bx0 = (int)fgs_safe_floor(p0.fx) - BRICK_LO;
+    by0 = (int)fgs_safe_floor(p0.fy) - BRICK_LO;
+    bz0 = (int)fgs_safe_floor(p0.fz) - BRICK_LO;
   }
   for (int e = j; e < BRICK * BRICK * BRICK; e += 32) brick[e] = 0.f;
   __syncthreads();
-  if (tap_lane) {
-    const float total = d_f + ((pair & 1) ? c_axis : -c_axis);
-    if (total != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tp.fx, tp.fy, tp.fz), total);
-  }
-  if (row_ok && tot_sdf && j >= 24 && j < 31) {
-    // lane 24: centre lookup (d sdf); lanes 25..30: the six +/-1 voxel taps of the finite-difference gradient
-    if (j == 24) {
-      const float g = tot_sdf[m];
-      if (g != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(pc.fx, pc.fy, pc.fz), g);
-    } else {
-      const int pr = j - 25, ax = pr >> 1;                       // ax: 0 -> z, 1 -> y, 2 -> x
-      const float dgax = tot_grad[3 * m + (2 - ax)];
-      if (dgax != 0.f) {
-        const TapPoint tm = fgs_tap_point(pc, gd, 2 * ax, 1.0f), tq = fgs_tap_point(pc, gd, 2 * ax + 1, 1.0f);
-        const float cf = (dgax / S.geom.voxel_size) / (tq.clamped - tm.clamped);
-        const TapPoint &tt = (pr & 1) ? tq : tm;
-        brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tt.fx, tt.fy, tt.fz), (pr & 1) ? cf : -cf);
+  for (int gi = 0; gi < TAPS_GROUP; ++gi) {
+    const int64_t m = m_first + gi;
+    const bool row_ok = m < S.M;
+    const bool tap_lane = row_ok && j < 6 * K;
+    float f = 0.f, cl = 0.f, d_f = 0.f;
+    TapPoint tp = {0.f, 0.f, 0.f, 0.f};
+    PointIdx pc = {0.f, 0.f, 0.f};
+    if (row_ok) pc = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, gd);
+    if (tap_lane) {
+      tp = fgs_tap_point(pc, gd, j / K, S.L.disp[j % K]);
+      f = X0[m * S.L.ldx0 + S.L.off_feat + j];  // saved forward value
+      cl = tp.clamped;
+      d_f = dX0[m * S.L.ldx0 + S.L.off_feat + j];
+    }
+    // lanes j < 3K: gradient of the (optionally normalised) finite difference w.r.t. the raw difference
+    const int a = (j < 3 * K) ? j / K : 0, k = (j < 3 * K) ? j % K : 0;
+    const float fp = group_shfl(f, (2 * a + 1) * K + k), fm = group_shfl(f, (2 * a) * K + k);
+    const float cp = group_shfl(cl, (2 * a + 1) * K + k), cm = group_shfl(cl, (2 * a) * K + k);
+    const float diff = cp - cm;
+    const float g_raw = ((fp - fm) / diff) / S.geom.voxel_size;
+    float dy = (row_ok && j < 3 * K) ? dX0[m * S.L.ldx0 + S.L.off_hgrad + j] : 0.f;
+    float dg = dy;
+    if (S.L.use_grad_norm) {
+      const float g0 = group_shfl(g_raw, k), g1 = group_shfl(g_raw, K + k), g2 = group_shfl(g_raw, 2 * K + k);
+      const float y0 = group_shfl(dy, k), y1 = group_shfl(dy, K + k), y2 = group_shfl(dy, 2 * K + k);
+      const float r = sqrtf((g0 * g0 + g1 * g1) + g2 * g2);
+      const float dot = (y0 * g0 + y1 * g1) + y2 * g2;
+      dg = dy / (r + 1e-5f);
+      if (r > 0.f) dg -= dot / (r * (r + 1e-5f) * (r + 1e-5f)) * g_raw;
+    }
+    const float coef = (j < 3 * K && K > 0) ? (dg / S.geom.voxel_size) / diff : 0.f;
+    // back to the tap lanes: tap (pair, k) takes +/- coef of axis pair>>1
+    const int pair = (j < 6 * K) ? j / K : 0, kk = (j < 6 * K) ? j % K : 0;
+    const float c_axis = group_shfl(coef, (pair >> 1) * K + kk);
+    if (tap_lane) {
+      const float total = d_f + ((pair & 1) ? c_axis : -c_axis);
+      if (total != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tp.fx, tp.fy, tp.fz), total);
+    }
+    if (row_ok && tot_sdf && j >= 24 && j < 31) {
+      // lane 24: centre lookup (d sdf); lanes 25..30: the six +/-1 voxel taps of the finite-difference gradient
+      if (j == 24) {
+        const float g = tot_sdf[m];
+        if (g != 0.f) brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(pc.fx, pc.fy, pc.fz), g);
+      } else {
+        const int pr = j - 25, ax = pr >> 1;                       // ax: 0 -> z, 1 -> y, 2 -> x
+        const float dgax = tot_grad[3 * m + (2 - ax)];
+        if (dgax != 0.f) {
+          const TapPoint tm = fgs_tap_point(pc, gd, 2 * ax, 1.0f), tq = fgs_tap_point(pc, gd, 2 * ax + 1, 1.0f);
+          const float cf = (dgax / S.geom.voxel_size) / (tq.clamped - tm.clamped);
+          const TapPoint &tt = (pr & 1) ? tq : tm;
+          brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tt.fx, tt.fy, tt.fz), (pr & 1) ? cf : -cf);
+        }
       }
     }
   }
   __syncthreads();
-  if (row_ok) {
-    for (int e = j; e < BRICK * BRICK * BRICK; e += 32) {  // 8 consecutive lanes = 8 consecutive z of one (x,y) row
+  if (m_first < S.M) {
+    for (int e = j; e < BRICK * BRICK * BRICK; e += 32) {  // consecutive lanes = consecutive z of one (x,y) row
       const float v = brick[e];
       if (v == 0.f) continue;
-      const int x = bx0 + (e >> 6), y = by0 + ((e >> 3) & 7), z = bz0 + (e & 7);
+      const int x = bx0 + e / (BRICK * BRICK), y = by0 + (e / BRICK) % BRICK, z = bz0 + e % BRICK;
       atomicAdd(sdf_grad_grid + (int64_t)x * gd.sX + (int64_t)y * gd.sY + z, v);  // nonzero entries are in-volume
     }
   }
@@ -718,7 +727,7 @@ FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_m
   S.M = M; S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
-  hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
+  hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks((M + TAPS_GROUP - 1) / TAPS_GROUP * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
                      tot_grad, sdf_grad_grid);
   FGS_LAUNCH_OK("fgs_sdf_scatter_surv");
   return 0;
