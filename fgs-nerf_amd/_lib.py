@@ -64,7 +64,7 @@ _SIGNATURES = {
     "fgs_feat_fine_bwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64,
                           P, P, P],
     "fgs_head_fwd": [P, I64, I32, I64, P, P, P, P],
-    "fgs_head_bwd": [P, I64, I32, I64, P, P, P, P, P, P, P],
+    "fgs_head_bwd": [P, I64, I32, I64, P, P, P, P, P, P, P, P],
     "fgs_composite_fwd": [I64, P, P, P, P, P, F32, F32, P, P, P, P, P, P, P],
     "fgs_composite_bwd": [I64, P, P, P, P, P, P, P, P, P, F32, P, P, P],
     "fgs_smooth3d_fwd": [P, I32, I32, I32, I32, P, P, P],
@@ -95,7 +95,7 @@ class FgsError(RuntimeError):
 def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
-                                          "fgs_mc_num_blocks"])
+                                          "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats"])
 
 
 def lib() -> ctypes.CDLL:
@@ -115,6 +115,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_version.restype = c_int
         handle.fgs_gemm_workspace_bytes.restype = c_int64
         handle.fgs_gemm_workspace_bytes.argtypes = []
+        handle.fgs_head_bwd_scratch_floats.restype = c_int64
+        handle.fgs_head_bwd_scratch_floats.argtypes = [c_int]
         handle.fgs_mc_num_blocks.restype = c_int64
         handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -391,7 +391,8 @@ constexpr int HEAD_ILP = 4;
 __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
                                                         const float *__restrict__ V, const float *__restrict__ d_out,
                                                         float *__restrict__ dR, float *__restrict__ dV,
-                                                        float *__restrict__ dbias, float *__restrict__ dR_colsum) {
+                                                        float *__restrict__ dbias, float *__restrict__ dR_colsum,
+                                                        float *__restrict__ scratch /* [gridDim.x][4W + 4] or null */) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
@@ -454,14 +455,56 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict_
   __syncthreads();
   // consecutive threads finish consecutive output elements: one atomic wave-instruction covers 4 cache lines, not 16
   // (memory-side float atomics are priced per 64-byte line, and every block hits the same 4W floats)
-  (void)wv;
+  float *part = scratch ? scratch + (int64_t)blockIdx.x * (4 * W + 4) : nullptr;
   for (int idx = threadIdx.x; idx < 4 * W; idx += FGS_BLOCK) {
     const int c = idx / W, col = idx - c * W, v = 4 * c + (col & 3), l = col >> 2;
     const float s = (red[0][v][l] + red[1][v][l]) + (red[2][v][l] + red[3][v][l]);
-    if (c < 3) atomicAdd(dV + idx, s);
+    if (part) part[idx] = s;                    // two-stage form: k_head_bwd_reduce sums the per-block partials
+    else if (c < 3) atomicAdd(dV + idx, s);
     else if (dR_colsum) atomicAdd(dR_colsum + col, s);
   }
-  if (lane < 3) atomicAdd(dbias + lane, bsum[lane]);  // every lane of the wave walked the same rows
+  // every lane of a wave walked the same rows: lane l < 3 holds the wave's sum of d_out[:, l]
+  if (part) {
+    __shared__ float bred[FGS_BLOCK / FGS_WAVE][3];
+    if (lane < 3) bred[wv][lane] = bsum[lane];
+    __syncthreads();
+    if (threadIdx.x < 3) part[4 * W + threadIdx.x] = (bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+  } else if (lane < 3) {
+    atomicAdd(dbias + lane, bsum[lane]);
+  }
+}
+
+// second stage: element e of (dV [3W] | dR_colsum [W] | dbias [3]) += sum over blocks of scratch[b][e].  Workgroup =
+// 64 elements x 4 slices of the partial rows, grid.y = 8 more slices: a thread sums n_blocks / 32 partials (4 loads in
+// flight), the 4 slices meet in LDS, and the 8 workgroups of an element finish with one atomic each.  With atomics in
+// the first stage instead, 1024 blocks x 4W floats land on the same 64 cache lines and the memory-side atomic units
+// serialise them: 62 us for a pass that moves 100 MB.
+__global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd_reduce(const float *__restrict__ scratch, int n_blocks, int W,
+                                                               float *__restrict__ dV, float *__restrict__ dbias,
+                                                               float *__restrict__ dR_colsum) {
+  __shared__ float red[4][64];
+  const int le = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + le;
+  const int n_el = 4 * W + 3, ld = 4 * W + 4;
+  const int slice = blockIdx.y * 4 + sub, n_slices = gridDim.y * 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n_el) {
+    int b = slice;
+    for (; b + 3 * n_slices < n_blocks; b += 4 * n_slices) {
+      s0 += scratch[(int64_t)b * ld + e];
+      s1 += scratch[(int64_t)(b + n_slices) * ld + e];
+      s2 += scratch[(int64_t)(b + 2 * n_slices) * ld + e];
+      s3 += scratch[(int64_t)(b + 3 * n_slices) * ld + e];
+    }
+    for (; b < n_blocks; b += n_slices) s0 += scratch[(int64_t)b * ld + e];
+  }
+  red[sub][le] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub != 0 || e >= n_el) return;
+  const float s = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
+  if (e < 3 * W) atomicAdd(dV + e, s);
+  else if (e < 4 * W) { if (dR_colsum) atomicAdd(dR_colsum + (e - 3 * W), s); }
+  else atomicAdd(dbias + (e - 4 * W), s);
 }
 
 // -------------------------------------------------------------------------------------------- per-ray compositing
@@ -746,8 +789,10 @@ FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const fl
   return 0;
 }
 
+FGS_API int64_t fgs_head_bwd_scratch_floats(int W) { return (int64_t)1024 * (4 * (int64_t)W + 4); }
+
 FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR,
-                         float *dV, float *dbias, float *dR_colsum, fgs_stream_t stream) {
+                         float *dV, float *dbias, float *dR_colsum, float *scratch, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && W > 0 && W <= 256 && (W & 3) == 0 && (ldr & 3) == 0, FGS_E_RANGE,
               "fgs_head_bwd: M=%lld W=%d ldr=%lld", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
@@ -755,10 +800,16 @@ FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const fl
   // >= 16 rows per wave, at most 4 blocks per CU: every block ends with ~4W atomics on the same few cache lines
   const int64_t want = (M + 63) / 64;
   static const int64_t cap = getenv("FGS_HEAD_BLOCKS") ? atoll(getenv("FGS_HEAD_BLOCKS")) : 1024;
-  const unsigned blocks = (unsigned)(want < cap ? want : cap);
+  unsigned blocks = (unsigned)(want < cap ? want : cap);
+  if (scratch && blocks > 1024) blocks = 1024;      // fgs_head_bwd_scratch_floats() sizes the scratch for 1024 blocks
   hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
-                     dR_colsum);
+                     dR_colsum, scratch);
   FGS_LAUNCH_OK("fgs_head_bwd");
+  if (scratch) {
+    hipLaunchKernelGGL(k_head_bwd_reduce, dim3((4 * W + 3 + 63) / 64, 8), dim3(FGS_BLOCK), 0, fgs_s(stream), scratch,
+                       (int)blocks, W, dV, dbias, dR_colsum);
+    FGS_LAUNCH_OK("fgs_head_bwd (reduce)");
+  }
   return 0;
 }
 

@@ -319,6 +319,12 @@ def _zeros_like_strided(t):
     return torch.empty_strided(t.shape, t.stride(), dtype=F32, device=t.device).zero_()
 
 
+def _head_scratch(width, dev):
+    """Per-workgroup partial sums of fgs_head_bwd (4 MB at width 256); uninitialised, consumed inside the same call."""
+    from ._lib import lib
+    return torch.empty(int(lib().fgs_head_bwd_scratch_floats(int(width))), dtype=F32, device=dev)
+
+
 class _FusedFine(torch.autograd.Function):
     """inputs: sdf grid, k0 grid, then (weight, bias) of every rgbnet and refnet Linear; `run` carries the rest."""
 
@@ -508,7 +514,7 @@ class _FusedFine(torch.autograd.Function):
         dY = torch.empty(M, fw, dtype=F32, device=dev)
         gw_last, gb_last, gb_prev = view(i_gw_ref + n_ref - 1), view(i_gb_ref + n_ref - 1), view(i_gb_ref + n_ref - 2)
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_last),
-             ptr(gb_last), ptr(gb_prev), st)
+             ptr(gb_last), ptr(gb_prev), ptr(_head_scratch(fw, dev)), st)
         views = [view(i) for i in range(len(items))]
         gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
         gb_rgb = views[i_gb_rgb:i_gb_rgb + n_rgb]
@@ -729,7 +735,7 @@ class _FusedCoarse(torch.autograd.Function):
         a_last = acts[n_ref - 1]
         dY = torch.empty(M, fw, dtype=F32, device=dev)
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
-             ptr(gb[-1]), ptr(gb[n_ref - 2]), st)
+             ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), st)
         dX0 = None
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
         for i in range(n_ref - 2, -1, -1):

@@ -340,9 +340,12 @@ int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts, const 
 int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *bias, float *rgb,
                  fgs_stream_t stream);
 /* d_out [M,3] (w.r.t. the pre-sigmoid output) -> dR = (d_out . V) * (R > 0), dV += d_out^T R, dbias += colsum(d_out),
- * dR_colsum[W] += colsum(dR) (the bias gradient of the layer that produced R; may be NULL). */
+ * dR_colsum[W] += colsum(dR) (the bias gradient of the layer that produced R; may be NULL).
+ * `scratch`: fgs_head_bwd_scratch_floats(W) floats (uninitialised) -> per-workgroup partial sums + a second, atomic-free
+ * reduction launch; NULL -> the sums go out as float atomics (1024 workgroups on the same 64 cache lines). */
 int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR, float *dV,
-                 float *dbias, float *dR_colsum, fgs_stream_t stream);
+                 float *dbias, float *dR_colsum, float *scratch, fgs_stream_t stream);
+int64_t fgs_head_bwd_scratch_floats(int W);
 
 /* The three segment_coo sums + background + clamp (model/nerf.py:888-903), optional normal_marched / depth
  * (:905-920).  pre_rgb / pre_sig keep the un-clamped values for the backward pass. */
