@@ -329,13 +329,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 // Backward of one Linear layer in ONE launch: the data-gradient product (NN, store epilogue with ReLU mask / column sums)
 // and the weight-gradient product (TN, split-K atomics) both depend only on dY.  Launched separately each pays its own
 // launch gap, first-chunk latency and partially filled last round of tiles (780 tiles on 512 slots = 1.52 rounds for the
-// price of 2); launched together the split-K workgroups of the weight gradient, dealt after the data-gradient tiles,
-// fill that round.
-__global__ __launch_bounds__(256, 2) void k_linear_bwd(GemmArgs nn, GemmArgs tn, int nn_blocks) {
+// price of 2); launched together the split-K workgroups of the weight gradient and the data-gradient tiles share the
+// rounds.
+//
+// Order and slice length matter (measured per layer at M = 49 920, 780 data tiles of ~43 us on 512 resident slots):
+//   data tiles first, then 512 equal slices (13 chunks, ~65 us each)        179 us -- the slices start in rounds 2 and 3
+//   192 long slices FIRST (33 chunks, ~145 us), the data tiles behind them   166 us -- the long workgroups start at t = 0
+//     and the short data tiles pack into the other 320 slots (2.4 rounds); 160..224 slices are within 3 us of each other
+//   one persistent workgroup per slot with its data tiles and a slice sized to even out the finish times: 170 us.
+__global__ __launch_bounds__(256, 2) void k_linear_bwd(GemmArgs nn, GemmArgs tn, int nn_blocks, int tn_blocks, int tn_first) {
   __shared__ __attribute__((aligned(16))) LdsImage lds;
   const int b = (int)blockIdx.x;
-  if (b < nn_blocks) gemm_block<true, false, EPI_STORE>(nn, b, lds);
-  else gemm_block<false, false, EPI_ATOMIC>(tn, b - nn_blocks, lds);
+  if (tn_first) {
+    if (b < tn_blocks) gemm_block<false, false, EPI_ATOMIC>(tn, b, lds);
+    else gemm_block<true, false, EPI_STORE>(nn, b - tn_blocks, lds);
+  } else {
+    if (b < nn_blocks) gemm_block<true, false, EPI_STORE>(nn, b, lds);
+    else gemm_block<false, false, EPI_ATOMIC>(tn, b - nn_blocks, lds);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -460,9 +471,10 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // split the long reduction of a weight-gradient product so that ~2 workgroups per CU are in flight; returns the splits
 // (measured on MI355X at M_s = 64 K, 256x256 outputs: 256-512 workgroups 96 us, 128: 159 us, 2048: 147 us)
-unsigned setup_splitk(GemmArgs &g) {
+unsigned setup_splitk(GemmArgs &g, int default_wgs = 512) {
   const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n;
-  static const int target_wgs = getenv("FGS_TN_WGS") ? atoi(getenv("FGS_TN_WGS")) : 512;
+  static const int env_wgs = getenv("FGS_TN_WGS") ? atoi(getenv("FGS_TN_WGS")) : 0;
+  const int target_wgs = env_wgs > 0 ? env_wgs : default_wgs;
   int64_t want = (target_wgs + tiles - 1) / tiles;
   const int64_t chunks = (g.K + BK - 1) / BK;
   if (want > chunks) want = chunks;
@@ -555,10 +567,19 @@ FGS_API int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const flo
               FGS_E_INVALID, "fgs_linear_bwd_f32: operands must be 16-byte aligned; sizes and leading dimensions multiples of 4");
   GemmArgs nn = make_args(M, K_in, N_out, dY, lddy, W, ldw, dX, lddx, nullptr, 0, mask, ldm, colsum);
   GemmArgs tn = make_args(N_out, K_in, M, dY, lddy, X, ldx, dW, lddw, nullptr, 0, nullptr, 0, nullptr);
-  const unsigned splits = setup_splitk(tn);
+  static const int tn_first = getenv("FGS_TN_FIRST") ? atoi(getenv("FGS_TN_FIRST")) : 1;
+  // weight-gradient slices: 192 long ones dispatched first (see k_linear_bwd); 512 short ones when they come last
+  unsigned splits = setup_splitk(tn, tn_first ? 192 : 512);
+  const unsigned tn_tiles = (unsigned)(tn.tiles_m * tn.tiles_n);
+  if (tn_first && ((tn_tiles * splits) & 7u)) {   // keep the data tiles' XCD-aware numbering: a multiple of 8 in front
+    while ((tn_tiles * splits) & 7u) ++splits;
+    const int64_t chunks = (tn.K + BK - 1) / BK;
+    tn.k_per_split = ((chunks + splits - 1) / splits) * BK;
+  }
   const unsigned nn_blocks = (unsigned)((nn.tiles_m + 7) / 8) * 8 * (unsigned)nn.tiles_n;
-  const unsigned tn_blocks = (unsigned)(tn.tiles_m * tn.tiles_n) * splits;
-  hipLaunchKernelGGL(k_linear_bwd, dim3(nn_blocks + tn_blocks), dim3(256), 0, fgs_s(stream), nn, tn, (int)nn_blocks);
+  const unsigned tn_blocks = tn_tiles * splits;
+  hipLaunchKernelGGL(k_linear_bwd, dim3(nn_blocks + tn_blocks), dim3(256), 0, fgs_s(stream), nn, tn, (int)nn_blocks,
+                     (int)tn_blocks, tn_first);
   FGS_LAUNCH_OK("fgs_linear_bwd_f32");
   return 0;
 }
