@@ -179,3 +179,18 @@ def test_two_ranks_on_one_gpu_match_a_dense_all_reduce(dev):
         assert worst2 < 1e-2, results                   # parameter updates of the step with the optimizer-side wait
         assert worst < 1e-6, results
         assert fill is not None and 0 < fill < 0.6, results
+
+
+@pytest.mark.parametrize("total", [0, 1, 1023, 1024, 1025, 5000, 64000])
+def test_brick_compact_matches_nonzero(dev, total):
+    """fgs_brick_compact (one workgroup per 1024-flag tile, offsets counted from the flags in front of the tile): ascending
+    indices of the set flags and their count, entirely on the device."""
+    from fgs_nerf_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(total)
+    flags = (torch.rand(max(total, 1), generator=g) < 0.18).to(torch.int32)[:total].to(dev)
+    idx = torch.full((max(total, 1),), -1, dtype=torch.int64, device=dev)
+    count = torch.full((1,), -7, dtype=torch.int64, device=dev)
+    call("fgs_brick_compact", ptr(flags) if total else None, total, ptr(idx) if total else None, ptr(count), stream())
+    ref = flags.nonzero(as_tuple=False).squeeze(1)
+    assert int(count) == ref.numel()
+    assert torch.equal(idx[:ref.numel()], ref)
