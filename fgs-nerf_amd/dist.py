@@ -20,6 +20,7 @@ What is exchanged (160^3: k0.grad 197 MB, sdf.grad 16 MB, MLP grads 1.7 MB; 320^
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -240,7 +241,11 @@ class GradAverager:
         if not tensor.is_cuda:
             return
         if st['stream'] is None:
-            st['stream'] = torch.cuda.Stream(device=tensor.device)
+            # high priority: HIP maps streams onto a few hardware queues, and a second normal-priority stream can land on
+            # the queue of the main stream, where its kernels serialise with the backward pass (seen in a kernel trace:
+            # gather / reduce / scatter of the k0 exchange sitting between the scatter kernels of the main stream)
+            prio = int(os.environ.get("FGS_DIST_STREAM_PRIORITY", "-1"))
+            st['stream'] = torch.cuda.Stream(device=tensor.device, priority=prio)
         ready = torch.cuda.Event()
         ready.record()
         with torch.no_grad(), torch.cuda.stream(st['stream']):
