@@ -134,6 +134,9 @@ def main():
     torch.cuda.set_device(dev)
     force_dist = world == 1 and os.environ.get("FGS_FORCE_DIST") == "1"   # rehearse the RCCL exchange on one GPU
     if world > 1 or force_dist:
+        # RCCL's internal streams on their own (high-priority) hardware queues: HIP maps streams onto a few queues, and a
+        # collective that lands on the queue of the compute stream would hold up the kernels behind it
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
