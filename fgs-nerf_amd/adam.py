@@ -39,6 +39,8 @@ class MaskedAdam(torch.optim.Optimizer):
                 raise ValueError(what)
         self.per_lr = None
         self.before_param = None      # optional callable(param), invoked right before a parameter is updated (dist.py)
+        self._early = {}              # id(param) -> event of an update already applied by early_update() in this step
+        self._early_stream = None
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def set_pervoxel_lr(self, count):
@@ -65,15 +67,61 @@ class MaskedAdam(torch.optim.Optimizer):
         masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
         call("fgs_adam_upd_multi", n, *tables, sizes, steps, lrs, masked, float(b1), float(b2), float(eps), stream())
 
+    def _update_one(self, p, g, group):
+        """The reference's per-tensor rule (model/adam.py:205-221) for one big tensor."""
+        b1, b2 = group['betas']
+        hyper = (b1, b2, group['lr'], group['eps'])
+        st = self._state_of(p)
+        st['step'] += 1
+        g = _as_layout_of(g, p)
+        m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
+        if self.per_lr is not None and p.shape == self.per_lr.shape:
+            adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
+        elif group['skip_zero_grad']:
+            adam_upd_cuda.masked_adam_upd(p, g, m, v, t, *hyper)
+        else:
+            adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
+
+    @torch.no_grad()
+    def early_update(self, p, grad, on_stream=None) -> bool:
+        """Apply this step's update of ONE parameter now, from inside the backward pass, as soon as its gradient is
+        final (fused.py calls this for the feature grid right after its scatter kernel): the update -- and, on several
+        GPUs, the gradient exchange in front of it -- then runs beside the rest of the backward pass instead of after
+        it.  `on_stream`: the stream the caller is already on (dist.GradAverager's exchange stream); otherwise a
+        high-priority stream of this optimizer, ordered after the caller's current stream.  `step()` skips the parameter
+        and ends by making the current stream wait for the update, so everything after `step()` sees the new values.
+        Only valid when nothing else adds to this parameter's gradient between backward and step (no TV on it)."""
+        group = next((gr for gr in self.param_groups if any(q is p for q in gr['params'])), None)
+        if group is None or not p.is_cuda or id(p) in self._early:
+            return False
+        if on_stream is not None:
+            self._update_one(p, grad, group)
+            done = torch.cuda.Event()
+            done.record()
+        else:
+            if self._early_stream is None:
+                self._early_stream = torch.cuda.Stream(device=p.device, priority=-1)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._early_stream):
+                self._early_stream.wait_event(ready)
+                self._update_one(p, grad, group)
+                done = torch.cuda.Event()
+                done.record()
+            grad.record_stream(self._early_stream)
+        self._early[id(p)] = done
+        return True
+
     @torch.no_grad()
     def step(self):
+        early, self._early = self._early, {}
         for group in self.param_groups:
             b1, b2 = group['betas']
             hyper = (b1, b2, group['lr'], group['eps'])
             masked = group['skip_zero_grad']
             small = []
             for p in group['params']:
-                if p.grad is None:
+                if p.grad is None or id(p) in early:    # already updated by early_update()
                     continue
                 if self.before_param is not None:       # dist.GradAverager.wait_for: this gradient's exchange is done
                     self.before_param(p)
@@ -90,3 +138,5 @@ class MaskedAdam(torch.optim.Optimizer):
                 else:
                     adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
             self._flush_small(small, b1, b2, group['eps'])
+        for done in early.values():                     # everything after step() sees the early updates
+            torch.cuda.current_stream().wait_event(done)

@@ -72,6 +72,8 @@ class GradAverager:
             ranks = dist.get_process_group_ranks(group) if group is not None else None
             self.early_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
         self._deferred = {}               # id(param) -> event of its early exchange, waited on by wait_for()
+        self.after_early = None           # callable(param, grad): runs on the exchange stream right after an early grid
+                                          # exchange (MaskedAdam.early_update through fused.enable_early_update)
         self.defer_to_optimizer = False   # set by attach_optimizer(): the optimizer waits per parameter, not average()
         self._bucket = None
         self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
@@ -260,13 +262,16 @@ class GradAverager:
             else:
                 dist.all_reduce(tensor, op=self._op(), group=self.early_group)
                 self._post_scale(tensor, inv)
+            updated = False
+            if kind == 'k0' and self.after_early is not None:
+                updated = bool(self.after_early(params[0], tensor))   # the optimizer's pass over k0, same stream
             done = torch.cuda.Event()
             done.record()
         tensor.record_stream(st['stream'])
         st['params'].update(id(p) for p in params)
         if kind == 'mlp':
             st['mlp_done'] = done                       # waited for by early('join') at the end of the backward pass
-        else:
+        elif not updated:                               # (an early update is waited for by optimizer.step() itself)
             for p in params:
                 self._deferred[id(p)] = done
 

@@ -574,6 +574,8 @@ class _FusedFine(torch.autograd.Function):
              ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)       # final: its exchange runs under the sdf scatter kernels below
+        elif run.cache.get('opt_hook') is not None:
+            run.cache['opt_hook'](k0_grid, grad_k0)   # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
         call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
@@ -766,6 +768,8 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(g_grad_s), st)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)
+        elif run.cache.get('opt_hook') is not None:
+            run.cache['opt_hook'](k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
         # it in place through element strides
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
@@ -801,6 +805,24 @@ def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tenso
         cache.clear()            # keep one shape resident
         cache[key] = ws
     return ws
+
+
+def enable_early_update(model, optimizer, averager=None) -> None:
+    """Let `optimizer` (MaskedAdam) update the feature grid from inside the fused backward pass, right after the grid's
+    gradient is final -- on several GPUs right after that gradient's exchange, on the exchange stream.  The ~45 us Adam
+    pass over k0 (and the wait for its exchange) then leave the end of the step.  Only for steps in which nothing else
+    writes into k0.grad (no TV on k0); `disable_early_update` turns it off again."""
+    cache = model.__dict__.setdefault('_fused_cache', {})
+    if averager is not None and (averager.world_size > 1 or averager.force):
+        averager.after_early = lambda p, g: optimizer.early_update(p, g, on_stream=True)
+    else:
+        cache['opt_hook'] = optimizer.early_update
+
+
+def disable_early_update(model, averager=None) -> None:
+    model.__dict__.setdefault('_fused_cache', {}).pop('opt_hook', None)
+    if averager is not None:
+        averager.after_early = None
 
 
 class LazyResult(dict):

@@ -130,6 +130,9 @@ def _two_rank_worker(rank, world, port, out_q):
         import bench
         opt, opt_twin = bench.make_optimizer(model), bench.make_optimizer(twin)
         avg.attach_optimizer(opt)
+        from fgs_nerf_amd import fused
+        fused.enable_early_update(model, opt, avg)       # k0's Adam pass right behind its exchange, on the exchange stream
+        assert avg.after_early is not None
         before, worst2 = [p.detach().clone() for p in model.parameters()], 0.0
         assert opt.before_param is not None and avg.defer_to_optimizer
         for m_ in (model, twin):
@@ -140,7 +143,7 @@ def _two_rank_worker(rank, world, port, out_q):
         fused_render_losses(res, target, synth.FINE_LOSS, model).backward()
         avg.average()
         opt.step()
-        assert not avg._deferred                                    # the optimizer consumed the pending k0 event
+        assert not avg._deferred and not opt._early                 # nothing left pending: k0 was updated early, step() waited
         fused_render_losses(twin(*rays, global_step=1000, **synth.RENDER_KWARGS), target, synth.FINE_LOSS, twin).backward()
         for p in twin.parameters():
             if p.grad is not None:

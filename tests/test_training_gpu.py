@@ -161,3 +161,33 @@ def test_training_reduces_the_loss_on_a_synthetic_scene(dev, stage):
     after = mse()
     assert after < 0.5 * before, (before, after)
     assert st.stats()['psnr'] > 0
+
+
+def test_early_update_of_the_feature_grid_matches_a_plain_step(dev):
+    """MaskedAdam.early_update (k0's Adam pass issued from inside the fused backward pass, on a side stream) against the
+    same step with the update in optimizer.step(): identical parameters and optimizer state afterwards."""
+    import bench
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    rays = tuple(t.to(dev) for t in synth.random_rays(600, seed=3))
+    target = torch.rand(600, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    outs = []
+    for early in (False, True):
+        model = synth.build_model(48, synth.FINE_MODEL, device=dev)
+        opt = bench.make_optimizer(model)
+        if early:
+            fused.enable_early_update(model, opt)
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            res = model(*rays, global_step=1000 + step, **synth.RENDER_KWARGS)
+            fused_render_losses(res, target, synth.FINE_LOSS, model).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        st = opt.state[model.k0.grid]
+        outs.append((model.k0.grid.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone(), st['step'],
+                     model.sdf.grid.detach().clone()))
+        assert not opt._early
+    # the scatter kernels' float atomics are order dependent: compare in norm (Adam's first steps amplify tiny gradients)
+    assert outs[0][3] == outs[1][3] == 3
+    for a, b in zip(outs[0][:3] + outs[0][4:], outs[1][:3] + outs[1][4:]):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-3
