@@ -203,6 +203,12 @@ class GradAverager:
             # stream then competes with the persistent MLP kernel and the step gets 0.09 ms slower, not faster)
             model.__dict__.setdefault('_fused_cache', {})['grad_hook'] = self.early
 
+    def rebind(self, params) -> None:
+        """The model replaced its parameters (scale_volume_grid builds new grids): average the new ones from now on."""
+        self.params = [p for p in params if p.requires_grad]
+        self._hints.clear()
+        self._deferred.clear()
+
     def attach_optimizer(self, optimizer) -> None:
         """Let the optimizer wait for an early exchange only when it reaches that parameter (MaskedAdam.before_param):
         the TV pass and the updates of the other parameters then run under the tail of the k0 exchange."""

@@ -123,9 +123,7 @@ class TrainStepper:
         self.rgb_tr, self.rays_o_tr, self.rays_d_tr, self.viewdirs_tr = rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr
         self.optimizer = optimizer or create_optimizer_or_freeze_model(model, self.cfg_train, global_step=0)
         self.averager = averager
-        if averager is not None:
-            averager.attach(model)
-            averager.attach_optimizer(self.optimizer)        # k0's exchange is waited for when the optimizer reaches k0
+        self._bind_averager()
         self.poses_train, self.near = poses_train, near
         if self.cfg_train.get('ray_sampler', 'flatten') not in ('flatten', 'in_maskcache', 'random'):
             raise NotImplementedError(self.cfg_train.ray_sampler)
@@ -158,6 +156,18 @@ class TrainStepper:
         return self.rgb_tr[sel], self.rays_o_tr[sel], self.rays_d_tr[sel], self.viewdirs_tr[sel]
 
     # ------------------------------------------------------------------------------------------------ one iteration
+    def _bind_averager(self) -> None:
+        """(Re)connect the gradient exchange to the model's CURRENT parameters and optimizer."""
+        av = self.averager
+        if av is None:
+            return
+        av.rebind(self.model.parameters())
+        av.attach(self.model)
+        av.attach_optimizer(self.optimizer)                  # k0's exchange is waited for when the optimizer reaches k0
+        if (av.world_size > 1 or av.force) and self.cfg_train.get('weight_tv_k0', 0) == 0 and hasattr(self.optimizer, 'early_update'):
+            from . import fused
+            fused.enable_early_update(self.model, self.optimizer, av)   # ... or applied right behind it (no TV on k0)
+
     def step(self, global_step: int) -> torch.Tensor:
         model, ct, opt = self.model, self.cfg_train, self.optimizer
         # progressive growing (:243-253)
@@ -168,6 +178,7 @@ class TrainStepper:
                 if self.cfg_model.get('maskout_near_cam_vox', False) and self.poses_train is not None:
                     model.maskout_near_cam_vox(self.poses_train[:, :3, 3], self.near)
             opt = self.optimizer = create_optimizer_or_freeze_model(model, ct, global_step=0)
+            self._bind_averager()                            # new grids, new optimizer
         target, rays_o, rays_d, viewdirs = self._select_rays()
         # voxel increment (:288-295)
         if ct.get('voxel_inc', False):
