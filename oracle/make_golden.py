@@ -194,8 +194,33 @@ def make_e2e():
         save(f"e2e_{stage}.npz", **out)
 
 
+def make_extras():
+    """Fixtures of the two rows outside the render path: the integrated directional encoding (restated generate_ide_fn,
+    float32, sh_max_level 4; its known answer against scipy's Y_l^m is checked in tests/test_ide.py) and marching cubes
+    (table-free restatement of the device convention, oracle/mcubes_ref.py, on a 12^3 off-centre sphere and a 7x8x9 noise
+    field).  Neither has a counterpart fixture in the reference (parity unpinned)."""
+    from oracle import mcubes_ref as R
+    SEED = 777
+    g = torch.Generator().manual_seed(SEED)
+    d = torch.randn(64, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    kinv = torch.rand(64, 1, generator=g) * 0.5
+    save("ide_deg4.npz", dirs=d, kappa_inv=kinv, ide=O.generate_ide_fn(4)(d, kinv))
+    ax = np.linspace(-1, 1, 12, dtype=np.float32)
+    x, y, z = np.meshgrid(ax, ax, ax, indexing='ij')
+    sphere = (np.sqrt((x - 0.1) ** 2 + (y + 0.05) ** 2 + z ** 2) - 0.55).astype(np.float32)
+    noise = np.random.default_rng(SEED).standard_normal((7, 8, 9)).astype(np.float32)
+    out = {}
+    for name, f, iso in (("sphere", sphere, 0.0), ("noise", noise, 0.2)):
+        v, t = R.marching_cubes(f, iso)
+        out.update({name + "_field": f, name + "_iso": np.float32(iso), name + "_vertices": v, name + "_triangles": t})
+    save("mcubes.npz", **out)
+
+
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"rays", "kernels", "trilerp", "e2e"}
+    what = set(sys.argv[1:]) or {"rays", "kernels", "trilerp", "e2e", "extras"}
+    if "extras" in what:
+        make_extras()
     if "rays" in what:
         make_rays()
     if "kernels" in what:

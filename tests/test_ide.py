@@ -72,3 +72,17 @@ def test_model_builds_the_encoder_like_the_reference(dev):
     model = synth.build_model(16, synth.FINE_MODEL, device=dev)
     enc = model.integrated_dir_enc(unit_dirs(10, 1).to(dev), torch.full((10, 1), 0.1, device=dev))
     assert enc.shape == (10, 38)                                           # sh_max_level = 4 -> 19 (m, l) pairs
+
+
+def test_restatement_matches_committed_fixture(oracle, golden):
+    g = golden("ide_deg4.npz")
+    out = oracle.generate_ide_fn(4)(torch.from_numpy(g["dirs"]), torch.from_numpy(g["kappa_inv"]))
+    assert rel_l2(out, g["ide"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_ide_hip_matches_committed_fixture(dev, golden):
+    from fgs_nerf_amd.ide import generate_ide_fn
+    g = golden("ide_deg4.npz")
+    out = generate_ide_fn(4)(torch.from_numpy(g["dirs"]).to(dev), torch.from_numpy(g["kappa_inv"]).to(dev))
+    assert rel_l2(out, g["ide"]) < 1e-5

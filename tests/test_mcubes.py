@@ -112,3 +112,20 @@ def test_extract_geometry_on_the_sdf_model(dev):
     assert np.abs(np.linalg.norm(verts, axis=1) - 0.6).max() < 2e-3
     rep = R.mesh_report(verts, tris)
     assert rep['closed_oriented'] and rep['euler'] == 2 and rep['signed_volume'] > 0      # outward for the object (-sdf field)
+
+
+@pytest.mark.gpu
+def test_device_marching_cubes_matches_committed_fixture(dev, golden):
+    """tests/golden/mcubes.npz (oracle/make_golden.py extras): vertices and triangles bit for bit."""
+    from fgs_nerf_amd.extract_geometry import marching_cubes
+    g = golden("mcubes.npz")
+    for name in ("sphere", "noise"):
+        v, t = marching_cubes(g[name + "_field"], float(g[name + "_iso"]))
+        assert np.array_equal(v, g[name + "_vertices"]) and np.array_equal(t, g[name + "_triangles"]), name
+
+
+def test_restatement_matches_committed_fixture(golden):
+    from oracle import mcubes_ref as R
+    g = golden("mcubes.npz")
+    v, t = R.marching_cubes(g["noise_field"], float(g["noise_iso"]))
+    assert np.array_equal(v, g["noise_vertices"]) and np.array_equal(t, g["noise_triangles"])
