@@ -338,13 +338,14 @@ class _FusedFine(torch.autograd.Function):
         ms = run.max_steps
         rec = N * ms
         ws = run.workspace
-        # 1. march
+        # 1. march (alphainv_last is an output of this call: a fresh tensor per step, the other records live in `ws`)
+        alphainv_last = torch.empty(N, dtype=F32, device=dev)
         call("fgs_march_fine_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, ptr(sdf_grid), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
              g.mask[3] if g.mask else 0.0, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']),
              ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']), ptr(ws['n_alive']),
-             ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
+             ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
         # everything that does not need the survivor count is issued BEFORE the host read, off the post-sync path:
         # first-layer weights are copied into K-padded operands (their row length is not a multiple of 4)
@@ -432,7 +433,6 @@ class _FusedFine(torch.autograd.Function):
         depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
         call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
-        alphainv_last = ws['alphainv_last'].clone()
         # The big zero fills of the backward pass are issued HERE: when loss.backward() starts, the autograd engine needs
         # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
         run.pre = None
@@ -630,13 +630,14 @@ class _FusedCoarse(torch.autograd.Function):
         sdf_smooth, gradvol = sdf_smooth.contiguous(), gradvol.contiguous()
         use_mc = run.mask_grid is not None
         inc = run.inc
+        alphainv_last = torch.empty(N, dtype=F32, device=dev)   # an output of the march: a fresh tensor per step
         call("fgs_march_coarse_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
              g.mask[3] if use_mc else 0.0, ptr(inc[0]) if inc else None, *(inc[1] if inc else (0, 0, 0)),
              inc[2] if inc else None, inc[3] if inc else None, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
-             ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(ws['alphainv_last']), st)
+             ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
         token = _count_begin(run, ws['surv_off'], N)
         n_ref = run.n_ref                           # queued behind the count copy: K-padded first-layer weights, k0.grad fill
@@ -686,7 +687,6 @@ class _FusedCoarse(torch.autograd.Function):
         depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
         call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
-        alphainv_last = ws['alphainv_last'].clone()
         run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
@@ -800,8 +800,7 @@ def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tenso
                   a_surv=torch.empty(rec, dtype=I32, device=dev), surv_slot=torch.empty(rec, dtype=I32, device=dev),
                   n_alive=torch.empty(n_rays, dtype=I64, device=dev), n_surv=torch.empty(n_rays, dtype=I64, device=dev),
                   n_inbbox=torch.empty(n_rays, dtype=I64, device=dev),
-                  surv_off=torch.empty(n_rays + 1, dtype=I64, device=dev),
-                  alphainv_last=torch.empty(n_rays, dtype=F32, device=dev))
+                  surv_off=torch.empty(n_rays + 1, dtype=I64, device=dev))
         cache.clear()            # keep one shape resident
         cache[key] = ws
     return ws
