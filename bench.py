@@ -103,7 +103,7 @@ def cpu_baseline(n_rays=1024, iters=3):
         pass
     return {"value": round(n_in / med / 1e6, 4), "unit": "M ray-samples/s", "cores": torch.get_num_threads(),
             "cpu_model": cpu_model,
-            "kind": "port", "sample": f"{n_rays} rays x {iters} fwd+bwd iterations of the same 160^3 workload "
+            "kind": "port", "sample": f"{n_rays} rays x {iters} fwd+bwd iterations of the same {GRID}^3 workload "
                                       f"({n_in} in-bbox samples/iter, median {med * 1e3:.0f} ms), torch CPU + C oracle"}
 
 
@@ -116,7 +116,10 @@ def main():
     ap.add_argument("--composed", action="store_true", help="operator-at-a-time HIP path instead of the fused kernels")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
+    ap.add_argument("--grid", type=int, default=GRID,
+                    help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
     args = ap.parse_args()
+    globals()["GRID"] = args.grid
 
     # host side of this path is one Python thread + the autograd thread; the box grants a 16-CPU quota per GPU and
     # torch would otherwise spawn one OpenMP worker per visible core (256) for the synthetic-scene setup
@@ -212,12 +215,12 @@ def main():
         elapsed, samples = float(tmax.item()), float(ssum.item())
     if rank == 0:
         line = {
-            "metric": "M ray-samples/sec (fwd+bwd), 160^3 grid, 4096-ray batch",
+            "metric": f"M ray-samples/sec (fwd+bwd), {GRID}^3 grid, 4096-ray batch",
             "value": round(samples / elapsed / 1e6, 3), "unit": "M ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 160^3 sdf(1ch)+k0(12ch) fine-stage training step "
+            "config": {"workload": (f"configs[1]: {GRID}^3 sdf(1ch)+k0(12ch) fine-stage training step "
                                     "(forward_fine + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step")
                        if args.stage == "fine" else
                        ("configs[2] path at the bench size: 160^3 coarse-stage training step (5^3 smoothing + gradient "
