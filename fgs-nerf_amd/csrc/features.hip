@@ -34,12 +34,19 @@ struct SurvArgs {
   FeatLayout L;
 };
 
+// thread id -> survivor index for the (survivor, channel) kernels: a 32-bit division whenever M * C fits (always, in
+// practice); the 64-bit one is emulated and costs more than the rest of the index arithmetic together
+__device__ __forceinline__ int64_t surv_of(int64_t tid, int64_t M, int64_t C) {
+  if (M * C < ((int64_t)1 << 32)) return (int64_t)((unsigned)tid / (unsigned)C);
+  return tid / C;
+}
+
 // ---------------------------------------------------------------------------------------------- k0 lookup
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const float *__restrict__ k0, GridDesc kd,
                                                            float *__restrict__ X0) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
-  const int64_t m = tid / kd.C, c = tid - m * kd.C;
+  const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
   const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
   X0[m * S.L.ldx0 + S.L.off_k0 + c] = fgs_tri_sample(k0, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz));
 }
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__
                                                            const float *__restrict__ dX0) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
-  const int64_t m = tid / kd.C, c = tid - m * kd.C;
+  const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
   const float g = dX0[m * S.L.ldx0 + S.L.off_k0 + c];
   if (g == 0.f) return;
   const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
