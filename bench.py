@@ -173,6 +173,18 @@ def main():
         batches.append(batch)
     del out
 
+    # Setup, not a step: one forward + backward (no optimizer update) over every resident batch, so that PyTorch's caching
+    # allocator already owns blocks for the largest survivor count.  The batches differ in that count (50-64 K rows of
+    # every activation) and --warmup may be shorter than the batch cycle; a first-time hipMalloc inside the timed region
+    # would cost milliseconds.  (The remaining run-to-run spread, 2.32-2.56 ms/step on a noisy box, is host jitter: the
+    # Python launch path needs ~2 ms of CPU per 2.3 ms step.)
+    from fgs_nerf_amd.losses import fused_render_losses
+    for b in batches:
+        res = model(b[0], b[1], b[2], global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
+        fused_render_losses(res, b[3], synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model).backward()
+        opt.zero_grad(set_to_none=True)
+        del res
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
     torch.cuda.synchronize()
