@@ -141,8 +141,9 @@ def ptr(t):
 
 
 def stream() -> int:
-    """PyTorch-ROCm's current HIP stream as an integer handle."""
-    return torch.cuda.current_stream().cuda_stream
+    """PyTorch-ROCm's current HIP stream as an integer handle (the raw accessor: ~0.5 us instead of the ~13 us of
+    torch.cuda.current_stream(), and the step asks a dozen times)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def check_input(x: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
