@@ -179,7 +179,7 @@ def main():
     # would cost milliseconds.  (The remaining run-to-run spread, 2.32-2.56 ms/step on a noisy box, is host jitter: the
     # Python launch path needs ~2 ms of CPU per 2.3 ms step.)
     from fgs_nerf_amd.losses import fused_render_losses
-    for b in batches:
+    for b in (batches if args.warmup < N_BATCHES else []):     # a warm-up that covers the batch cycle needs no priming
         res = model(b[0], b[1], b[2], global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
         fused_render_losses(res, b[3], synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model).backward()
         opt.zero_grad(set_to_none=True)
