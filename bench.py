@@ -107,6 +107,48 @@ def cpu_baseline(n_rays=1024, iters=3):
                                       f"({n_in} in-bbox samples/iter, median {med * 1e3:.0f} ms), torch CPU + C oracle"}
 
 
+def launch_ranks(n_gpus: int, argv) -> int:
+    """One process per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port); returns the children's
+    exit status (non-zero if any rank failed: torchrun tears the others down)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_rank(args) -> int:
+    """FGS_BENCH_DRY=gloo: rehearse the launcher and the cross-rank reporting protocol on CPU (no device work, no timing
+    claim): process group, barrier, MAX / SUM reductions, rank 0 prints the JSON line with the world size it saw."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend=os.environ["FGS_BENCH_DRY"])
+        dist.barrier()
+    stats = torch.tensor([1.0 + rank, 100.0], dtype=torch.float64)
+    tmax, ssum = stats[:1].clone(), stats[1:].clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+    seen = dist.get_world_size() if world > 1 else 1
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher rehearsal, no device work)", "value": None, "n_gpus": seen,
+                          "steps": args.steps, "warmup": args.warmup, "max_elapsed": float(tmax), "sum_units": float(ssum)}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +162,13 @@ def main():
                     help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
     args = ap.parse_args()
     globals()["GRID"] = args.grid
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE anything
+    # in this process touches the GPU (the parent never initialises HIP and never replaces itself with another program).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("FGS_BENCH_DRY"):
+        sys.exit(dry_rank(args))
 
     # host side of this path is one Python thread + the autograd thread; the box grants a 16-CPU quota per GPU and
     # torch would otherwise spawn one OpenMP worker per visible core (256) for the synthetic-scene setup
@@ -145,7 +194,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     model = synth.build_model(GRID, synth.FINE_MODEL if args.stage == "fine" else synth.COARSE_MODEL, device=dev,
                               fused=False if args.composed else None)
@@ -229,7 +279,7 @@ def main():
         line = {
             "metric": f"M ray-samples/sec (fwd+bwd), {GRID}^3 grid, 4096-ray batch",
             "value": round(samples / elapsed / 1e6, 3), "unit": "M ray-samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": (dist.get_world_size() if dist.is_initialized() else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"configs[1]: {GRID}^3 sdf(1ch)+k0(12ch) fine-stage training step "

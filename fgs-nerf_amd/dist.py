@@ -78,6 +78,8 @@ class GradAverager:
         self._bucket = None
         self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
         self._hints = {}                  # id(param) -> state of hint_touched()
+        self.dense_sources = {}           # id(param) -> True while a dense term (TV loss) also writes that gradient
+        self.last_hint_wait_us = 0.0      # host time spent waiting for the hinted brick count (diagnostics)
 
     # ------------------------------------------------------------------------------------------------ early occupancy
     def hint_touched(self, param: torch.nn.Parameter, pts: torch.Tensor, xyz_min, xyz_max) -> None:
@@ -90,8 +92,14 @@ class GradAverager:
         if (self.world_size == 1 and not self.force) or not (pts.is_cuda and param.dim() == 5):
             return
         _, C, X, Y, Z = param.shape
-        if X % BRICK or Y % BRICK or Z % BRICK or C == 1:
+        # The same predicate as the consumer (`early('k0')` / `average()` take the sparse path only for grids of at least
+        # `sparse_min_numel` elements): every condition that decides whether the collective below is issued is a function
+        # of the parameter's SHAPE, identical on all ranks -- never of rank-local state (survivor counts, allocator
+        # addresses), or ranks would disagree on the collective sequence of `self.group` and hang.
+        if X % BRICK or Y % BRICK or Z % BRICK or C == 1 or param.numel() < self.sparse_min_numel:
             return
+        if self.dense_sources.get(id(param), False):
+            return        # something else (a TV loss on this grid) adds a dense gradient: occupancy comes from the gradient
         import ctypes
         from ._lib import call, ptr, stream
         total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
@@ -109,9 +117,6 @@ class GradAverager:
             h['box_key'] = (id(xyz_min), id(xyz_max))
         lo, hi = h['lo'], h['hi']
         pts = pts.detach().contiguous()
-        if h['armed'] and h.get('pts_key') == (pts.data_ptr(), pts.shape[0]):
-            return                                    # already hinted for this survivor list (from inside the forward pass)
-        h['pts_key'] = (pts.data_ptr(), pts.shape[0])
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(h['stream']):
@@ -151,7 +156,18 @@ class GradAverager:
         if on_gpu and h is not None and h['armed'] and h['total'] == total:
             from ._lib import call, ptr, stream
             h['armed'] = False
-            h['event'].synchronize()                       # side-stream work issued ~one MLP pass ago: already complete
+            # The brick count sizes a collective, so every rank must read the SAME number here: a non-blocking "use it
+            # if it has arrived, else go dense" would let ranks choose different collectives.  The count was produced on
+            # the side stream right behind the survivor list (before the MLP forward ran on the device), so this wait is
+            # over as soon as the device has passed the march kernels of THIS step -- one MLP forward + backward before
+            # the gradient this exchange needs exists; the device never idles on it.  `last_hint_wait_us` records it.
+            if not h['event'].query():
+                import time
+                t0 = time.perf_counter()
+                h['event'].synchronize()
+                self.last_hint_wait_us = (time.perf_counter() - t0) * 1e6
+            else:
+                self.last_hint_wait_us = 0.0
             torch.cuda.current_stream().wait_event(h['event'])
             n = int(h['count_host'][0])
             self.last_sparse_fill = n / max(total, 1)
@@ -195,6 +211,17 @@ class GradAverager:
         buf.mul_(inv)
         bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
         return True
+
+    def _disarm(self, param) -> None:
+        h = self._hints.get(id(param)) if param is not None else None
+        if h is not None:
+            h['armed'] = False
+
+    def set_dense_source(self, param, active: bool) -> None:
+        """Declare that this step adds a dense term to `param.grad` besides the trilinear scatter at the survivors (an
+        autograd TV loss on the grid).  While active, `hint_touched` is ignored for the parameter and the brick occupancy
+        is read from the gradient itself (or the exchange goes dense)."""
+        self.dense_sources[id(param)] = bool(active)
 
     def attach(self, model) -> None:
         """Let the fused backward pass of `model` (fused.py) hand gradients over as soon as they are final (see `early`)."""
@@ -263,6 +290,7 @@ class GradAverager:
                 ok = (g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1
                       and self._sparse(g, inv, params[0], group=self.early_group))
                 if not ok:
+                    self._disarm(params[0])
                     _, flat = self._dense(g, async_op=False, group=self.early_group)
                     self._post_scale(flat, inv)
             else:
@@ -322,6 +350,7 @@ class GradAverager:
             torch._foreach_copy_(small, views)                                             # a few launches out
         for g in sparse_later:
             if not self._sparse(g, inv, owner.get(id(g))):
+                self._disarm(owner.get(id(g)))
                 h, flat = self._dense(g, async_op=False)
                 self._post_scale(flat, inv)
         for h, flat in handles:

@@ -88,10 +88,15 @@ class _Geom:
 
 
 def _geom(model) -> _Geom:
-    key = (tuple(model.sdf.grid.shape), id(model.mask_cache))
+    # keyed on the grid shape AND on the identity / in-place version of everything _Geom copies to the host (a new bbox or
+    # voxel size with an unchanged grid shape must not serve stale lo / hi / voxel_size); the keyed objects are kept alive
+    # by the cache entry so that an id() cannot be reused by a successor
+    objs = (model.voxel_size, model.xyz_min, model.xyz_max, model.mask_cache)
+    key = (tuple(model.sdf.grid.shape),) + tuple((id(o), getattr(o, '_version', 0)) for o in objs)
     g = getattr(model, '_fused_geom', None)
     if g is None or getattr(model, '_fused_geom_key', None) != key:
         g = _Geom(model)
+        g._keyed = objs
         model._fused_geom, model._fused_geom_key = g, key
     return g
 
@@ -338,6 +343,7 @@ class _FusedFine(torch.autograd.Function):
         ms = run.max_steps
         rec = N * ms
         ws = run.workspace
+        _own_workspace(run, any(ctx.needs_input_grad))
         # 1. march (alphainv_last is an output of this call: a fresh tensor per step, the other records live in `ws`)
         alphainv_last = torch.empty(N, dtype=F32, device=dev)
         call("fgs_march_fine_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
@@ -459,10 +465,46 @@ class _FusedFine(torch.autograd.Function):
         return rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient
 
     @staticmethod
+    def _backward_empty(run, sdf_grid, k0_grid, mlp, rgb_w, ref_w, rw, fw, ldx0, ldz):
+        """No sample survived on THIS rank (every ray missed the volume): the local gradients are exactly zero, but the
+        other ranks still exchange theirs from inside their backward passes -- issue the same hooks in the same order
+        on the same buffers shapes, or the collectives of the early communicator would not match up (deadlock)."""
+        dev = sdf_grid.device
+        n_rgb, n_ref = run.n_rgb, run.n_ref
+        items, total = _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz)
+        flat = torch.zeros(total, dtype=F32, device=dev)
+        views = [flat[off:off + n].view(sh) for sh, n, off in items]
+        grad_sdf = torch.zeros_like(sdf_grid)
+        grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+        run.pre = None
+        hook, opt_hook = _early_hooks(run)
+        if hook is not None:
+            hook('mlp', mlp, flat)
+            hook('k0', [k0_grid], grad_k0)
+            hook('join', None)
+        elif opt_hook is not None:
+            opt_hook(k0_grid, grad_k0)
+        gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
+        gb_rgb = views[n_rgb + n_ref:2 * n_rgb + n_ref]
+        gb_ref = views[2 * n_rgb + n_ref:2 * n_rgb + 2 * n_ref]
+        gW0p, gV0p, cs = views[-3], views[-2], views[-1]       # where the other ranks' first-layer / last-bias gradients live
+        gw_rgb[0], gw_ref[0], gb_rgb[-1] = gW0p[:, :rgb_w[0].shape[1]], gV0p[:, :ref_w[0].shape[1]], cs[:rw]
+        grads = [None, grad_sdf, grad_k0]
+        for i in range(n_rgb):
+            grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
+        for i in range(n_ref):
+            grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
+        return tuple(grads)
+
+    @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
         run = ctx.run
-        sdf_grid, k0_grid, *mlp = ctx.saved_tensors
+        if run.done:
+            raise RuntimeError("fused forward_fine: backward called twice on the same forward (its march records are released "
+                               "after the first backward; retain_graph is not supported by the fused path)")
+        run.done = True          # releases the record set for the next forward (the kernels below are already ordered
+        sdf_grid, k0_grid, *mlp = ctx.saved_tensors            # on the stream in front of anything that forward enqueues)
         S, g, N, M, st = run.saved, run.geom, run.n_rays, run.M, stream()
         ws = run.workspace
         dev = sdf_grid.device
@@ -477,10 +519,8 @@ class _FusedFine(torch.autograd.Function):
         g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
             c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
 
-        if M == 0:   # no sample survived (every ray missed the volume): all gradients are exactly zero
-            return (None, torch.zeros_like(sdf_grid),
-                    torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_(),
-                    *[torch.zeros_like(t) for t in mlp])
+        if M == 0:
+            return _FusedFine._backward_empty(run, sdf_grid, k0_grid, mlp, rgb_w, ref_w, rw, fw, ldx0, ldz)
         # 1. compositing
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
@@ -490,17 +530,7 @@ class _FusedFine(torch.autograd.Function):
         # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised): one zero fill for all of
         # them, views of a flat buffer, each 16-byte aligned.  The layout is cached; only the three views the head kernel
         # needs are made before its launch, the rest while it runs (the GPU is idle at the start of a backward pass).
-        lay = run.cache.get('grad_layout')
-        if lay is None:
-            shapes = ([tuple(w.shape) for w in rgb_w] + [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in rgb_w] +
-                      [(w.shape[0],) for w in ref_w] + [(rw, ldx0), (fw, ldz), (ldz,)])
-            items, off = [], 0
-            for sh in shapes:
-                n = int(np.prod(sh))
-                items.append((sh, n, off))
-                off += (n + 3) // 4 * 4
-            lay = run.cache['grad_layout'] = (items, off)
-        items, total = lay
+        items, total = _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz)
         flat = torch.zeros(total, dtype=F32, device=dev)
 
         def view(i):
@@ -553,7 +583,7 @@ class _FusedFine(torch.autograd.Function):
         gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
-        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split", "chain") else None   # dist.GradAverager.early
+        hook, opt_hook = _early_hooks(run)
         if hook is not None:
             hook('mlp', mlp, flat)               # every MLP gradient is a view of `flat`, final from here on
 
@@ -574,8 +604,8 @@ class _FusedFine(torch.autograd.Function):
              ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)       # final: its exchange runs under the sdf scatter kernels below
-        elif run.cache.get('opt_hook') is not None:
-            run.cache['opt_hook'](k0_grid, grad_k0)   # MaskedAdam.early_update: k0's Adam pass runs beside them too
+        elif opt_hook is not None:
+            opt_hook(k0_grid, grad_k0)           # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
         call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
@@ -595,6 +625,26 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_ref):
             grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
         return tuple(grads)
+
+
+def _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz):
+    """(items, total): every MLP gradient of the fine stage as a 16-byte aligned view of one flat buffer (cached)."""
+    lay = run.cache.get('grad_layout')
+    if lay is None:
+        shapes = ([tuple(w.shape) for w in rgb_w] + [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in rgb_w] +
+                  [(w.shape[0],) for w in ref_w] + [(rw, ldx0), (fw, ldz), (ldz,)])
+        items, off = [], 0
+        for sh in shapes:
+            n = int(np.prod(sh))
+            items.append((sh, n, off))
+            off += (n + 3) // 4 * 4
+        lay = run.cache['grad_layout'] = (items, off)
+    return lay
+
+
+def _early_hooks(run):
+    hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split", "chain") else None   # dist.GradAverager.early
+    return hook, run.cache.get('opt_hook')
 
 
 def supports_coarse(model) -> bool:
@@ -627,6 +677,7 @@ class _FusedCoarse(torch.autograd.Function):
         ctx.set_materialize_grads(False)              # see _FusedFine.forward
         dev = sdf_smooth.device
         g, N, st, ms, ws = run.geom, run.n_rays, stream(), run.max_steps, run.workspace
+        _own_workspace(run, any(ctx.needs_input_grad))
         sdf_smooth, gradvol = sdf_smooth.contiguous(), gradvol.contiguous()
         use_mc = run.mask_grid is not None
         inc = run.inc
@@ -705,6 +756,10 @@ class _FusedCoarse(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
         run = ctx.run
+        if run.done:
+            raise RuntimeError("fused forward_coarse: backward called twice on the same forward (retain_graph is not "
+                               "supported by the fused path)")
+        run.done = True          # see _FusedFine.backward
         k0_grid, *mlp = ctx.saved_tensors
         S, g, N, M, st, ws = run.saved, run.geom, run.n_rays, run.M, stream(), run.workspace
         dev = k0_grid.device
@@ -716,15 +771,6 @@ class _FusedCoarse(torch.autograd.Function):
             return None if t is None else t.contiguous()
         g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal = map(
             c, (g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal))
-        if M == 0:   # no kept sample: all gradients are exactly zero
-            return (None, torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev),
-                    torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev),
-                    torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_(),
-                    *[torch.zeros_like(t) for t in mlp])
-        d_out = torch.empty(M, 3, dtype=F32, device=dev)
-        d_w = torch.empty(M, dtype=F32, device=dev)
-        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
-             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
         shapes = [tuple(w.shape) for w in ref_w] + [(w.shape[0],) for w in ref_w] + [(fw, ldx0)]
         sizes = [(int(np.prod(s)) + 3) // 4 * 4 for s in shapes]
         flat = torch.zeros(sum(sizes), dtype=F32, device=dev)
@@ -733,6 +779,26 @@ class _FusedCoarse(torch.autograd.Function):
             views.append(flat[off:off + int(np.prod(s))].view(*s))
             off += n
         gw, gb, gV0p = views[:n_ref], views[n_ref:2 * n_ref], views[-1]
+        if M == 0:   # no kept sample on this rank: zero local gradients, but the same hooks as every other rank (see
+            run.pre = None                                  # _FusedFine._backward_empty)
+            grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+            hook, opt_hook = _early_hooks(run)
+            if hook is not None:
+                hook('mlp', mlp, flat)
+                hook('k0', [k0_grid], grad_k0)
+                hook('join', None)
+            elif opt_hook is not None:
+                opt_hook(k0_grid, grad_k0)
+            gw[0] = gV0p[:, :ref_w[0].shape[1]]
+            grads = [None, torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev),
+                     torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev), grad_k0]
+            for i in range(n_ref):
+                grads += [gw[i].contiguous(), gb[i].contiguous()]
+            return tuple(grads)
+        d_out = torch.empty(M, 3, dtype=F32, device=dev)
+        d_w = torch.empty(M, dtype=F32, device=dev)
+        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
+             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
         acts = S['acts']
         a_last = acts[n_ref - 1]
         dY = torch.empty(M, fw, dtype=F32, device=dev)
@@ -752,7 +818,7 @@ class _FusedCoarse(torch.autograd.Function):
         gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
-        hook = run.cache.get('grad_hook') if _LINEAR_BWD_MODE in ("one", "split", "chain") else None   # dist.GradAverager.early
+        hook, opt_hook = _early_hooks(run)
         if hook is not None:
             hook('mlp', mlp, flat)
         if run.pre is not None:
@@ -768,8 +834,8 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(g_grad_s), st)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)
-        elif run.cache.get('opt_hook') is not None:
-            run.cache['opt_hook'](k0_grid, grad_k0)
+        elif opt_hook is not None:
+            opt_hook(k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
         # it in place through element strides
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
@@ -788,10 +854,19 @@ class _FusedCoarse(torch.autograd.Function):
 
 
 def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tensor]:
-    """Per-(n_rays, max_steps) record arrays, cached on the model: no allocator traffic in the steady state."""
+    """Per-(n_rays, max_steps) record arrays, cached on the model: no allocator traffic in the steady state.
+
+    The records of a forward are re-read by its backward.  A forward whose backward is still pending OWNS the set it
+    wrote (`ws['owner']`, a weak reference to its run): a second forward with the same ray count before that backward
+    (a loss over two batches, gradient accumulation, a validation render while the graph is alive) gets a fresh set
+    instead of overwriting it -- the reference's autograd graph owns its saved tensors the same way."""
     key = (n_rays, max_steps, str(dev))
     cache = model.__dict__.setdefault('_fused_ws', {})
     ws = cache.get(key)
+    if ws is not None:
+        owner = ws['owner']() if ws.get('owner') is not None else None
+        if owner is not None and not owner.done:
+            ws = None
     if ws is None:
         rec = n_rays * max_steps
         ws = dict(a_step=torch.empty(rec, dtype=I32, device=dev), a_alpha=torch.empty(rec, dtype=F32, device=dev),
@@ -801,9 +876,20 @@ def _workspace(model, n_rays: int, max_steps: int, dev) -> Dict[str, torch.Tenso
                   n_alive=torch.empty(n_rays, dtype=I64, device=dev), n_surv=torch.empty(n_rays, dtype=I64, device=dev),
                   n_inbbox=torch.empty(n_rays, dtype=I64, device=dev),
                   surv_off=torch.empty(n_rays + 1, dtype=I64, device=dev))
+        ws['owner'], ws['gen'] = None, 0
         cache.clear()            # keep one shape resident
         cache[key] = ws
+    ws['gen'] += 1               # one generation per forward: late readers (lazy 'mask') check they still see their own
     return ws
+
+
+def _own_workspace(run, needs_grad: bool) -> None:
+    """Called by the forward pass: the run keeps its record set until its backward has run (see _workspace)."""
+    import weakref
+    run.done = not needs_grad
+    run.gen = run.workspace['gen']
+    if needs_grad:
+        run.workspace['owner'] = weakref.ref(run)
 
 
 def enable_early_update(model, optimizer, averager=None) -> None:
@@ -970,6 +1056,9 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
         """`weights > thres` over the reference's alpha-compacted list (model/nerf.py:825): per ray the alive records come
         first (survivors flagged), the samples behind the terminating one follow (all False)."""
         g, ws = run.geom, run.workspace
+        if ws['gen'] != run.gen:
+            raise RuntimeError("result['mask'] of the fused forward_fine must be read before the next forward with the same "
+                               "ray count (its per-ray records have been overwritten)")
         n_m1 = torch.empty(N, dtype=I64, device=dev)
         n_in = torch.empty(N, dtype=I64, device=dev)
         call("fgs_march_count", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,

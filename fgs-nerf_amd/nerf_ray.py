@@ -24,4 +24,4 @@ def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='cente
     return _r.get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode=mode, device=_accel())
 
 
-get_training_rays_in_maskcache_sampling = _r._maskcache_sampler(use_sample_ray_ori=True)
+get_training_rays_in_maskcache_sampling = _r._maskcache_sampler(use_sample_ray_ori=True, rays_fn=get_rays_of_a_view)

@@ -211,6 +211,9 @@ class TrainStepper:
                 if ct.get('weight_tv_k0', 0) > 0:
                     loss = loss + ct.weight_tv_k0 * model.k0_total_variation(**ct.get('k0_tv_terms', {}))
                     hinted = False            # k0 receives a dense gradient: the survivor-point occupancy does not cover it
+        if self.averager is not None:                # the averager itself refuses a hint while a dense k0 term is active
+            self.averager.set_dense_source(model.k0.grid, tv_now and ori_tv and ct.get('weight_tv_density', 0) > 0
+                                           and ct.get('weight_tv_k0', 0) > 0)
         if hinted:
             self.averager.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
         loss.backward()

@@ -101,8 +101,10 @@ def get_training_rays(rgb_tr, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_
     return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, [1] * len(rgb_tr)
 
 
-def _flatten_views(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, keep_mask_fn=None):
-    """Shared body of the two flattening samplers: concatenates (optionally masked) per-view rays."""
+def _flatten_views(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, keep_mask_fn=None, rays_fn=None):
+    """Shared body of the two flattening samplers: concatenates (optionally masked) per-view rays.  `rays_fn`: the calling
+    module's own get_rays_of_a_view (nerf_ray's returns rays on the accelerator, which the mask filter then runs on)."""
+    get_rays_of_a_view = rays_fn or globals()['get_rays_of_a_view']
     assert len(rgb_tr_ori) == len(train_poses) and len(rgb_tr_ori) == len(Ks) and len(rgb_tr_ori) == len(HW)
     dev = rgb_tr_ori[0].device
     N = sum(im.shape[0] * im.shape[1] for im in rgb_tr_ori)
@@ -118,7 +120,7 @@ def _flatten_views(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip
         else:
             keep = keep_mask_fn(o, d, img)
             n = int(keep.sum())
-            sel = lambda t: t[keep]
+            sel = lambda t: t[keep.to(t.device)]
         rgb_tr[top:top + n].copy_(sel(img))
         rays_o_tr[top:top + n].copy_(sel(o).to(dev))
         rays_d_tr[top:top + n].copy_(sel(d).to(dev))
@@ -139,7 +141,7 @@ def get_training_rays_flatten(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, f
     return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, imsz
 
 
-def _maskcache_sampler(use_sample_ray_ori):
+def _maskcache_sampler(use_sample_ray_ori, rays_fn=None):
     @torch.no_grad()
     def get_training_rays_in_maskcache_sampling(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y,
                                                 model, render_kwargs):
@@ -160,10 +162,10 @@ def _maskcache_sampler(use_sample_ray_ori):
                                                          **render_kwargs)
                 mask_outbbox[~mask_outbbox] |= (~model.mask_cache(pts[~mask_outbbox]))
                 keep[r0:r0 + CHUNK] &= (~mask_outbbox).any(-1).to(dev)
-            return keep
+            return keep.to(rays_o.device)      # indexes the rays (and, moved back, the image) in _flatten_views
 
         rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, imsz, top, N = _flatten_views(
-            rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, keep_mask_fn=keep_mask)
+            rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, keep_mask_fn=keep_mask, rays_fn=rays_fn)
         print('get_training_rays_in_maskcache_sampling: ratio', top / N)
         print('get_training_rays_in_maskcache_sampling: finish (eps time:', time.time() - t0, 'sec)')
         return rgb_tr[:top], rays_o_tr[:top], rays_d_tr[:top], viewdirs_tr[:top], imsz

@@ -2,6 +2,7 @@
 
     python oracle/make_golden.py            # everything
     python oracle/make_golden.py rays       # only the fixtures that need /root/reference
+    python oracle/make_golden.py maskcache_rays   # the mask-cache ray pre-filter fixture alone (needs /root/reference)
 
 Two kinds of fixture:
 
@@ -70,6 +71,61 @@ def make_rays():
     np.random.seed(5)
     gen = ref.batch_indices_generator(10, 4)
     save("batch_indices.npz", seed=5, N=10, BS=4, batches=np.stack([next(gen).numpy() for _ in range(5)]))
+
+
+class DuckModel:
+    """What get_training_rays_in_maskcache_sampling asks of `model` (model/nerf_ray.py:230-232), backed by the oracle:
+    `sample_ray_ori` (model/nerf.py:734-758 restated) and a `mask_cache` callable (model/nerf.py:1202-1209 restated)."""
+
+    def __init__(self, P, grid_shape, mc):
+        self.P, self.grid_shape, self.mc = P, tuple(grid_shape), mc
+
+    def sample_ray_ori(self, rays_o, rays_d, near, far, stepsize, is_train=False, **render_kwargs):
+        return O.sample_ray_ori(self.P, self.grid_shape, rays_o, rays_d, near, far, stepsize)
+
+    def mask_cache(self, pts):
+        return O.mask_cache_forward(self.mc, pts)
+
+
+def maskcache_scene():
+    """Inputs of the mask-cache ray pre-filter fixture: 3 small views (two sizes), an occupied blob off-centre so that
+    whole image regions are dropped.  Returned as plain tensors so the test can rebuild the same duck model."""
+    from fgs_nerf_amd import synth
+    G = 16
+    lo, hi = torch.tensor([-1., -1., -1.]), torch.tensor([1., 1., 1.])
+    voxel_size, world = O.grid_resolution(lo, hi, G ** 3)
+    ax = torch.linspace(-1, 1, G)
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing='ij')
+    occupied = ((x - 0.3) ** 2 + (y + 0.2) ** 2 + (z - 0.1) ** 2).sqrt() < 0.45
+    sdf_mask = (occupied.float() * 1e-3)[None, None]
+    HW = np.array([[40, 48], [40, 48], [33, 25]])
+    Ks = np.stack([synth.intrinsics(int(h), int(w), fov_x=0.6911) for h, w in HW])
+    poses = torch.stack([torch.from_numpy(synth.look_at_origin(a, e, 4.0)) for a, e in ((20., 30.), (140., 10.), (260., 50.))])
+    gen = torch.Generator().manual_seed(31)
+    images = [torch.rand(int(h), int(w), 3, generator=gen) for h, w in HW]
+    return dict(G=G, xyz_min=lo, xyz_max=hi, voxel_size=voxel_size, sdf_mask=sdf_mask, thres=0.5e-3, HW=HW, Ks=Ks,
+                poses=poses, images=images, render_kwargs=dict(near=2.0, far=6.0, stepsize=0.5))
+
+
+def make_maskcache_rays():
+    """model/nerf_ray.py:208-250 run by IMPORTING the reference's own file, on the duck model above."""
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location("ref_nerf_ray", os.path.join(REF, "model", "nerf_ray.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    sc = maskcache_scene()
+    P = dict(xyz_min=sc['xyz_min'], xyz_max=sc['xyz_max'], voxel_size=sc['voxel_size'])
+    mc = O.make_mask_cache(sc['sdf_mask'], sc['xyz_min'], sc['xyz_max'], sc['thres'])
+    duck = DuckModel(P, (sc['G'],) * 3, mc)
+    rgb_tr, ro_tr, rd_tr, vd_tr, imsz = ref.get_training_rays_in_maskcache_sampling(
+        rgb_tr_ori=sc['images'], train_poses=sc['poses'], HW=sc['HW'], Ks=sc['Ks'], ndc=False, inverse_y=False, flip_x=False,
+        flip_y=False, model=duck, render_kwargs=sc['render_kwargs'])
+    n_all = int(sum(int(h) * int(w) for h, w in sc['HW']))
+    assert 0 < len(rgb_tr) < n_all, (len(rgb_tr), n_all)      # the filter really dropped rays, and kept some
+    save("maskcache_rays.npz", G=sc['G'], xyz_min=sc['xyz_min'], xyz_max=sc['xyz_max'], voxel_size=sc['voxel_size'],
+         sdf_mask=sc['sdf_mask'], thres=sc['thres'], HW=sc['HW'], Ks=sc['Ks'], poses=sc['poses'],
+         image0=sc['images'][0], image1=sc['images'][1], image2=sc['images'][2], near=2.0, far=6.0, stepsize=0.5,
+         rgb_tr=rgb_tr, rays_o_tr=ro_tr, rays_d_tr=rd_tr, viewdirs_tr=vd_tr, imsz=np.array([int(n) for n in imsz]))
 
 
 def special_rays():
@@ -223,6 +279,8 @@ if __name__ == "__main__":
         make_extras()
     if "rays" in what:
         make_rays()
+    if "rays" in what or "maskcache_rays" in what:
+        make_maskcache_rays()
     if "kernels" in what:
         make_kernels()
     if "trilerp" in what:

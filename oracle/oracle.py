@@ -277,7 +277,7 @@ def grid_sampler_ret_grad(xyz, grid, xyz_min, xyz_max, voxel_size):
 
 def neus_sdf_gradient(sdf: torch.Tensor, voxel_size) -> torch.Tensor:
     """model/nerf.py:485-494 (mode 'interpolate'): interior central difference, zero faces."""
-    g = torch.zeros([1, 3, *sdf.shape[-3:]])
+    g = torch.zeros([1, 3, *sdf.shape[-3:]], dtype=sdf.dtype)
     g[:, 0, 1:-1, :, :] = (sdf[:, 0, 2:, :, :] - sdf[:, 0, :-2, :, :]) / 2 / voxel_size
     g[:, 1, :, 1:-1, :] = (sdf[:, 0, :, 2:, :] - sdf[:, 0, :, :-2, :]) / 2 / voxel_size
     g[:, 2, :, :, 1:-1] = (sdf[:, 0, :, :, 2:] - sdf[:, 0, :, :, :-2]) / 2 / voxel_size
@@ -293,11 +293,23 @@ def gaussian_kernel3d(ksize: int, sigma: float) -> torch.Tensor:
     return k / k.sum()
 
 
+def tv_smooth_kernel(sigma: float = 0) -> torch.Tensor:
+    """model/nerf.py:226-236,250-252: the 3^3 binomial taps of `tv_smooth_conv` (kernel0 / kernel0.sum()), [3,3,3] float32."""
+    kernel = np.asarray([[[1, 2, 1], [2, 4, 2], [1, 2, 1]], [[2, 4, 2], [4, 8, 4], [2, 4, 2]], [[1, 2, 1], [2, 4, 2], [1, 2, 1]]])
+    distance = np.zeros((3, 3, 3))
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                distance[i, j, k] = ((i - 1) ** 2 + (j - 1) ** 2 + (k - 1) ** 2 - 1)
+    kernel0 = kernel * np.exp(-distance * sigma)
+    return torch.from_numpy(kernel0 / kernel0.sum()).float()
+
+
 def smooth_conv(grid: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     """model/nerf.py:267-272: Conv3d(1,1,k, padding=k//2, padding_mode='replicate'), zero bias."""
     k = kernel.shape[0]
     padded = F.pad(grid, (k // 2,) * 6, mode='replicate')
-    return F.conv3d(padded, kernel[None, None], bias=torch.zeros(1))
+    return F.conv3d(padded, kernel[None, None].to(grid.dtype), bias=torch.zeros(1, dtype=grid.dtype))
 
 
 def s_val_schedule(global_step, s_ratio, s_start, step_start=0) -> float:
@@ -342,6 +354,63 @@ class Alphas2Weights(torch.autograd.Function):
         g = K.alpha2weight_backward(alpha.detach().numpy(), w.numpy(), T.numpy(), last.numpy(), i_s.numpy(), i_e.numpy(),
                                     ctx.n_rays, grad_weights.contiguous().numpy(), grad_last.contiguous().numpy())
         return torch.from_numpy(g), None, None
+
+
+class Alphas2WeightsF64(torch.autograd.Function):
+    """The same recurrences as alpha2weight / alpha2weight_backward (render_utils_kernel.cu:576-605, 653-677) carried out
+    in float64, for the fp64 error yardstick of the parity tests.  The per-ray stopping point (the first sample after
+    which T < 1e-3) is a DECISION, taken from the float32 run (`i_end`), so that both precisions weight the same samples."""
+
+    @staticmethod
+    def forward(ctx, alpha, ray_id, N, i_end):
+        a = alpha.detach().numpy().astype(np.float64)
+        rid = ray_id.numpy()
+        M = a.shape[0]
+        w, T, last = np.zeros(M), np.ones(M), np.ones(N)
+        i_start = np.searchsorted(rid, np.arange(N), side='left')
+        i_end = np.asarray(i_end, dtype=np.int64)
+        for r in range(N):
+            s, e = int(i_start[r]), int(i_end[r])
+            if e <= s:
+                continue
+            cp = np.cumprod(1.0 - a[s:e])
+            T[s + 1:e] = cp[:-1]
+            w[s:e] = T[s:e] * a[s:e]
+            last[r] = cp[-1]
+        w_t, last_t = torch.from_numpy(w), torch.from_numpy(last)
+        ctx.save_for_backward(alpha.detach().double(), w_t, torch.from_numpy(T), last_t, torch.from_numpy(i_start),
+                              torch.from_numpy(i_end))
+        ctx.n_rays = N
+        return w_t, last_t
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_weights, grad_last):
+        alpha, w, T, last, i_start, i_end = (t.numpy() for t in ctx.saved_tensors)
+        gw, gl = grad_weights.numpy().astype(np.float64), grad_last.numpy().astype(np.float64)
+        g = np.zeros_like(alpha)
+        for r in range(ctx.n_rays):
+            s, e = int(i_start[r]), int(i_end[r])
+            if e <= s:
+                continue
+            gww = gw[s:e] * w[s:e]
+            # back_cum seen by sample i = grad_last*alphainv_last + sum_{j>i} gw_j w_j   (:660-676)
+            tail = np.concatenate([np.cumsum(gww[::-1])[::-1][1:], [0.0]])
+            back = gl[r] * last[r] + tail
+            g[s:e] = gw[s:e] * T[s:e] - back / ((1.0 - alpha[s:e]) + 1e-10)
+        return torch.from_numpy(g), None, None, None
+
+
+def alphas2weights(alpha, ray_id, N, force_end=None):
+    """(weights, alphainv_last, i_end).  float32: the C restatement; float64 (needs `force_end` from a float32 run): the
+    same recurrences in double."""
+    if alpha.dtype == torch.float64:
+        assert force_end is not None, "the float64 yardstick takes its stopping points from a float32 run"
+        w, last = Alphas2WeightsF64.apply(alpha, ray_id, N, force_end)
+        return w, last, np.asarray(force_end)
+    w, last = Alphas2Weights.apply(alpha, ray_id, N)
+    _, _, _, _, i_e = K.alpha2weight(alpha.detach().numpy(), ray_id.numpy(), N)
+    return w, last, i_e
 
 
 def segment_sum(src: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
@@ -396,18 +465,57 @@ def sample_ray(P: Dict, rays_o, rays_d, near, stepsize):
             torch.from_numpy(mask_out), int(pts.shape[0]))
 
 
+def params_f64(P: Dict) -> Dict:
+    """Copy of an oracle parameter dict with the grids and MLP tensors in float64 (fresh leaves); scalars that the
+    reference rounds to float32 before use (voxel_size, bbox, frequencies) stay float32 VALUES, promoted on use."""
+    Q = dict(P)
+    Q['sdf'], Q['k0'] = P['sdf'].detach().double(), P['k0'].detach().double()
+    for net in ('rgbnet', 'refnet'):
+        if P.get(net) is not None:
+            Q[net] = [(W.detach().double(), b.detach().double()) for W, b in P[net]]
+    if P.get('smooth_kernel') is not None:
+        Q['smooth_kernel'] = P['smooth_kernel'].double()
+    return Q
+
+
+def sample_ray_ori(P: Dict, grid_shape, rays_o, rays_d, near, far, stepsize):
+    """model/nerf.py:734-758 (is_train=False): padded [..., N_samples, 3] sampling by the slab test in torch; used by the
+    mask-cache ray pre-filter (model/nerf_ray.py:230-231).  `grid_shape` = sdf.grid.shape[2:]."""
+    N_samples = int(np.linalg.norm(np.array(list(grid_shape)) + 1) / stepsize) + 1
+    vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+    rate_a = (P['xyz_max'] - rays_o) / vec
+    rate_b = (P['xyz_min'] - rays_o) / vec
+    t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+    t_max = torch.maximum(rate_a, rate_b).amin(-1).clamp(min=near, max=far)
+    mask_outbbox = (t_max <= t_min)
+    rng = torch.arange(N_samples)[None].float()
+    step = stepsize * P['voxel_size'] * rng
+    interpx = (t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True))
+    rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+    mask_outbbox = mask_outbbox[..., None] | ((P['xyz_min'] > rays_pts) | (rays_pts > P['xyz_max'])).any(dim=-1)
+    return rays_pts, mask_outbbox, step
+
+
 def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize, bg,
-                 render_depth=False, render_grad=False) -> Dict:
+                 render_depth=False, render_grad=False, decisions: Optional[Dict] = None) -> Dict:
     """model/nerf.py:776-941.  P holds: xyz_min, xyz_max, voxel_size (0-d fp32 tensor), sdf [1,1,X,Y,Z],
     k0 [1,C,X,Y,Z], rgbnet / refnet (lists of (W,b)), posfreq, viewfreq, reffreq, fast_color_thres,
     s_ratio, s_start, grad_feat_displace (sorted tuple), use_grad_norm, center_sdf, optional
     mask_cache, optional smooth_kernel."""
+    # `decisions` (the 'decisions' entry of an earlier float32 run on the same inputs): every discrete choice of the
+    # path -- mask-cache skip, alpha > thres, the T < 1e-3 stopping point, weights > thres -- is replayed instead of
+    # re-taken, so that a float64 run (P from params_f64) differentiates the SAME sample set: the error yardstick of
+    # the full-size parity tests.  Without it the function is the reference path, decisions included.
+    dec, rec = decisions, {}
     N = len(rays_o)
+    dt = P['sdf'].dtype
     xyz_min, xyz_max, voxel_size = P['xyz_min'], P['xyz_max'], P['voxel_size']
     ray_pts, ray_id, step_id, mask_outbbox, m_total = sample_ray(P, rays_o, rays_d, near, stepsize)
+    ray_pts, viewdirs = ray_pts.to(dt), viewdirs.to(dt)
     n_inbbox = int(ray_pts.shape[0])
     if P.get('mask_cache') is not None:
-        m = mask_cache_forward(P['mask_cache'], ray_pts)
+        m = dec['mc'] if dec else mask_cache_forward(P['mask_cache'], ray_pts)
+        rec['mc'] = m
         ray_pts, ray_id, step_id = ray_pts[m], ray_id[m], step_id[m]
         mask_outbbox[~mask_outbbox] |= ~m
     sdf_grid = smooth_conv(P['sdf'], P['smooth_kernel']) if P.get('smooth_kernel') is not None else P['sdf']
@@ -419,12 +527,14 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
     viewdirs_pts = viewdirs[ray_id]
     thres = P['fast_color_thres']
     if thres > 0:
-        mask = alpha > thres
+        mask = dec['alpha_mask'] if dec else alpha > thres
+        rec['alpha_mask'] = mask
         alpha, ray_id, viewdirs_pts, ray_pts = alpha[mask], ray_id[mask], viewdirs_pts[mask], ray_pts[mask]
         step_id, gradient, sdf = step_id[mask], gradient[mask], sdf[mask]
-    weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, N)
+    weights, alphainv_last, rec['i_end'] = alphas2weights(alpha, ray_id, N, dec['i_end'] if dec else None)
     if thres > 0:
-        mask = weights > thres
+        mask = dec['weight_mask'] if dec else weights > thres
+        rec['weight_mask'] = mask
         weights, alpha, ray_pts, viewdirs_pts = weights[mask], alpha[mask], ray_pts[mask], viewdirs_pts[mask]
         ray_id, step_id, gradient, sdf = ray_id[mask], step_id[mask], gradient[mask], sdf[mask]
     normal = l2_normalize(gradient / (gradient.norm(dim=-1, keepdim=True) + 1e-7))
@@ -464,25 +574,32 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
         'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': disp_map, 'mask': mask,
         'mask_outbbox': mask_outbbox, 'gradient': gradient, 's_val': s_val,
         # bookkeeping for the bench/tests (not in the reference dict)
-        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'sdf': sdf,
+        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'sdf': sdf, 'decisions': rec,
     }
 
 
 def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize, bg, stage='coarse',
-                   render_depth=True, render_grad=False) -> Dict:
-    """model/nerf.py:943-1075.  Extra keys in P: inc_mask (dict(mask, scale, shift) or None)."""
+                   render_depth=True, render_grad=False, decisions: Optional[Dict] = None) -> Dict:
+    """model/nerf.py:943-1075.  Extra keys in P: inc_mask (dict(mask, scale, shift) or None).  `decisions`: see
+    forward_fine."""
+    dec, rec = decisions, {}
     N = len(rays_o)
+    dt = P['sdf'].dtype
     xyz_min, xyz_max, voxel_size = P['xyz_min'], P['xyz_max'], P['voxel_size']
     ray_pts, ray_id, step_id, mask_outbbox, m_total = sample_ray(P, rays_o, rays_d, near, stepsize)
     n_inbbox = int(ray_pts.shape[0])
+    ray_pts32 = ray_pts
+    ray_pts, viewdirs = ray_pts.to(dt), viewdirs.to(dt)
     viewdirs_pts = viewdirs[ray_id]
     if stage == 'coarse' and P.get('mask_cache') is not None:
-        m = mask_cache_forward(P['mask_cache'], ray_pts)
+        m = dec['mc'] if dec else mask_cache_forward(P['mask_cache'], ray_pts)
+        rec['mc'] = m
         ray_pts, ray_id, viewdirs_pts, step_id = ray_pts[m], ray_id[m], viewdirs_pts[m], step_id[m]
+        ray_pts32 = ray_pts32[m]
         mask_outbbox[~mask_outbbox] |= ~m
     if P.get('inc_mask') is not None:
         im = P['inc_mask']
-        m = torch.from_numpy(K.maskcache_lookup(im['mask'].numpy(), ray_pts.numpy(), im['scale'].numpy(),
+        m = torch.from_numpy(K.maskcache_lookup(im['mask'].numpy(), ray_pts32.numpy(), im['scale'].numpy(),
                                                 im['shift'].numpy()))
         ray_pts, ray_id, viewdirs_pts, step_id = ray_pts[m], ray_id[m], viewdirs_pts[m], step_id[m]
     sdf_grid = smooth_conv(P['sdf'], P['smooth_kernel']) if P.get('smooth_kernel') is not None else P['sdf']
@@ -492,14 +609,20 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
     dist = stepsize * voxel_size
     s_val = s_val_schedule(global_step, P['s_ratio'], P['s_start'])
     alpha = neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradient, s_val)
-    weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, N)
     mask = None
     thres = P['fast_color_thres']
+    pass1 = None
+    if dec is None:
+        weights, alphainv_last, rec['i_end'] = alphas2weights(alpha, ray_id, N)
+        pass1 = dict(ray_id=ray_id, step_id=step_id, weights=weights.detach(), raw_alpha=alpha.detach())   # bookkeeping
     if thres > 0:
-        mask = weights > thres
+        mask = dec['weight_mask'] if dec else weights > thres
+        rec['weight_mask'] = mask
         ray_pts, ray_id, viewdirs_pts, step_id = ray_pts[mask], ray_id[mask], viewdirs_pts[mask], step_id[mask]
         alpha, gradient = alpha[mask], gradient[mask]
-    weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, N)
+        weights, alphainv_last, rec['i_end'] = alphas2weights(alpha, ray_id, N, dec['i_end'] if dec else None)
+    elif dec is not None:
+        weights, alphainv_last, rec['i_end'] = alphas2weights(alpha, ray_id, N, dec['i_end'])
     normal = l2_normalize(gradient / (gradient.norm(dim=-1, keepdim=True) + 1e-7))
     rays_xyz = (ray_pts - xyz_min) / (xyz_max - xyz_min)
     xyz_emb = posenc(rays_xyz, P['posfreq'])
@@ -526,7 +649,7 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
         'rgb_marched': rgb_marched, 'sigmoid_rgb': sigmoid_rgb, 'normal_marched': normal_marched,
         'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': disp_map, 'mask': mask,
         'mask_outbbox': mask_outbbox, 'gradient': gradient, 's_val': s_val,
-        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox,
+        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'decisions': rec, 'pass1': pass1,
     }
 
 

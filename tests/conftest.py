@@ -50,3 +50,42 @@ def rel_l2_finite(a, b):
     fin = torch.isfinite(b)
     assert torch.equal(torch.isfinite(a), fin), "non-finite pattern differs"
     return float((a[fin] - b[fin]).norm() / b[fin].norm().clamp_min(1e-30))
+
+
+def match_survivors(res, ref, thres=1e-4, label=""):
+    """The kept-sample lists (ray_id, step_id) of the HIP path and of the oracle must be IDENTICAL.  The only accepted
+    deviation is a decision flipped by an ulp-level difference in expf/sigmoid: every sample that is in one list and not
+    in the other must sit within 1e-7 of one of the path's three decision thresholds (alpha > thres, weights > thres,
+    T < 1e-3 with T = weights / alpha), judged on the values of the side that kept it.  Such samples are printed.
+    Returns (ia, ib, n_flips): index tensors selecting the common samples, in order, from `res` and `ref`."""
+    import torch
+    ka = res["ray_id"].cpu().long() * (1 << 24) + res["step_id"].cpu().long()
+    kb = torch.as_tensor(ref["ray_id"]).long() * (1 << 24) + torch.as_tensor(ref["step_id"]).long()
+    if ka.shape == kb.shape and torch.equal(ka, kb):
+        idx = torch.arange(ka.numel())
+        return idx, idx, 0
+    in_b, in_a = torch.isin(ka, kb), torch.isin(kb, ka)
+    flips = []
+    # coarse stage (model/nerf.py:981-988): the kept set is `weights > thres` of a FIRST Alphas2Weights pass over all
+    # samples; the oracle records that pass ('pass1'), and a differing sample is judged on its first-pass values there
+    p1 = ref.get("pass1") if hasattr(ref, "get") else None
+    k1 = None if p1 is None else p1["ray_id"].long() * (1 << 24) + p1["step_id"].long()
+    for side, d, keep in (("hip", res, ~in_b), ("oracle", ref, ~in_a)):
+        for i in torch.nonzero(keep).flatten().tolist():
+            w = float(torch.as_tensor(d["weights"])[i])
+            a = float(torch.as_tensor(d["raw_alpha"])[i])
+            near = min(abs(a - thres), abs(w - thres), abs(w / max(a, 1e-30) - 1e-3))
+            if k1 is not None:
+                key = int(torch.as_tensor(d["ray_id"])[i]) * (1 << 24) + int(torch.as_tensor(d["step_id"])[i])
+                j = torch.nonzero(k1 == key).flatten()
+                if j.numel():
+                    w1, a1 = float(p1["weights"][j[0]]), float(p1["raw_alpha"][j[0]])
+                    # (a sample the first pass never reached has w1 == 0 there: it was cut by the T < 1e-3 stop, whose
+                    # deciding T is that of the last sample the pass did reach on this ray)
+                    near = min(near, abs(w1 - thres), abs(w1 / max(a1, 1e-30) - 1e-3))
+            flips.append((side, int(torch.as_tensor(d["ray_id"])[i]), int(torch.as_tensor(d["step_id"])[i]), a, w, near))
+    print(f"[match_survivors{' ' + label if label else ''}] {len(flips)} sample(s) differ between the HIP path and the oracle:")
+    for f in flips:
+        print("    only in %-6s ray %d step %d alpha %.9g weight %.9g  distance to nearest threshold %.3g" % f)
+    assert all(f[5] < 1e-7 for f in flips), "a kept-sample difference that no threshold explains"
+    return torch.nonzero(in_b).flatten(), torch.nonzero(in_a).flatten(), len(flips)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import match_survivors, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -170,13 +170,11 @@ def test_fused_coarse_full_size_vs_oracle_forward(dev, oracle):
         res = model(ro.to(dev), rd.to(dev), vd.to(dev), global_step=1000, **synth.RENDER_KWARGS)
         ref = oracle.forward_coarse(synth.oracle_params(model), ro, rd, vd, global_step=1000, near=2.0, stepsize=0.5, bg=1)
     assert res["weights"].shape[0] > 20_000
-    same = res["ray_id"].shape == ref["ray_id"].shape and torch.equal(res["ray_id"].cpu(), ref["ray_id"])
+    ia, ib, _ = match_survivors(res, ref, label="160^3 coarse")   # identical, or every difference explained and printed
     assert rel_l2(res["rgb_marched"], ref["rgb_marched"]) < 1e-5
     assert rel_l2(res["alphainv_cum"], ref["alphainv_cum"]) < 1e-5
-    if same:
-        assert rel_l2(res["weights"], ref["weights"]) < 1e-5 and rel_l2(res["raw_rgb"], ref["raw_rgb"]) < 1e-5
-    else:
-        assert abs(res["ray_id"].shape[0] - ref["ray_id"].shape[0]) <= 8
+    assert rel_l2(res["weights"].cpu()[ia], ref["weights"][ib]) < 1e-5
+    assert rel_l2(res["raw_rgb"].cpu()[ia], ref["raw_rgb"][ib]) < 1e-5
     w_sum = torch.zeros(4096, device=dev).index_add_(0, res["ray_id"], res["weights"])
     assert float((w_sum + res["alphainv_cum"]).max()) <= 1.0 + 1e-5
     assert bool((res["ray_id"][1:] >= res["ray_id"][:-1]).all())

@@ -197,3 +197,84 @@ def test_brick_compact_matches_nonzero(dev, total):
     ref = flags.nonzero(as_tuple=False).squeeze(1)
     assert int(count) == ref.numel()
     assert torch.equal(idx[:ref.numel()], ref)
+
+
+def _edge_worker(rank, world, port, out_q, mode):
+    """Two gloo ranks on the box's one GPU, rank-ASYMMETRIC situations that used to desynchronise the collective sequence:
+      'empty_rank'  every ray of rank 1 misses the volume (M == 0 there): its backward must still issue the in-backward
+                    exchanges the other rank issues (fused._backward_empty), and receive rank 0's gradients;
+      'small_grid'  a grid below `sparse_min_numel` with hint_touched called every step and different survivor counts per
+                    rank and step: the hint must be ignored on shape grounds alone (no collective issued by one rank only)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fgs_nerf_amd import synth
+        from fgs_nerf_amd.dist import GradAverager
+        from fgs_nerf_amd.losses import fused_render_losses
+        if mode == 'empty_rank':
+            G, cfg, lossw, kw = 32, synth.FINE_MODEL, synth.FINE_LOSS, dict(sparse_min_numel=1 << 16)
+        else:
+            G, cfg, lossw, kw = 16, synth.COARSE_MODEL, synth.COARSE_LOSS, {}
+        model = synth.build_model(G, cfg, device=dev)
+        twin = synth.build_model(G, cfg, device=dev)
+        avg = GradAverager(model.parameters(), **kw)
+        avg.attach(model)
+        worst, n_surv = 0.0, []
+        for step in range(3):
+            n = 256 if mode == 'empty_rank' else (200 + 90 * ((rank + step) % 3))
+            ro, rd, vd = synth.random_rays(n, seed=40 + 7 * rank + step)
+            if mode == 'empty_rank' and rank == 1:
+                rd, vd = -rd, -vd                          # looking away from the box: no sample at all
+            rays = tuple(t.to(dev) for t in (ro, rd, vd))
+            target = torch.rand(n, 3, generator=torch.Generator().manual_seed(step)).to(dev)
+            for m_ in (model, twin):
+                for p in m_.parameters():
+                    p.grad = None
+            fused_render_losses(twin(*rays, global_step=1000, **synth.RENDER_KWARGS), target, lossw, twin).backward()
+            res = model(*rays, global_step=1000, **synth.RENDER_KWARGS)
+            n_surv.append(int(res['weights'].shape[0]))
+            avg.hint_touched(model.k0.grid, res['survivor_pts'], model.xyz_min, model.xyz_max)
+            fused_render_losses(res, target, lossw, model).backward()
+            avg.average()
+            for p, q in zip(model.parameters(), twin.parameters()):
+                if q.grad is None:
+                    continue
+                ref = q.grad.detach().contiguous().cpu()
+                dist.all_reduce(ref)
+                ref = ref / world
+                got = p.grad.detach().cpu()
+                if float(ref.norm()) > 0:
+                    worst = max(worst, float((got - ref).norm() / ref.norm()))
+                else:
+                    assert float(got.norm()) == 0
+        out_q.put((rank, worst, n_surv, len(avg._hints)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["empty_rank", "small_grid"])
+def test_rank_asymmetric_steps_keep_the_collectives_matched(dev, mode):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_edge_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, "a rank hung or failed (mismatched collectives?)"
+    results = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, worst, n_surv, n_hints in results:
+        assert worst < 1e-6, results
+    if mode == 'empty_rank':
+        assert all(n == 0 for n in results[1][2]) and all(n > 0 for n in results[0][2]), results
+    else:
+        assert all(r[3] == 0 for r in results), results            # the hint never armed anything on the small grid
+        assert results[0][2] != results[1][2]                      # different survivor histories on the two ranks

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import match_survivors, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -127,13 +127,11 @@ def test_fused_full_size_vs_oracle_forward(dev, oracle):
         res = model(ro.to(dev), rd.to(dev), vd.to(dev), global_step=1000, **synth.RENDER_KWARGS)
         ref = oracle.forward_fine(synth.oracle_params(model), ro, rd, vd, global_step=1000, near=2.0, stepsize=0.5, bg=1)
     assert res["weights"].shape[0] > 40_000
-    same = res["ray_id"].shape == ref["ray_id"].shape and torch.equal(res["ray_id"].cpu(), ref["ray_id"])
+    ia, ib, _ = match_survivors(res, ref, label="160^3 fine")     # identical, or every difference explained and printed
     assert rel_l2(res["rgb_marched"], ref["rgb_marched"]) < 1e-5
     assert rel_l2(res["alphainv_cum"], ref["alphainv_cum"]) < 1e-5
-    if same:
-        assert rel_l2(res["weights"], ref["weights"]) < 1e-5 and rel_l2(res["raw_rgb"], ref["raw_rgb"]) < 1e-5
-    else:   # a threshold decision flipped by an ulp-level expf difference: at most a handful of samples
-        assert abs(res["ray_id"].shape[0] - ref["ray_id"].shape[0]) <= 8
+    assert rel_l2(res["weights"].cpu()[ia], ref["weights"][ib]) < 1e-5
+    assert rel_l2(res["raw_rgb"].cpu()[ia], ref["raw_rgb"][ib]) < 1e-5
     # size-independent properties
     w_sum = torch.zeros(4096, device=dev).index_add_(0, res["ray_id"], res["weights"])
     assert float((w_sum + res["alphainv_cum"]).max()) <= 1.0 + 1e-5
@@ -294,7 +292,8 @@ def test_config4_shape_320_grid_forward(dev, oracle):
     assert int(res['n_inbbox_visited'].sum()) > 0 and res['weights'].shape[0] > 50_000
     assert rel_l2(res["rgb_marched"], ref["rgb_marched"]) < 1e-5
     assert rel_l2(res["alphainv_cum"], ref["alphainv_cum"]) < 1e-5
-    assert abs(res["ray_id"].shape[0] - ref["ray_id"].shape[0]) <= 16
+    ia, ib, _ = match_survivors(res, ref, label="320^3 fine")
+    assert rel_l2(res["weights"].cpu()[ia], ref["weights"][ib]) < 1e-5
     w_sum = torch.zeros(4096, device=dev).index_add_(0, res["ray_id"], res["weights"])
     assert float((w_sum + res["alphainv_cum"]).max()) <= 1.0 + 1e-5
 
@@ -389,3 +388,45 @@ def test_fused_full_size_backward_properties(dev):
     nz = (g1["k0"][0] != 0)
     assert not bool((nz.any(dim=0) & ~touched).any())
     assert int(nz.any(dim=0).sum()) > 100_000 and int(touched.sum()) < 2 * int(nz.any(dim=0).sum())
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_two_forwards_before_their_backwards_keep_their_own_records(dev, stage):
+    """A second forward with the same ray count before the first backward (loss over two batches, gradient accumulation,
+    a no_grad validation render while the graph is alive) must not overwrite the march records the first backward
+    re-reads: each forward owns its record set until its backward ran (fused._workspace).  Checked against the same two
+    batches run one after the other."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    from fgs_nerf_amd.nerf import mlp_layers
+    cfg, lossw = (synth.FINE_MODEL, synth.FINE_LOSS) if stage == "fine" else (synth.COARSE_MODEL, synth.COARSE_LOSS)
+    N = 300
+    batches = []
+    for seed in (5, 6):
+        rays = tuple(r.to(dev) for r in synth.random_rays(N, seed=seed))
+        batches.append((rays, torch.rand(N, 3, generator=torch.Generator().manual_seed(seed)).to(dev)))
+
+    def grads(model):
+        out = [model.sdf.grid.grad.clone(), model.k0.grid.grad.clone()]
+        return out + [p.grad.clone() for p in model.refnet.parameters()]
+
+    # reference: one after the other, gradients accumulated by autograd
+    a = synth.build_model(32, cfg, device=dev)
+    for rays, target in batches:
+        render_losses(a(*rays, global_step=1000, **synth.RENDER_KWARGS), target, lossw, a).backward()
+    ref = grads(a)
+    # interleaved: forward 1, forward 2 (+ a no_grad render of the same size in between), then the sum's backward
+    b = synth.build_model(32, cfg, device=dev)
+    r1 = b(*batches[0][0], global_step=1000, **synth.RENDER_KWARGS)
+    with torch.no_grad():
+        b(*batches[1][0], global_step=1000, **synth.RENDER_KWARGS)
+    r2 = b(*batches[1][0], global_step=1000, **synth.RENDER_KWARGS)
+    (render_losses(r1, batches[0][1], lossw, b) + render_losses(r2, batches[1][1], lossw, b)).backward()
+    for x, y in zip(grads(b), ref):
+        assert rel_l2(x, y) < 2e-5
+    # and a second backward through the same forward is refused loudly instead of reading released records
+    r3 = b(*batches[0][0], global_step=1000, **synth.RENDER_KWARGS)
+    l3 = render_losses(r3, batches[0][1], lossw, b)
+    l3.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="backward called twice"):
+        l3.backward()

@@ -31,43 +31,55 @@ def test_schedule_arithmetic_matches_reference_formulas():
     assert abs(nt.lr_decay_factor(dict(cfg, cosine_lr=False), 5) - 0.1 ** (1 / 20000)) < 1e-15
 
 
-def test_stepper_matches_oracle_loop(dev, oracle):
-    from fgs_nerf_amd import nerf_training as nt
-    from fgs_nerf_amd import synth
+def _oracle_loop(oracle, P, rays_c, target_c, cfg, iters, sampler, tvk):
+    """The reference's per-iteration body written out literally on the CPU (model/nerf_training.py:243-253, 300-456):
+    progressive growing (trilinear rescale of both grids, model/grid.py:101-106, new optimizer with the base learning
+    rates), oracle.forward_fine, the loss terms, the smooth-gradient TV term, TV add-grad, the C restatement of the Adam
+    kernels, the schedule arithmetic.  Mutates P; returns (losses, lr)."""
     from fgs_nerf_amd.losses import render_losses
-    G, R, ITERS = 24, 256, 6
-    model = synth.build_model(G, synth.FINE_MODEL, device=dev)
-    rays_c = synth.random_rays(R, seed=11)
-    target_c = torch.rand(R, 3, generator=torch.Generator().manual_seed(12))
-    rays = tuple(r.to(dev) for r in rays_c)
-    P = synth.oracle_params(model)                       # snapshot of the initial parameters on the CPU
-    stepper = nt.TrainStepper(model, TRAIN, {}, synth.RENDER_KWARGS, target_c.to(dev), *rays, stage='fine', seed=5)
-    twin = nt.DeviceBatchSampler(R, R, dev, seed=5)      # the same permutations the stepper will draw
+    R = len(target_c)
+    base_lr = {'k0': cfg['lrate_k0'], 'sdf': cfg['lrate_sdf'], 'rgbnet': cfg['lrate_rgbnet'], 'refnet': cfg['lrate_refnet']}
+    lr = dict(base_lr)
+    n_iters = cfg['N_iters']
 
-    # ---- oracle-side loop
-    names = ['sdf', 'k0'] + [f'rgbnet.{i}.{k}' for i in range(len(P['rgbnet'])) for k in ('w', 'b')] + \
-            [f'refnet.{i}.{k}' for i in range(len(P['refnet'])) for k in ('w', 'b')]
-    leaves = [P['sdf'], P['k0']] + [t for wb in P['rgbnet'] for t in wb] + [t for wb in P['refnet'] for t in wb]
-    lr = {'k0': 0.1, 'sdf': 0.005, 'rgbnet': 1e-3, 'refnet': 1e-3}
+    def leaves_of():
+        names = ['sdf', 'k0'] + [f'rgbnet.{i}.{k}' for i in range(len(P['rgbnet'])) for k in ('w', 'b')] + \
+                [f'refnet.{i}.{k}' for i in range(len(P['refnet'])) for k in ('w', 'b')]
+        leaves = [P['sdf'], P['k0']] + [t for wb in P['rgbnet'] for t in wb] + [t for wb in P['refnet'] for t in wb]
+        return names, leaves
+    names, leaves = leaves_of()
     state = [(np.zeros(t.numel(), np.float32), np.zeros(t.numel(), np.float32)) for t in leaves]
-    tvk = model.tv_smooth_conv.weight.detach().cpu()
-    vs = P['voxel_size']
-    w_tv = float(TRAIN['weight_tv_density'] * 0.1 / R * max(G, G, G) / 128)
-    losses_o = []
-    for gs in range(1, ITERS + 1):
-        sel = twin().cpu()
+    adam_step = 0
+    num_voxels = int(P['sdf'].shape[2]) ** 3
+    losses = []
+    for gs in range(1, iters + 1):
+        if gs in cfg.get('pg_scale', []):
+            num_voxels = num_voxels * cfg['scale_ratio']
+            voxel_size, world = oracle.grid_resolution(P['xyz_min'], P['xyz_max'], num_voxels)
+            size = tuple(int(w) for w in world)
+            with torch.no_grad():
+                P['sdf'] = F.interpolate(P['sdf'].detach(), size=size, mode='trilinear', align_corners=True)
+                P['k0'] = F.interpolate(P['k0'].detach(), size=size, mode='trilinear', align_corners=True)
+            P['voxel_size'] = voxel_size
+            names, leaves = leaves_of()
+            state = [(np.zeros(t.numel(), np.float32), np.zeros(t.numel(), np.float32)) for t in leaves]
+            adam_step, lr = 0, dict(base_lr)               # create_optimizer_or_freeze_model(..., global_step=0)
+        G = int(P['sdf'].shape[2])
+        w_tv = float(cfg['weight_tv_density'] * cfg['tv_terms']['sdf_tv'] / R * G / 128)
+        sel = sampler().cpu()
         for t in leaves:
             t.requires_grad_(True)
             t.grad = None
         res = oracle.forward_fine(P, rays_c[0][sel], rays_c[1][sel], rays_c[2][sel], global_step=gs, near=2.0, stepsize=0.5, bg=1)
-        loss = render_losses(res, target_c[sel], TRAIN)
-        tv_now = gs % 3 == 0
+        loss = render_losses(res, target_c[sel], cfg)
+        tv_now = gs % cfg['tv_every'] == 0
         if tv_now:
-            gv = oracle.neus_sdf_gradient(P['sdf'], vs).permute(1, 0, 2, 3, 4)
+            gv = oracle.neus_sdf_gradient(P['sdf'], P['voxel_size']).permute(1, 0, 2, 3, 4)
             sm = F.conv3d(F.pad(gv, (1,) * 6, mode='replicate'), tvk)
-            loss = loss + 0.01 * ((sm.detach() - gv) ** 2).mean() * 0.05
+            loss = loss + cfg['weight_tv_density'] * ((sm.detach() - gv) ** 2).mean() * cfg['tv_terms']['smooth_grad_tv']
         loss.backward()
-        losses_o.append(float(loss))
+        losses.append(float(loss))
+        adam_step += 1
         with torch.no_grad():
             if tv_now:
                 g = np.ascontiguousarray(P['sdf'].grad.numpy())
@@ -76,15 +88,30 @@ def test_stepper_matches_oracle_loop(dev, oracle):
             for t, name, (m, v) in zip(leaves, names, state):
                 grp = name.split('.')[0]
                 p = np.ascontiguousarray(t.detach().numpy()).reshape(-1)
-                oracle.K.adam_upd(p, np.ascontiguousarray(t.grad.numpy()).reshape(-1), m, v, gs, 0.9, 0.99, lr[grp], 1e-8,
+                oracle.K.adam_upd(p, np.ascontiguousarray(t.grad.numpy()).reshape(-1), m, v, adam_step, 0.9, 0.99, lr[grp], 1e-8,
                                   mode=1 if grp == 'k0' else 0)
                 t.detach().copy_(torch.from_numpy(p).view_as(t))
-        f = (lambda it: 1.0 if it < 0 else (1 + math.cos(it / 20 * math.pi)) * 0.5)
+        f = (lambda it: 1.0 if it < 0 else (1 + math.cos(it / n_iters * math.pi)) * 0.5)
         fac = f(gs - 1) / f(gs - 2)
         for k in lr:
             lr[k] *= fac
-        if gs - 1 == 2:
-            lr['sdf'] *= 0.1
+        for name, mul in cfg.get('decay_step_module', {}).get(gs - 1, {}).items():
+            lr[name] *= mul
+    return losses, lr
+
+
+def test_stepper_matches_oracle_loop(dev, oracle):
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    G, R, ITERS = 24, 256, 6
+    model = synth.build_model(G, synth.FINE_MODEL, device=dev)
+    rays_c = synth.random_rays(R, seed=11)
+    target_c = torch.rand(R, 3, generator=torch.Generator().manual_seed(12))
+    rays = tuple(r.to(dev) for r in rays_c)
+    P = synth.oracle_params(model)                       # snapshot of the initial parameters on the CPU
+    stepper = nt.TrainStepper(model, TRAIN, {}, synth.RENDER_KWARGS, target_c.to(dev), *rays, stage='fine', seed=5)
+    twin = nt.DeviceBatchSampler(R, R, dev, seed=5)      # the same permutations the stepper will draw
+    losses_o, lr = _oracle_loop(oracle, P, rays_c, target_c, TRAIN, ITERS, twin, model.tv_smooth_conv.weight.detach().cpu())
 
     # ---- the stepper
     losses_g = [float(stepper.step(gs)) for gs in range(1, ITERS + 1)]
@@ -99,6 +126,57 @@ def test_stepper_matches_oracle_loop(dev, oracle):
     assert rel_l2(model.k0.grid, P['k0']) < 5e-2
     st = stepper.stats()
     assert set(st) == {'psnr', 'wmax', 'wsum', 'wnonzero', 's_val'} and st['psnr'] > 0
+
+
+@pytest.mark.parametrize("forced_averager", [False, True])
+def test_stepper_across_a_pg_scale_boundary_matches_oracle_loop(dev, oracle, forced_averager):
+    """Progressive growing in the middle of a run (model/nerf_training.py:243-253): at iteration 4 both grids are resampled
+    to 2x the voxels, a new optimizer starts from the base learning rates, the fused path's cached geometry / workspaces
+    and -- with an averager -- the gradient exchange and the in-backward k0 update are re-bound to the NEW parameters
+    (GradAverager.rebind).  Three iterations before and three after, against the literal oracle loop; the forced averager
+    runs the whole exchange path in a single-rank RCCL group (an identity that still exercises every re-bound hook)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.dist import GradAverager
+    G, R, ITERS = 24, 256, 6
+    cfg = dict(TRAIN, pg_scale=[4], scale_ratio=2.0, decay_step_module={})
+    if forced_averager:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        model = synth.build_model(G, synth.FINE_MODEL, device=dev)
+        rays_c = synth.random_rays(R, seed=11)
+        target_c = torch.rand(R, 3, generator=torch.Generator().manual_seed(12))
+        rays = tuple(r.to(dev) for r in rays_c)
+        P = synth.oracle_params(model)
+        avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 12) if forced_averager else None
+        stepper = nt.TrainStepper(model, cfg, {}, synth.RENDER_KWARGS, target_c.to(dev), *rays, stage='fine', seed=5,
+                                  averager=avg)
+        twin = nt.DeviceBatchSampler(R, R, dev, seed=5)
+        losses_o, lr = _oracle_loop(oracle, P, rays_c, target_c, cfg, ITERS, twin, model.tv_smooth_conv.weight.detach().cpu())
+        k0_before = model.k0.grid
+        losses_g = [float(stepper.step(gs)) for gs in range(1, ITERS + 1)]
+        assert model.k0.grid is not k0_before and tuple(model.k0.grid.shape[2:]) == tuple(P['k0'].shape[2:]) != (G, G, G)
+        assert torch.equal(model.voxel_size.cpu(), P['voxel_size'])
+        for a, b in zip(losses_g, losses_o):
+            assert abs(a - b) < 2e-4 * abs(b), (losses_g, losses_o)
+        lrs = {g['name']: g['lr'] for g in stepper.optimizer.param_groups}
+        for k in lr:
+            assert abs(lrs[k] - lr[k]) < 1e-12 * max(1.0, lr[k]), (k, lrs[k], lr[k])
+        assert all(st['step'] == 3 for st in stepper.optimizer.state.values())       # the new optimizer took 3 steps
+        assert rel_l2(model.sdf.grid, P['sdf']) < 2e-3
+        assert rel_l2(model.k0.grid, P['k0']) < 5e-2
+        if forced_averager:       # the exchange follows the NEW grids
+            assert any(p is model.k0.grid for p in avg.params) and not any(p is k0_before for p in avg.params)
+    finally:
+        if forced_averager:
+            dist.destroy_process_group()
 
 
 def test_stepper_fused_and_composed_agree_and_coarse_runs(dev):
