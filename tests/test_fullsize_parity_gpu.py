@@ -7,7 +7,7 @@ For every compared tensor
 
     e_hip = rel-L2(HIP, oracle-f64)        e_ref = rel-L2(oracle-f32, oracle-f64)
 
-and the bar is  e_hip <= 2 * e_ref + FLOOR.  e_ref is what float32 itself costs on this computation (accumulation
+and the bar is  e_hip <= 2 * e_ref + FLOOR, plus a direct bar HIP-vs-oracle-f32 (DIRECT_OUT / DIRECT_GRAD, see check()).  e_ref is what float32 itself costs on this computation (accumulation
 order, expf/sigmoid ulps, ReLU pre-activations that change sign between two correct float32 evaluations -- each such
 flip moves a gradient by a whole term, which is why gradients sit at 1e-5..1e-4 and not at 1e-7 at these sizes); a kernel
 bug shows as e_hip >> e_ref.  FLOOR = 2e-6 covers tensors whose e_ref happens to be ~0 (a float32 evaluation that is
@@ -24,6 +24,8 @@ from conftest import match_survivors, rel_l2
 pytestmark = pytest.mark.gpu
 
 FLOOR = 2e-6
+DIRECT_OUT = 1e-5      # rendered pixels, weights, normals ... HIP vs the float32 reference arithmetic (north_star: <= 1e-5)
+DIRECT_GRAD = 5e-4     # gradients, HIP vs the float32 reference arithmetic (measured values are printed; order noise + ReLU flips)
 
 
 def _leaves(P):
@@ -82,9 +84,13 @@ def _case(dev, oracle, G, stage, n_rays, ray_seed, label):
     rows, bad = [], []
 
     def check(name, a_hip, a32, a64):
-        e_hip, e_ref = rel_l2(a_hip, a64), rel_l2(a32, a64)
-        ok = e_hip <= 2.0 * e_ref + FLOOR
-        rows.append((name, e_hip, e_ref, ok))
+        e_hip, e_ref, e_dir = rel_l2(a_hip, a64), rel_l2(a32, a64), rel_l2(a_hip, a32)
+        # second bar, direct: the yardstick can be loose where float32 itself is (the NeuS alpha is a difference of two
+        # sigmoids, so d alpha / d sdf cancels badly in float32 and BOTH float32 evaluations sit 1e-3..1e-2 from float64):
+        # there a wrong kernel could hide under e_ref, so HIP must also sit within DIRECT of the float32 reference
+        # arithmetic itself (same formulas, only summation order / ReLU-flip noise apart)
+        ok = e_hip <= 2.0 * e_ref + FLOOR and e_dir <= (DIRECT_GRAD if name.startswith('grad') else DIRECT_OUT)
+        rows.append((name, e_hip, e_ref, e_dir, ok))
         if not ok:
             bad.append(name)
     for key in ('rgb_marched', 'sigmoid_rgb', 'alphainv_cum'):
@@ -96,9 +102,9 @@ def _case(dev, oracle, G, stage, n_rays, ray_seed, label):
         check('grad ' + k, hip[k], L32[k].grad, L64[k].grad)
     print(f"\n[{label}] rays {n_rays}, in-bbox samples {r32['n_inbbox']}, survivors {r32['weights'].shape[0]}, "
           f"kept-sample differences {n_flips}")
-    print("    %-24s %-12s %-12s" % ("tensor", "e_hip", "e_ref(f32 vs f64)"))
-    for name, e_hip, e_ref, ok in rows:
-        print("    %-24s %-12.3e %-12.3e %s" % (name, e_hip, e_ref, "" if ok else "  <-- above 2 x e_ref + floor"))
+    print("    %-24s %-12s %-18s %-12s" % ("tensor", "e_hip", "e_ref(f32 vs f64)", "HIP vs f32"))
+    for name, e_hip, e_ref, e_dir, ok in rows:
+        print("    %-24s %-12.3e %-18.3e %-12.3e %s" % (name, e_hip, e_ref, e_dir, "" if ok else "  <-- out of tolerance"))
     assert res['weights'].shape[0] > 5_000
     assert not bad, bad
     # the north_star's own bars, flat: rendered pixels <= 1e-5 rel-L2 vs the float32 reference arithmetic

@@ -172,3 +172,26 @@ def test_degenerate_batches(dev, stage, fused):
     # the fused compositing is a fixed-order per-ray reduction; the operator form sums with atomics (index_add_)
     same = torch.equal if fused else (lambda x, y: torch.allclose(x, y, atol=1e-6))
     assert same(a['rgb_marched'], b['rgb_marched']) and bool(torch.isfinite(a['rgb_marched']).all())
+
+
+def test_maskcache_ray_prefilter_on_the_device_matches_reference_fixture(dev, golden):
+    """nerf_ray.get_training_rays_in_maskcache_sampling with the PRODUCT model (sample_ray_ori in torch on the device,
+    MaskCache through the HIP trilinear kernel) against the fixture the reference's own model/nerf_ray.py:208-250 produced
+    (oracle/make_golden.py make_maskcache_rays): same kept rays, same order, same values."""
+    import numpy as np
+    from fgs_nerf_amd import nerf_ray, synth
+    from fgs_nerf_amd.nerf import MaskCache
+    g = golden("maskcache_rays.npz")
+    G = int(g["G"])
+    model = synth.build_model(G, synth.FINE_MODEL, device=dev)
+    model.mask_cache = MaskCache(path=None, mask_cache_thres=float(g["thres"]), sdf_mask=torch.from_numpy(g["sdf_mask"]),
+                                 xyz_min=g["xyz_min"], xyz_max=g["xyz_max"]).to(dev)
+    assert torch.equal(model.voxel_size.cpu(), torch.from_numpy(g["voxel_size"]))
+    images = [torch.from_numpy(g[f"image{i}"]).to(dev) for i in range(3)]
+    rgb_tr, ro, rd, vd, imsz = nerf_ray.get_training_rays_in_maskcache_sampling(
+        images, torch.from_numpy(g["poses"]), g["HW"], g["Ks"], False, False, False, False, model,
+        dict(near=float(g["near"]), far=float(g["far"]), stepsize=float(g["stepsize"])))
+    assert [int(n) for n in imsz] == g["imsz"].tolist()
+    assert ro.is_cuda and rgb_tr.is_cuda
+    for got, key in ((rgb_tr, "rgb_tr"), (ro, "rays_o_tr"), (rd, "rays_d_tr"), (vd, "viewdirs_tr")):
+        assert np.array_equal(got.cpu().numpy(), g[key]), key
