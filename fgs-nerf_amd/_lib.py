@@ -42,6 +42,8 @@ _SIGNATURES = {
     "fgs_mlp_fwd_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P],
     "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
+    "fgs_set_row_count_ptr": [P],
+    "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -88,6 +90,15 @@ _SIGNATURES = {
 _lib = None
 
 
+class RcLayer(ctypes.Structure):
+    """fgs_rc_layer_t (include/fgs_hip.h): one Linear layer of a register-resident MLP chain."""
+    _fields_ = [("W", c_void_p), ("ldw", c_int64), ("n_out", c_int), ("n_in", c_int),
+                ("bias", c_void_p), ("relu", c_int),
+                ("mask_bits", c_void_p),
+                ("out", c_void_p), ("ldo", c_int64), ("n_store", c_int),
+                ("ext", c_void_p), ("ld_ext", c_int64), ("ext_cols", c_int)]
+
+
 class FgsError(RuntimeError):
     """A libfgs_hip.so entry point returned a non-zero status."""
 
@@ -95,7 +106,7 @@ class FgsError(RuntimeError):
 def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
-                                          "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats"])
+                                          "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats"])
 
 
 def lib() -> ctypes.CDLL:
@@ -117,6 +128,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_gemm_workspace_bytes.argtypes = []
         handle.fgs_head_bwd_scratch_floats.restype = c_int64
         handle.fgs_head_bwd_scratch_floats.argtypes = [c_int]
+        handle.fgs_mlp_rc_image_floats.restype = c_int64
+        handle.fgs_mlp_rc_image_floats.argtypes = [c_int, c_int, c_void_p]
         handle.fgs_mc_num_blocks.restype = c_int64
         handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -6,6 +6,14 @@
 
 namespace {
 thread_local char g_last_error[512] = "";
+thread_local const int64_t *g_row_ptr = nullptr;
+}
+
+const int64_t *fgs_row_ptr() { return g_row_ptr; }
+
+FGS_API int fgs_set_row_count_ptr(const int64_t *count_dev) {
+  g_row_ptr = count_dev;
+  return 0;
 }
 
 int fgs_set_error(int code, const char *fmt, ...) {

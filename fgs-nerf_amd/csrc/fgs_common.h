@@ -29,6 +29,9 @@ int fgs_set_error(int code, const char *fmt, ...);
 
 static inline hipStream_t fgs_s(fgs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Dynamic row count (fgs_set_row_count_ptr): the device pointer launches are currently issued under, or NULL.
+const int64_t *fgs_row_ptr();
+
 constexpr int FGS_WAVE = 64;      // gfx950 wavefront
 constexpr int FGS_BLOCK = 256;    // 4 waves: one per SIMD of a CU
 constexpr int64_t FGS_MAX_ELEMS = (int64_t)1 << 40;
@@ -38,6 +41,14 @@ static inline unsigned fgs_blocks(int64_t n, int per_block = FGS_BLOCK) {
 }
 
 // ------------------------------------------------------------------------------------ device
+
+// Rows a kernel really has to process: the host count, or -- under fgs_set_row_count_ptr -- the device count clamped to
+// the capacity the host count then stands for.  A wave-uniform scalar load.
+__device__ __forceinline__ int64_t fgs_rows(int64_t host_or_capacity, const int64_t *__restrict__ count_dev) {
+  if (!count_dev) return host_or_capacity;
+  const int64_t m = *count_dev;
+  return m < host_or_capacity ? (m < 0 ? 0 : m) : host_or_capacity;
+}
 
 struct GridDesc {
   int64_t C, X, Y, Z;      // logical [1,C,X,Y,Z]

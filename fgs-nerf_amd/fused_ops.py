@@ -96,3 +96,42 @@ def transpose_multi(mats) -> list:
          IntArr(*[w.shape[1] for w in mats]), I64Arr(*[w.stride(0) for w in mats]), PtrArr(*[ptr(o) for o in outs]),
          I64Arr(*[o.stride(0) for o in outs]), stream())
     return outs
+
+
+_RC_IMAGES = {}   # (device index, stream handle, backward) -> packed-weight scratch of the register-resident chains
+
+
+def rc_mask_bits(M: int, device) -> torch.Tensor:
+    """Buffer for the ReLU sign bits of one layer of `rc_chain` (16 bytes per lane of every 32-sample group)."""
+    return torch.empty(((M + 31) // 32 + 4) * 64 * 4, dtype=torch.int32, device=device)
+
+
+def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers) -> None:
+    """Register-resident MLP chain (include/fgs_hip.h fgs_mlp_rc_chain).  `layers`: list of dicts with W (the nn.Linear
+    weight [n_out, >= n_in], any leading dimension) and optional n_in (default W.shape[1]), bias, relu, mask_bits (int32
+    buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext ([M, >= ext_cols] view) / ext_cols."""
+    import ctypes
+    from ._lib import RcLayer
+    n = len(layers)
+    arr = (RcLayer * n)()
+    for i, l in enumerate(layers):
+        W = l['W']
+        arr[i].W, arr[i].ldw, arr[i].n_out = ptr(W), W.stride(0), W.shape[0]
+        arr[i].n_in = int(l.get('n_in', W.shape[1]))
+        arr[i].bias, arr[i].relu = ptr(l.get('bias')), int(bool(l.get('relu', False)))
+        arr[i].mask_bits = ptr(l.get('mask_bits'))
+        out = l.get('out')
+        arr[i].out, arr[i].ldo = ptr(out), (0 if out is None else out.stride(0))
+        arr[i].n_store = int(l.get('n_store', 0 if out is None else out.shape[1]))
+        ext = l.get('ext')
+        arr[i].ext, arr[i].ld_ext = ptr(ext), (0 if ext is None else ext.stride(0))
+        arr[i].ext_cols = int(l.get('ext_cols', 0 if ext is None else ext.shape[1]))
+    need = int(lib().fgs_mlp_rc_image_floats(int(backward), n, ctypes.cast(arr, ctypes.c_void_p)))
+    if need < 0:
+        raise RuntimeError("rc_chain: bad layer list")
+    key = (in0.device.index, stream(), bool(backward))
+    ws = _RC_IMAGES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
+    call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0), in0_cols,
+         ptr(ws), ws.numel(), stream())

@@ -36,6 +36,14 @@ int fgs_version(void);                       /* ABI version, currently 1 */
 /* Fills name (<=255 chars + NUL), CU count, wavefront size, LDS bytes per CU. */
 int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wave_size, int64_t *lds_bytes);
 
+/* Dynamic row count (sync-free / graph-capturable steps).  The survivor count M_s of a step lives in
+ * device memory (the last entry of the march kernels' survivor offsets).  While a pointer is set (per host thread), every
+ * entry point below that takes a per-survivor row count treats the HOST value as the CAPACITY of its buffers -- it sizes
+ * the grid for it -- and the kernels read the ACTUAL count min(*count, capacity) from the device: the host never needs the
+ * number, so nothing in a step waits for a device->host copy and the whole step can be captured in a hipGraph.
+ * NULL (the default) restores plain host counts.  The pointer must stay valid while launches issued under it run. */
+int fgs_set_row_count_ptr(const int64_t *count_dev);
+
 /* ---------------------------------------------------------------------------------
  * render_utils_cuda  (model/cuda/render_utils.cpp:170-184)
  * ------------------------------------------------------------------------------ */
@@ -237,6 +245,31 @@ int fgs_linear_bwd_f32(int64_t M, int64_t N_out, int64_t K_in, const float *dY, 
 int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int k0, const float *T, int64_t ldt, int t_cols,
                     const float *const *W, const int64_t *ldw, const int *K, const float *const *bias, const int *relu,
                     float *const *outs, const int64_t *ldo, fgs_stream_t stream);
+/* The MLP chains with the activations resident in REGISTERS (csrc/mlp_rc.hip): every product is computed transposed,
+ * features x samples, so that a layer's accumulator registers are the next layer's matrix-core operand as they stand; the
+ * weights stream through LDS by LDS-DMA.  One persistent launch (plus a small weight-packing launch) per chain.
+ *   backward = 0:  x_0 = in0[M, in0_cols];  x_{l+1} = act_l([x_l | ext_l] . W_l^T + bias_l)      (nn.Linear forward)
+ *   backward = 1:  g_0 = in0[M, n_out_0];   g_{l+1} = (g_l . W_l) with the elements whose bit in mask_bits_l is 0 zeroed
+ * W_l is the nn.Linear weight [n_out][ldw] (n_in valid columns) in both directions (the packing transposes).  A layer's
+ * input is the first min(256, width) columns of the previous output, carried in registers; forward layers may append
+ * ext_cols <= 64 columns read from `ext` (refnet's reflection encoding).  Widths up to 320 (forward n_out <= 256).
+ *   out / ldo / n_store : row-major copy of the layer output (first n_store columns, multiple of 4), or NULL
+ *   mask_bits           : forward + relu: receives one bit per output element (1 = positive), [ceil(M / 32)][64] x 16 bytes,
+ *                         in the kernel's register order; backward: the bits to apply (those the forward wrote for the layer
+ *                         whose input gradient this is); NULL: none
+ *   image_ws            : scratch for the packed weight images, fgs_mlp_rc_image_floats() floats, 16-byte aligned
+ * Honours fgs_set_row_count_ptr (M = capacity).  The reduction order of a sum differs from fgs_gemm_f32's (pairs (k, k+4));
+ * results are deterministic but not bit-identical to the LDS-resident chain. */
+typedef struct fgs_rc_layer {
+  const float *W; int64_t ldw; int n_out, n_in;
+  const float *bias; int relu;
+  void *mask_bits;
+  float *out; int64_t ldo; int n_store;
+  const float *ext; int64_t ld_ext; int ext_cols;
+} fgs_rc_layer_t;
+int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers);
+int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0, int64_t ld_in0,
+                     int in0_cols, float *image_ws, int64_t image_ws_floats, fgs_stream_t stream);
 /* The general form of the one-launch chain, also used for the BACKWARD data gradients (dY of the top layer in, transposed
  * weights, per layer the ReLU mask of the layer below = its saved input, and the column sums = that layer's bias gradient):
  *   W[l] [n_rows[l] <= 256, ldw[l]]: output column n uses weight row n (only the last layer may have fewer than 256 rows);

@@ -1,0 +1,41 @@
+"""Micro-benchmark of the MLP forward chains at the bench's survivor counts: register-resident (fgs_mlp_rc_chain) vs the
+LDS-resident persistent kernel (fgs_mlp_fwd_f32).  Interleaved rounds in one process, HIP events."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fgs_nerf_amd import fused_ops as fo
+
+dev = torch.device('cuda:0')
+for M in (49920, 58430, 65536, 32768):
+    torch.manual_seed(0)
+    X0 = torch.randn(M, 108, device=dev); X0[:, 106:] = 0
+    Z = torch.randn(M, 308, device=dev); Z[:, 307] = 0
+    Ks = [106, 256, 256, 256, 307, 256, 256]
+    Ws = [torch.randn(256, k, device=dev) * 0.06 for k in Ks]
+    bs = [torch.randn(256, device=dev) * 0.1 for _ in Ks]
+    relu = [1, 1, 1, 0, 1, 1, 1]
+    outs = [torch.empty(M, 256, device=dev) for _ in Ks]; outs[3] = Z
+    bits = [fo.rc_mask_bits(M, dev) for _ in Ks]
+    rc_layers = []
+    for i in range(7):
+        L = dict(W=Ws[i], bias=bs[i], relu=relu[i], mask_bits=bits[i] if relu[i] else None, out=outs[i], n_store=256)
+        if i == 4: L.update(ext=Z[:, 256:], ext_cols=52)
+        rc_layers.append(L)
+    W0p = torch.nn.functional.pad(Ws[0], (0, 2)); V0p = torch.nn.functional.pad(Ws[4], (0, 1))
+    old_layers = [(W0p if i == 0 else V0p if i == 4 else Ws[i], 108 if i == 0 else 308 if i == 4 else 256, bs[i], relu[i], outs[i]) for i in range(7)]
+    flop = 2.0 * M * 256 * sum(Ks)
+    def run_rc(): fo.rc_chain(False, M, X0, 108, rc_layers)
+    def run_old(): fo.mlp_fwd(M, X0, 108, Z[:, 256:], 52, old_layers)
+    res = {}
+    for name, fn in (("rc", run_rc), ("lds", run_old)):
+        for _ in range(3): fn()
+    for rnd in range(5):
+        for name, fn in (("rc", run_rc), ("lds", run_old)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): fn()
+            e1.record(); torch.cuda.synchronize()
+            res.setdefault(name, []).append(e0.elapsed_time(e1) / 5 * 1e3)
+    for name, v in res.items():
+        v = sorted(v)
+        print(f"M={M} {name:4s} median {v[len(v)//2]:8.1f} us  min {v[0]:8.1f} us  -> {flop / (v[len(v)//2] * 1e-6) / 1e12:6.1f} TFLOP/s", flush=True)

@@ -1,0 +1,160 @@
+"""GPU tests of the register-resident MLP chains (csrc/mlp_rc.hip, fgs_mlp_rc_chain) against float64 torch: forward
+(bias, ReLU, appended columns, saved activations, ReLU sign bits), backward data gradients (transposed images, masks from
+the forward's bits, narrow and 308-wide outputs), ragged M, padding columns holding NaN, coarse-stage widths, and the
+device-side row count (fgs_set_row_count_ptr)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _fine_setup(M, dev, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    X0 = r(M, 108).to(dev)
+    X0[:, 106:] = float('nan')                       # padding columns of the operand buffer: must be ignored
+    Z = torch.full((M, 308), float('nan'), device=dev)
+    Z[:, 256:307] = r(M, 51).to(dev)
+    Ws = [r(256, 106) * 0.1, r(256, 256) * 0.06, r(256, 256) * 0.06, r(256, 256) * 0.06, r(256, 307) * 0.06,
+          r(256, 256) * 0.06, r(256, 256) * 0.06]
+    Ws = [w.to(dev) for w in Ws]
+    bs = [(r(256) * 0.1).to(dev) for _ in Ws]
+    relu = [1, 1, 1, 0, 1, 1, 1]
+    return X0, Z, Ws, bs, relu
+
+
+def _forward(M, X0, Z, Ws, bs, relu, dev, cap=None):
+    from fgs_nerf_amd import fused_ops as fo
+    cap = cap or M
+    outs = [torch.full((cap, 256), float('nan'), device=dev) for _ in Ws]
+    outs[3] = Z                                       # the last rgbnet layer writes Z[:, :256]
+    bits = [fo.rc_mask_bits(cap, dev) if relu[i] else None for i in range(7)]
+    layers = []
+    for i in range(7):
+        L = dict(W=Ws[i], bias=bs[i], relu=relu[i], mask_bits=bits[i], out=outs[i], n_store=256)
+        if i == 4:
+            L.update(ext=Z[:, 256:], ext_cols=52)
+        layers.append(L)
+    fo.rc_chain(False, cap, X0, 108, layers)
+    return outs, bits
+
+
+def _reference_forward(X0, Z, Ws, bs, relu):
+    x = X0[:, :106].double()
+    acts = []
+    for i in range(7):
+        if i == 4:
+            x = torch.cat([x, Z[:, 256:307].double()], 1)
+        x = x @ Ws[i].double().T + bs[i].double()
+        if relu[i]:
+            x = torch.relu(x)
+        acts.append(x)
+    return acts
+
+
+def _unpack_bits(bits, M):
+    """[groups][64 lanes] x 4 words -> bool [M][256] in (sample, feature) order (the kernel's register layout)."""
+    w = bits.view(-1, 64, 4).cpu().to(torch.int64) & 0xffffffff
+    G = w.shape[0]
+    out = torch.zeros(G * 32, 256, dtype=torch.bool)
+    for t in range(8):
+        for r in range(16):
+            word, sh = t >> 1, (t & 1) * 16 + r
+            b = ((w[:, :, word] >> sh) & 1).bool()            # [G][64]
+            for h in range(2):
+                f = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)
+                out[:, f] = b[:, 32 * h:32 * h + 32].reshape(-1)
+    return out[:M]
+
+
+@pytest.mark.parametrize("M", [1, 31, 33, 128, 129, 1000, 50001])
+def test_rc_forward_matches_fp64(dev, M):
+    X0, Z, Ws, bs, relu = _fine_setup(M, dev, seed=M)
+    outs, bits = _forward(M, X0, Z, Ws, bs, relu, dev)
+    ref = _reference_forward(X0, Z, Ws, bs, relu)
+    for i in range(7):
+        got = outs[i][:, :256]
+        assert bool(torch.isfinite(got).all()), i
+        assert rel_l2(got, ref[i]) < 2e-6, (i, rel_l2(got, ref[i]))
+    assert bool(torch.isfinite(Z[:, 256:307]).all()) and bool(torch.isnan(Z[:, 307]).all())   # appended columns untouched
+    for i in (0, 1, 2, 4, 5, 6):
+        assert torch.equal(_unpack_bits(bits[i], M), (outs[i][:, :256] > 0).cpu()), i
+
+
+@pytest.mark.parametrize("M", [1, 100, 4097])
+def test_rc_backward_matches_fp64(dev, M):
+    from fgs_nerf_amd import fused_ops as fo
+    X0, Z, Ws, bs, relu = _fine_setup(M, dev, seed=M + 3)
+    outs, bits = _forward(M, X0, Z, Ws, bs, relu, dev)
+    g = torch.Generator().manual_seed(M)
+    dY = torch.randn(M, 256, generator=g).to(dev)
+    # backward chain: layers 6 .. 0; the output of step i is masked by the ReLU of layer i - 1 (none below layers 4 and 0)
+    d5, d4 = (torch.full((M, 256), float('nan'), device=dev) for _ in range(2))
+    dZ = torch.full((M, 308), float('nan'), device=dev)
+    d2, d1, d0 = (torch.full((M, 256), float('nan'), device=dev) for _ in range(3))
+    dX0 = torch.full((M, 108), float('nan'), device=dev)
+    layers = [dict(W=Ws[6], mask_bits=bits[5], out=d5, n_store=256), dict(W=Ws[5], mask_bits=bits[4], out=d4, n_store=256),
+              dict(W=Ws[4], out=dZ, n_store=308), dict(W=Ws[3], mask_bits=bits[2], out=d2, n_store=256),
+              dict(W=Ws[2], mask_bits=bits[1], out=d1, n_store=256), dict(W=Ws[1], mask_bits=bits[0], out=d0, n_store=256),
+              dict(W=Ws[0], out=dX0, n_store=108)]
+    fo.rc_chain(True, M, dY, 256, layers)
+    acts = [o[:, :256].double() for o in outs]
+    gcur = dY.double()
+    refs = []
+    for i in range(6, -1, -1):
+        gcur = gcur @ Ws[i].double()
+        if i in (6, 5, 3, 2, 1):
+            gcur = gcur * (acts[i - 1] > 0)
+        refs.append(gcur)
+        if i == 4:
+            gcur = gcur[:, :256]
+    for got, ref, n in zip((d5, d4, dZ, d2, d1, d0, dX0), refs, (256, 256, 307, 256, 256, 256, 106)):
+        assert rel_l2(got[:, :n], ref[:, :n]) < 2e-6, (n, rel_l2(got[:, :n], ref[:, :n]))
+    assert float(dZ[:, 307].abs().max()) == 0.0 and float(dX0[:, 106:].abs().max()) == 0.0   # padding columns: exact zeros
+
+
+@pytest.mark.parametrize("width,n_in,M", [(192, 90, 777), (128, 72, 513)])
+def test_rc_coarse_widths(dev, width, n_in, M):
+    """The coarse (90 -> 192 -> 192) and geometry_searching (72 -> 128 -> 128) refnet trunks (config/shiny_blender.py:90-92,
+    163-167): widths that are not 256, forward and backward."""
+    from fgs_nerf_amd import fused_ops as fo
+    g = torch.Generator().manual_seed(width)
+    ld = (n_in + 3) // 4 * 4
+    X0 = torch.randn(M, ld, generator=g).to(dev)
+    X0[:, n_in:] = float('nan')
+    W0, W1 = (torch.randn(width, n_in, generator=g) * 0.1).to(dev), (torch.randn(width, width, generator=g) * 0.08).to(dev)
+    b0, b1 = (torch.randn(width, generator=g) * 0.1).to(dev), (torch.randn(width, generator=g) * 0.1).to(dev)
+    o0, o1 = (torch.full((M, width), float('nan'), device=dev) for _ in range(2))
+    m0, m1 = fo.rc_mask_bits(M, dev), fo.rc_mask_bits(M, dev)
+    fo.rc_chain(False, M, X0, ld, [dict(W=W0, bias=b0, relu=1, mask_bits=m0, out=o0, n_store=width),
+                                   dict(W=W1, bias=b1, relu=1, mask_bits=m1, out=o1, n_store=width)])
+    r0 = torch.relu(X0[:, :n_in].double() @ W0.double().T + b0.double())
+    r1 = torch.relu(r0 @ W1.double().T + b1.double())
+    assert rel_l2(o0, r0) < 2e-6 and rel_l2(o1, r1) < 2e-6
+    dY = torch.randn(M, width, generator=g).to(dev)
+    d0 = torch.full((M, width), float('nan'), device=dev)
+    dX0 = torch.full((M, ld), float('nan'), device=dev)
+    fo.rc_chain(True, M, dY, width, [dict(W=W1, mask_bits=m0, out=d0, n_store=width), dict(W=W0, out=dX0, n_store=ld)])
+    g0 = (dY.double() @ W1.double()) * (r0 > 0)
+    assert rel_l2(d0, g0) < 2e-6 and rel_l2(dX0[:, :n_in], g0 @ W0.double()) < 2e-6
+
+
+def test_rc_device_row_count(dev):
+    """fgs_set_row_count_ptr: the host count is only the capacity; rows beyond the device count are never written, rows
+    below it are bit-identical to a plain launch with that count."""
+    from fgs_nerf_amd._lib import call
+    cap, M = 3000, 1777
+    X0, Z, Ws, bs, relu = _fine_setup(cap, dev, seed=5)
+    outs_a, _ = _forward(M, X0[:M].contiguous(), Z[:M].clone(), Ws, bs, relu, dev)
+    count = torch.tensor([M], dtype=torch.int64, device=dev)
+    call("fgs_set_row_count_ptr", count.data_ptr())
+    try:
+        Zb = Z.clone()
+        outs_b, _ = _forward(M, X0, Zb, Ws, bs, relu, dev, cap=cap)
+    finally:
+        call("fgs_set_row_count_ptr", None)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a[:M, :256], b[:M, :256])
+        assert bool(torch.isnan(b[M:, :256]).all())
