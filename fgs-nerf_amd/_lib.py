@@ -44,6 +44,7 @@ _SIGNATURES = {
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
     "fgs_set_row_count_ptr": [P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
+    "fgs_mlp_rc_debug_stamps": [P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],

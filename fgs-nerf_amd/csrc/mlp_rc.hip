@@ -39,7 +39,7 @@ constexpr int RC_MAXL = 8;            // layers per chain
 constexpr int RC_MAXCH = 80;          // chunks per pass over all layers
 constexpr int RC_THREADS = 256;
 constexpr int RC_SLOTS = 3;
-constexpr int RC_SLOT_FLOATS = 320 * 32;   // up to 320 rows x 32 columns
+constexpr int RC_SLOT_FLOATS = 256 * 32;   // 256 rows x 32 columns
 constexpr int RC_BLOCK = 128;         // samples per workgroup pass (4 waves x 32)
 
 struct RcLayer {
@@ -53,17 +53,20 @@ struct RcLayer {
   int64_t ld_ext;
   int ext_cols, ext_valid;
   const float *bias;
+  int bias_slot;               // row of the LDS bias table (zeros for a layer without bias)
   uint4 *mask_w;               // forward: sign bits of the ReLU input, [ceil(M / 32)][64] uint4
   const uint4 *mask_r;         // backward: bits applied to this layer's output
   float *out;
   int64_t ldo;
   int n_store;                 // leading output columns stored (multiple of 4)
+  int defer_store;             // the HBM copy of the output is issued from inside the next layer's chunks
 };
 
 struct RcArgs {
   int64_t M;
   const int64_t *m_dev;
   int n_layers, total_chunks;
+  unsigned long long *stamps;              // diagnostics (fgs_mlp_rc_debug_stamps): per workgroup {s_memtime, s_memrealtime} x 2
   const float *img;
   int chunk_piece0[RC_MAXCH];              // first 1 KB piece of chunk j in the image
   int chunk_pieces[RC_MAXCH];              // 1 KB pieces of chunk j (= rows_pad / 8).  (int, not a byte array: hipcc (ROCm 7.2)
@@ -118,122 +121,221 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_rc_pack(PackArgs a) {
 struct RcState {
   const RcArgs *a;
   float *ring;
-  int64_t issued, total_steps;
+  int64_t issued, done, total_steps;
   int issue_j, issue_slot, slot;
   int wave, lane;
+  // the chunk whose DMA is being issued piece by piece between the MFMAs of the running chunk
+  const float *dma_src;
+  float *dma_dst;
+  int dma_p, dma_pieces;
+  // output of the layer that just finished: its tiles (now the B operands in `prev`) are written to HBM tile by tile from
+  // inside the NEXT layer's chunks (a 128 KB burst per layer and workgroup is store-issue bound: ~12k idle cycles)
+  float *pend_row;            // this lane's output row (out + row * ldo), or null
+  int pend_nstore;
+  unsigned long long t_init, t_chunks, t_epi, t_load;   // diagnostics (fgs_mlp_rc_debug_stamps): shader cycles per phase
+  bool timed;
 };
 
-__device__ __forceinline__ void rc_dma(RcState &s) {
+// start the DMA of the next chunk of the stream (nothing is issued yet: rc_dma_piece does that)
+__device__ __forceinline__ void rc_dma_begin(RcState &s) {
   const RcArgs &a = *s.a;
-  const int pieces = a.chunk_pieces[s.issue_j];
-  const float *src = a.img + (int64_t)a.chunk_piece0[s.issue_j] * 256 + s.lane * 4;
-  float *dst = s.ring + s.issue_slot * RC_SLOT_FLOATS;
-  for (int p = s.wave; p < pieces; p += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 256),
-                                     (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+  s.dma_pieces = a.chunk_pieces[s.issue_j];
+  s.dma_src = a.img + (int64_t)a.chunk_piece0[s.issue_j] * 256 + s.lane * 4;
+  s.dma_dst = s.ring + s.issue_slot * RC_SLOT_FLOATS;
+  s.dma_p = s.wave;
   ++s.issued;
   s.issue_j = (s.issue_j + 1 == a.total_chunks) ? 0 : s.issue_j + 1;
   s.issue_slot = (s.issue_slot + 1 == RC_SLOTS) ? 0 : s.issue_slot + 1;
 }
 
-// one 32-column chunk: 16 k-steps x NTT row tiles.  B = the 16 registers of one input tile.
-// Tile-major order inside a k-group: the four MFMAs of a tile form a dependent chain on its accumulator (the 32x32x2 form
-// issues back to back on one accumulator: issue interval = dependent latency = 64 cycles), after which the tile's A
-// registers are free and the ds_read_b128 of the NEXT k-group lands in them while the other tiles' MFMAs run -- a single
-// A buffer of 4 NTT registers is enough to keep the LDS reads under the matrix work.
-template <int NTT>
-__device__ __forceinline__ void rc_chunk(const float *__restrict__ S, const int (&rdoff)[4], const floatx16 &B,
-                                         floatx16 (&acc)[NTT]) {
-  // software pipeline over the 4 NTT (k-group, tile) steps, three A registers in rotation: the ds_read_b128 of step i + 2
-  // is issued between the second and third MFMA of step i.  sched_barrier(0) pins that order (left alone, the scheduler
-  // sinks every read to its use and the matrix pipe waits for LDS four times per k-group).  hipcc drains lgkmcnt(0) in
-  // front of every third step; by then the youngest read has two MFMAs (128 cycles) behind it.
+// One 1 KB piece (this wave's next one) of the chunk being fetched.  BRANCH-FREE: when the wave has no piece left (a chunk
+// with fewer rows than the issue slots provide for, or the end of the stream) the instruction still executes, re-fetching
+// the chunk's first piece into a 1 KB dump area behind the ring -- straight-line code keeps hipcc's register allocation of
+// the 500-register loop body stable (with a uniform branch per slot it spilled a whole B tile to scratch inside the loop).
+__device__ __forceinline__ void rc_dma_piece(RcState &s) {
+  const bool ok = s.dma_p < s.dma_pieces;
+  const int p = ok ? s.dma_p : 0;
+  float *dst = ok ? s.dma_dst + p * 256 : s.ring + RC_SLOTS * RC_SLOT_FLOATS + s.wave * 256;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.dma_src + p * 256),
+                                   (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+  s.dma_p += 4;
+}
+
+__device__ __forceinline__ void rc_dma(RcState &s) {     // a whole chunk at once (prologue)
+  rc_dma_begin(s);
+  while (s.dma_p < s.dma_pieces) rc_dma_piece(s);
+}
+
+// One 32-column chunk: 16 k-steps x NTT row tiles = 4 NTT steps of four MFMAs each.  B = the 16 registers of one input tile.
+// Tile-major order inside a k-group: the four MFMAs of a step form a dependent chain on one accumulator (the 32x32x2 form
+// issues back to back on one accumulator: issue interval = dependent latency = 64 cycles).
+//
+// The A operands come through three registers in rotation (PHASE = rotation index of this chunk's step 0, a compile-time
+// constant): the ds_read_b128 of step i + 2 is issued between the second and third MFMA of step i, and the rotation runs
+// ACROSS chunks -- the last two steps read the first two operands of the NEXT chunk from its slot (S_next) -- so the matrix
+// pipe does not drain at a chunk boundary.  That is legal because the synchronisation sits in the MIDDLE of a chunk:
+// after step 2 NTT - 1 every wave waits for its own DMA pieces of the next chunk (issued a full chunk earlier) and meets
+// the others at the one s_barrier of the chunk.  Past it (a) the next chunk is complete in LDS for everybody and (b)
+// everybody has left the previous chunk, whose slot the chunk after next may overwrite: its DMA pieces are issued one at a
+// time between the MFMAs of the second half (issued in a burst in front of a chunk, the 8-10 LDS-DMA instructions of a wave
+// cost ~1000 cycles of idle matrix pipe per chunk).  sched_barrier(0) pins this order: left alone, hipcc sinks every LDS
+// read to its use and the pipe then waits for LDS after every step.
+template <int NTT, int PHASE, int NS, int STORE_TILE>
+__device__ __forceinline__ void rc_chunk(RcState &s, const float *__restrict__ S, const float *__restrict__ S_next,
+                                         const int (&rdoff)[4], const floatx16 &B, floatx16 (&acc)[NTT], float4 (&A)[3],
+                                         int h) {
   constexpr int STEPS = 4 * NTT;
-  float4 A[3];
-  A[0] = *reinterpret_cast<const float4 *>(S + rdoff[0]);
-  A[1] = *reinterpret_cast<const float4 *>(S + 1024 + rdoff[0]);
+  constexpr int HALF = STEPS / 2;
 #pragma unroll
   for (int i = 0; i < STEPS; ++i) {
     const int q = i / NTT, t = i % NTT;
-    const float4 a = A[i % 3];
+    const float4 a = A[(PHASE + i) % 3];
     __builtin_amdgcn_sched_barrier(0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * q + 0], acc[t], 0, 0, 0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * q + 1], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (i + 2 < STEPS) {
       const int q2 = (i + 2) / NTT, t2 = (i + 2) % NTT;
-      A[(i + 2) % 3] = *reinterpret_cast<const float4 *>(S + t2 * 1024 + rdoff[q2]);
+      A[(PHASE + i + 2) % 3] = *reinterpret_cast<const float4 *>(S + t2 * 1024 + rdoff[q2]);
+    } else if (S_next) {
+      A[(PHASE + i + 2) % 3] = *reinterpret_cast<const float4 *>(S_next + (i + 2 - STEPS) * 1024 + rdoff[0]);
+    }
+    if (STORE_TILE >= 0 && i < 4 * 2 && (i & 1) == 1) {       // steps 1, 3, 5, 7: the four float4 of the pending tile
+      const int qs = i >> 1;
+      const int col = 32 * STORE_TILE + 8 * qs + 4 * h;
+      if (s.pend_row && col < s.pend_nstore)
+        *reinterpret_cast<float4 *>(s.pend_row + col) = make_float4(B[4 * qs], B[4 * qs + 1], B[4 * qs + 2], B[4 * qs + 3]);
+    }
+    if (i >= HALF) {      // issue slot k of NS sits at step HALF + k * HALF / NS (compile-time)
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (HALF + (k * HALF) / NS == i) rc_dma_piece(s);
     }
     __builtin_amdgcn_sched_barrier(0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * q + 2], acc[t], 0, 0, 0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * q + 3], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if (i == STEPS / 2 - 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s.issued < s.total_steps) rc_dma_begin(s);
+      else s.dma_pieces = 0;                      // end of the stream: the issue slots only touch the dump area
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// 32 appended input columns (tile `c` of L.ext) of this lane's sample -> the 16 registers of a B tile
+__device__ __forceinline__ void rc_load_ext(const RcLayer &L, int c, int64_t rowc, int h, floatx16 &B) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = 32 * c + 8 * q + 4 * h;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < L.ext_cols) v = *reinterpret_cast<const float4 *>(L.ext + rowc * L.ld_ext + col);
+    if (col + 3 >= L.ext_valid) {      // padding columns of the buffer may hold anything: 0 * NaN would poison the sum
+      if (col + 1 >= L.ext_valid) v.y = 0.f;
+      if (col + 2 >= L.ext_valid) v.z = 0.f;
+      v.w = 0.f;
+      if (col >= L.ext_valid) v.x = 0.f;
+    }
+    B[4 * q] = v.x; B[4 * q + 1] = v.y; B[4 * q + 2] = v.z; B[4 * q + 3] = v.w;
+  }
+}
+
+// chunks C, C + 1, ... of a layer (compile-time recursion: the rotation phase of a chunk is a template argument).
+// Appended input columns (forward refnet layer 0: reduction chunks 8 and 9) need no registers of their own: input tile 0 is
+// dead once chunk 0 has run, tile 1 after chunk 1, so the appended columns are loaded into THOSE registers right there --
+// seven chunks (~25 us) before chunks 8 and 9 multiply by them.
+template <int NTT, bool BWD, int C>
+__device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
+                                          floatx16 (&acc)[NTT], float4 (&A)[3], int64_t rowc, int h) {
+  if constexpr (C < 10) {
+    if (C < L.nch) {
+      const float *S = s.ring + s.slot * RC_SLOT_FLOATS;
+      s.slot = (s.slot + 1 == RC_SLOTS) ? 0 : s.slot + 1;
+      ++s.done;
+      const float *S_next = (s.done < s.total_steps) ? s.ring + s.slot * RC_SLOT_FLOATS : nullptr;
+      constexpr int PH = (C * 4 * NTT) % 3;
+      constexpr int NS = 2 * NTT / 2;        // DMA issue slots per chunk = the 1 KB pieces a wave fetches per chunk (rows / 32)
+      // chunk C < 8 multiplies by input tile C = output tile C of the previous layer: its HBM copy goes out from here
+      rc_chunk<NTT, PH, NS, (C < 8 ? C : -1)>(s, S, S_next, rdoff, prev[C < 8 ? C : C - 8], acc, A, h);
+      if constexpr (!BWD && C < 2) {
+        if (L.ext) rc_load_ext(L, C, rowc, h, prev[C]);
+      }
+      rc_chunks<NTT, BWD, C + 1>(s, L, rdoff, prev, acc, A, rowc, h);
+    }
   }
 }
 
 template <int NTT, bool BWD>
 __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
-                                         floatx16 (&ext)[2], int64_t row, int64_t rowc, bool row_ok, int64_t group, int h) {
+                                         float4 (&A)[3], int64_t row, int64_t rowc, bool row_ok, int64_t group, int h) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (s.timed) t0 = __builtin_amdgcn_s_memtime();
   floatx16 acc[NTT];
-  // accumulators start at the bias
 #pragma unroll
   for (int t = 0; t < NTT; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = 32 * t + 8 * q + 4 * h;
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!BWD && L.bias && col < L.n_rows) b = *reinterpret_cast<const float4 *>(L.bias + col);
-      acc[t][4 * q] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
-    }
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
   if (BWD && L.mask_r) mbits = L.mask_r[group * 64 + s.lane];
-#pragma unroll
-  for (int c = 0; c < (BWD ? 8 : 10); ++c) {
-    if (c < L.nch) {
-      // chunk `c` of this layer has landed in every wave's share of the slot (each wave waits for its own DMA pieces, then
-      // the barrier); all waves are also past the previous chunk, whose slot the next DMA overwrites
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (s.issued < s.total_steps) rc_dma(s);
-      const float *S = s.ring + s.slot * RC_SLOT_FLOATS;
-      if (c < 8) rc_chunk<NTT>(S, rdoff, prev[c < 8 ? c : 0], acc);
-      else if (!BWD) rc_chunk<NTT>(S, rdoff, ext[c >= 8 ? c - 8 : 0], acc);
-      s.slot = (s.slot + 1 == RC_SLOTS) ? 0 : s.slot + 1;
-    }
+  if (s.timed) t1 = __builtin_amdgcn_s_memtime();
+  rc_chunks<NTT, BWD, 0>(s, L, rdoff, prev, acc, A, rowc, h);
+  if (s.timed) t2 = __builtin_amdgcn_s_memtime();
+  {   // the two operands prefetched for the next layer's first steps sit at rotation index (nch * 4 NTT) % 3: make that 0
+    const int ph = (L.nch * 4 * NTT) % 3;
+    if (ph == 1) { const float4 t0 = A[1], t1 = A[2]; A[0] = t0; A[1] = t1; }
+    else if (ph == 2) { const float4 t0 = A[2], t1 = A[0]; A[0] = t0; A[1] = t1; }
   }
-  // ---- epilogue: activation / mask, sign bits, store, hand the tile registers to the next layer
+  // ---- epilogue, one tile at a time: bias (from the LDS copy made at kernel start), activation / mask, sign bits, store;
+  // the tile's 16 VGPRs then ARE the next layer's B operand
+  // the HBM copy of this output is deferred into the next layer's chunks when that layer multiplies by all of its tiles
+  // (next.nch >= NTT); the last layer of the chain stores here
+  const bool defer = L.defer_store != 0;
+  s.pend_row = (defer && L.out && row_ok) ? L.out + row * L.ldo : nullptr;
+  s.pend_nstore = L.n_store;
   unsigned bits[4] = {0u, 0u, 0u, 0u};
   const unsigned mb[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
+  const float *bias_l = s.ring + RC_SLOTS * RC_SLOT_FLOATS + 4 * 256 + L.bias_slot * 256 + 4 * h;
 #pragma unroll
   for (int t = 0; t < NTT; ++t) {
+    floatx16 v = acc[t];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[t][r];
+    for (int q = 0; q < 4; ++q) {
       if (!BWD) {
-        if (L.relu) v = fmaxf(v, 0.f);
-        if (t < 8 && v > 0.f) bits[t >> 1] |= 1u << ((t & 1) * 16 + r);
-      } else if (t < 8) {
-        if (L.mask_r && !((mb[t >> 1] >> ((t & 1) * 16 + r)) & 1u)) v = 0.f;
+        const float4 b = *reinterpret_cast<const float4 *>(bias_l + 32 * t + 8 * q);
+        v[4 * q] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
       }
-      acc[t][r] = v;
-    }
-    if (L.out && row_ok) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = 32 * t + 8 * q + 4 * h;
-        if (col < L.n_store)
-          *reinterpret_cast<float4 *>(L.out + row * L.ldo + col) =
-              make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        if (!BWD) {
+          if (L.relu) v[r] = fmaxf(v[r], 0.f);
+          if (t < 8) bits[t >> 1] |= (v[r] > 0.f) ? (1u << ((t & 1) * 16 + r)) : 0u;
+        } else if (t < 8) {
+          if (L.mask_r && !((mb[t >> 1] >> ((t & 1) * 16 + r)) & 1u)) v[r] = 0.f;
+        }
       }
+      const int col = 32 * t + 8 * q + 4 * h;
+      if (!defer && L.out && row_ok && col < L.n_store)
+        *reinterpret_cast<float4 *>(L.out + row * L.ldo + col) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
-    if (t < 8) prev[t] = acc[t];
+    if (t < 8) prev[t] = v;
+    __builtin_amdgcn_sched_barrier(0);      // one tile at a time: 16 staging registers, not 128
   }
   if (!BWD && L.mask_w) L.mask_w[group * 64 + s.lane] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+  if (s.timed) {
+    s.t_init += t1 - t0; s.t_chunks += t2 - t1; s.t_epi += __builtin_amdgcn_s_memtime() - t2;
+  }
 }
 
-template <bool BWD>
+// One instantiation per (direction, row tiles per layer): every layer of a launch has the same padded output width, so the
+// kernel holds ONE copy of the 4 NTT-step loop body (with the layers' tile counts switched at run time, hipcc's register
+// allocation over three inlined bodies spilled B tiles to scratch inside the loop).
+template <bool BWD, int NTT>
 __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
-  __shared__ __attribute__((aligned(16))) float ring[RC_SLOTS * RC_SLOT_FLOATS];
+  // ring | 1 KB dump area per wave | bias table [RC_MAXL + 1][256] (row RC_MAXL: zeros)
+  __shared__ __attribute__((aligned(16))) float ring[RC_SLOTS * RC_SLOT_FLOATS + 4 * 256 + (RC_MAXL + 1) * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -241,23 +343,42 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   const int64_t nb = (M + RC_BLOCK - 1) / RC_BLOCK;
   if ((int64_t)blockIdx.x >= nb) return;
   const int64_t my_blocks = (nb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  if (a.stamps && tid == 0) {
+    a.stamps[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    a.stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   RcState s;
   s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = my_blocks * a.total_chunks;
-  s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane;
+  s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane; s.done = 0;
+  s.dma_p = 0; s.dma_pieces = 0; s.dma_src = a.img + lane * 4; s.dma_dst = ring;
+  s.pend_row = nullptr; s.pend_nstore = 0;
+  s.timed = a.stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
   rc_dma(s);
   if (s.total_steps > 1) rc_dma(s);
+  {   // bias table -> LDS, once (a layer's epilogue then reads 16 bytes per output group instead of waiting on HBM)
+    float *bt = ring + RC_SLOTS * RC_SLOT_FLOATS + 4 * 256;
+    for (int i = tid; i < (RC_MAXL + 1) * 256; i += RC_THREADS) {
+      const int l = i >> 8, c = i & 255;
+      float v = 0.f;
+      if (!BWD && l < a.n_layers && a.L[l].bias && c < a.L[l].n_rows) v = a.L[l].bias[c];
+      bt[i] = v;
+    }
+  }
   int rdoff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) rdoff[q] = l31 * 32 + 4 * ((2 * q + h) ^ ((l31 >> 1) & 7));
-  floatx16 prev[8], ext[2];
+  // chunks 0 and 1 of the stream are in flight; the first mid-chunk barrier (inside chunk 0) covers chunk 1, this one chunk 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float4 A[3];
+  A[0] = *reinterpret_cast<const float4 *>(ring + rdoff[0]);
+  A[1] = *reinterpret_cast<const float4 *>(ring + 1024 + rdoff[0]);
+  A[2] = A[0];
+  floatx16 prev[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) prev[t][r] = 0.f;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ext[t][r] = 0.f;
 
   for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
     const int64_t group = b * 4 + wave;                  // 32-sample group of this wave
@@ -266,6 +387,8 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
     const int64_t rowc = row_ok ? row : M - 1;           // loads of padding samples read a valid row; their results are dropped
     for (int l = 0; l < a.n_layers; ++l) {
       const RcLayer &L = a.L[l];
+      unsigned long long tl = 0;
+      if (s.timed) tl = __builtin_amdgcn_s_memtime();
       if (L.in) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -283,42 +406,36 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
             prev[c][4 * q] = v.x; prev[c][4 * q + 1] = v.y; prev[c][4 * q + 2] = v.z; prev[c][4 * q + 3] = v.w;
           }
       }
-      if (!BWD && L.ext) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int col = 32 * c + 8 * q + 4 * h;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < L.ext_cols) v = *reinterpret_cast<const float4 *>(L.ext + rowc * L.ld_ext + col);
-            if (col + 3 >= L.ext_valid) {
-              if (col + 1 >= L.ext_valid) v.y = 0.f;
-              if (col + 2 >= L.ext_valid) v.z = 0.f;
-              v.w = 0.f;
-              if (col >= L.ext_valid) v.x = 0.f;
-            }
-            ext[c][4 * q] = v.x; ext[c][4 * q + 1] = v.y; ext[c][4 * q + 2] = v.z; ext[c][4 * q + 3] = v.w;
-          }
-      }
-      switch (L.nt) {      // (a forward layer has at most 8 row tiles; only a backward layer can have 10: refnet's dZ)
-        case 4: rc_layer<4, BWD>(s, L, rdoff, prev, ext, row, rowc, row_ok, group, h); break;
-        case 6: rc_layer<6, BWD>(s, L, rdoff, prev, ext, row, rowc, row_ok, group, h); break;
-        case 10: if (BWD) { rc_layer<BWD ? 10 : 8, BWD>(s, L, rdoff, prev, ext, row, rowc, row_ok, group, h); break; }
-        default: rc_layer<8, BWD>(s, L, rdoff, prev, ext, row, rowc, row_ok, group, h); break;
-      }
+      if (s.timed) s.t_load += __builtin_amdgcn_s_memtime() - tl;
+      rc_layer<NTT, BWD>(s, L, rdoff, prev, A, row, rowc, row_ok, group, h);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (a.stamps && tid == 0) {
+    a.stamps[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    a.stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    a.stamps[8 * blockIdx.x + 4] = s.t_init; a.stamps[8 * blockIdx.x + 5] = s.t_chunks;
+    a.stamps[8 * blockIdx.x + 6] = s.t_epi; a.stamps[8 * blockIdx.x + 7] = s.t_load;
+  }
 }
+
+unsigned long long *g_rc_stamps = nullptr;
 
 bool rc_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int rc_round_tiles(int rows) {   // output rows -> instantiated tile count
   const int t = (rows + 31) / 32;
-  return t <= 4 ? 4 : t <= 6 ? 6 : t <= 8 ? 8 : 10;
+  return t <= 4 ? 4 : t <= 6 ? 6 : t <= 8 ? 8 : 10;   // 10: rejected by the launcher
 }
 
 }  // namespace
+
+// Diagnostics: while set, every workgroup of the chain kernels records {shader clock, 100 MHz wall clock} at its start and
+// end into stamps[4 * workgroup ..] (>= 8 * 256 entries); in-kernel clock = d(shader) / d(wall) * 100 MHz.  NULL: off.
+FGS_API int fgs_mlp_rc_debug_stamps(unsigned long long *stamps) {
+  g_rc_stamps = stamps;
+  return 0;
+}
 
 FGS_API int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers) {
   if (!layers || n_layers < 1 || n_layers > RC_MAXL) return -1;
@@ -344,7 +461,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
               (long long)image_ws_floats, (long long)need);
   RcArgs a;
   PackArgs p;
-  a.M = M; a.m_dev = fgs_row_ptr(); a.n_layers = n_layers; a.img = image_ws;
+  a.M = M; a.m_dev = fgs_row_ptr(); a.n_layers = n_layers; a.img = image_ws; a.stamps = g_rc_stamps;
   p.n_layers = n_layers; p.transpose = backward ? 1 : 0; p.img = image_ws;
   int carried = in0_cols;            // columns of the input carried in registers
   int64_t base = 0, f4 = 0;
@@ -353,7 +470,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     const fgs_rc_layer_t &U = layers[l];
     FGS_REQUIRE(U.W && U.n_out > 0 && U.n_in > 0 && U.ldw >= U.n_in, FGS_E_INVALID, "fgs_mlp_rc_chain: layer %d: bad weight", l);
     const int rows = backward ? U.n_in : U.n_out, k = backward ? U.n_out : U.n_in;
-    FGS_REQUIRE(rows <= 320 && k <= 320, FGS_E_RANGE, "fgs_mlp_rc_chain: layer %d: %d x %d beyond 320 x 320", l, rows, k);
+    FGS_REQUIRE(rows <= 256 && k <= 320, FGS_E_RANGE, "fgs_mlp_rc_chain: layer %d: %d x %d beyond 256 x 320", l, rows, k);
     const int ext_cols = backward ? 0 : U.ext_cols;
     // the input may be padded to a multiple of 4 columns (X0: 106 -> 108, refnet: 256 + 51 -> 256 + 52); the padding is
     // zeroed on load
@@ -370,6 +487,9 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     FGS_REQUIRE(backward || (rows % 4) == 0, FGS_E_INVALID, "fgs_mlp_rc_chain: layer %d: n_out must be a multiple of 4", l);
     RcLayer &L = a.L[l];
     L.nt = rc_round_tiles(rows);
+    FGS_REQUIRE(L.nt <= 8 && (l == 0 || L.nt == a.L[0].nt), FGS_E_INVALID,
+                "fgs_mlp_rc_chain: layer %d produces %d columns: every layer of one chain must have the same output width "
+                "rounded up to 128 / 192 / 256 (narrow or wider products go through fgs_gemm_f32)", l, rows);
     L.nch = (k + 31) / 32;
     L.n_rows = rows;
     L.relu = backward ? 0 : U.relu;
@@ -377,6 +497,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     L.in_valid = (l == 0 && !ext_cols) ? k : in0_cols;
     L.ext = ext_cols ? U.ext : nullptr; L.ld_ext = U.ld_ext; L.ext_cols = ext_cols; L.ext_valid = k - carried;
     L.bias = backward ? nullptr : U.bias;
+    L.bias_slot = (!backward && U.bias) ? l : RC_MAXL;
     L.mask_w = (!backward && U.relu) ? reinterpret_cast<uint4 *>(U.mask_bits) : nullptr;
     L.mask_r = backward ? reinterpret_cast<const uint4 *>(U.mask_bits) : nullptr;
     L.out = U.out; L.ldo = U.ldo; L.n_store = U.n_store;
@@ -393,6 +514,8 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     f4 += (int64_t)P.rows_pad * 8 * L.nch;
     carried = rows < 256 ? rows : 256;      // what the next layer finds in the registers
   }
+  for (int l = 0; l < n_layers; ++l)     // deferred stores need the next layer to walk every tile of this output
+    a.L[l].defer_store = (l + 1 < n_layers && a.L[l + 1].nch >= a.L[l].nt && !a.L[l + 1].in) ? 1 : 0;
   a.total_chunks = chunk;
   p.f4_total = f4;
   hipStream_t st = fgs_s(stream);
@@ -404,8 +527,11 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     cus = 256;
   const int64_t nb = (M + RC_BLOCK - 1) / RC_BLOCK;
   const unsigned grid = (unsigned)(nb < cus ? nb : cus);
-  if (backward) hipLaunchKernelGGL(k_mlp_rc<true>, dim3(grid), dim3(RC_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(k_mlp_rc<false>, dim3(grid), dim3(RC_THREADS), 0, st, a);
+  const int nt = a.L[0].nt;
+#define RC_LAUNCH(B, N) hipLaunchKernelGGL((k_mlp_rc<B, N>), dim3(grid), dim3(RC_THREADS), 0, st, a)
+  if (backward) { if (nt == 4) RC_LAUNCH(true, 4); else if (nt == 6) RC_LAUNCH(true, 6); else RC_LAUNCH(true, 8); }
+  else { if (nt == 4) RC_LAUNCH(false, 4); else if (nt == 6) RC_LAUNCH(false, 6); else RC_LAUNCH(false, 8); }
+#undef RC_LAUNCH
   FGS_LAUNCH_OK("fgs_mlp_rc_chain");
   return 0;
 }

@@ -251,8 +251,11 @@ int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int 
  *   backward = 0:  x_0 = in0[M, in0_cols];  x_{l+1} = act_l([x_l | ext_l] . W_l^T + bias_l)      (nn.Linear forward)
  *   backward = 1:  g_0 = in0[M, n_out_0];   g_{l+1} = (g_l . W_l) with the elements whose bit in mask_bits_l is 0 zeroed
  * W_l is the nn.Linear weight [n_out][ldw] (n_in valid columns) in both directions (the packing transposes).  A layer's
- * input is the first min(256, width) columns of the previous output, carried in registers; forward layers may append
- * ext_cols <= 64 columns read from `ext` (refnet's reflection encoding).  Widths up to 320 (forward n_out <= 256).
+ * input is the previous output (<= 256 columns), carried in registers; forward layers may append ext_cols <= 64 columns
+ * read from `ext` (refnet's reflection encoding: reduction over up to 320 columns).  Every layer of ONE chain must produce
+ * the same number of columns rounded up to 128 / 192 / 256 (one kernel instantiation per width: the fine stage's 256, the
+ * coarse stages' 192 and 128); narrow products at the ends of the backward chain (dX0, the encoding columns of dZ) go
+ * through fgs_gemm_f32 on the dY tensors the chain writes out.
  *   out / ldo / n_store : row-major copy of the layer output (first n_store columns, multiple of 4), or NULL
  *   mask_bits           : forward + relu: receives one bit per output element (1 = positive), [ceil(M / 32)][64] x 16 bytes,
  *                         in the kernel's register order; backward: the bits to apply (those the forward wrote for the layer
@@ -270,6 +273,11 @@ typedef struct fgs_rc_layer {
 int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers);
 int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0, int64_t ld_in0,
                      int in0_cols, float *image_ws, int64_t image_ws_floats, fgs_stream_t stream);
+/* Diagnostics for the chain kernels: while a device buffer of >= 2048 uint64 is set, workgroup b records into stamps[8 b ..]
+ * {shader clock, 100 MHz wall clock} at its start and end -- the clock the chip holds inside the kernel is d(shader) /
+ * d(wall) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6) -- and the shader cycles its first wave spent in the
+ * accumulator initialisation, the reduction chunks, the layer epilogues and the input loads.  NULL switches it off. */
+int fgs_mlp_rc_debug_stamps(unsigned long long *stamps);
 /* The general form of the one-launch chain, also used for the BACKWARD data gradients (dY of the top layer in, transposed
  * weights, per layer the ReLU mask of the layer below = its saved input, and the column sums = that layer's bias gradient):
  *   W[l] [n_rows[l] <= 256, ldw[l]]: output column n uses weight row n (only the last layer may have fewer than 256 rows);

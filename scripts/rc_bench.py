@@ -39,3 +39,23 @@ for M in (49920, 58430, 65536, 32768):
     for name, v in res.items():
         v = sorted(v)
         print(f"M={M} {name:4s} median {v[len(v)//2]:8.1f} us  min {v[0]:8.1f} us  -> {flop / (v[len(v)//2] * 1e-6) / 1e12:6.1f} TFLOP/s", flush=True)
+
+# in-kernel clock of the register-resident chain (shader-clock / wall-clock stamps per workgroup)
+from fgs_nerf_amd._lib import call
+# (run_rc still refers to the buffers of the LAST M of the loop above: do not touch M here)
+stamps = torch.zeros(8 * 1024, dtype=torch.int64, device=dev)
+call("fgs_mlp_rc_debug_stamps", stamps.data_ptr())
+for _ in range(20):
+    run_rc()
+torch.cuda.synchronize()
+stamps.zero_()
+run_rc()
+torch.cuda.synchronize()
+call("fgs_mlp_rc_debug_stamps", None)
+st = stamps.view(-1, 8)[:256].cpu().double()
+cyc, wall = st[:, 2] - st[:, 0], (st[:, 3] - st[:, 1]) * 10e-9       # 100 MHz ticks -> seconds
+ghz = (cyc / wall / 1e9)
+print(f"in-kernel: shader cycles per workgroup median {cyc.median():.0f}, wall {wall.median() * 1e6:.1f} us, clock median {ghz.median():.3f} GHz "
+      f"(min {ghz.min():.3f}, max {ghz.max():.3f}); ideal MFMA cycles per pass {54 * 128 * 64} x passes {(M + 32767) // 32768}", flush=True)
+print("phases (median shader cycles per workgroup): init %.0f, chunks %.0f, epilogue %.0f, input load %.0f" %
+      tuple(float(st[:, k].median()) for k in (4, 5, 6, 7)), flush=True)
