@@ -45,6 +45,7 @@ _SIGNATURES = {
     "fgs_set_row_count_ptr": [P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
     "fgs_mlp_rc_debug_stamps": [P],
+    "fgs_mlp_wgrad": [I64, I32, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -98,6 +99,14 @@ class RcLayer(ctypes.Structure):
                 ("mask_bits", c_void_p),
                 ("out", c_void_p), ("ldo", c_int64), ("n_store", c_int),
                 ("ext", c_void_p), ("ld_ext", c_int64), ("ext_cols", c_int)]
+
+
+class WgradItem(ctypes.Structure):
+    """fgs_wgrad_item_t (include/fgs_hip.h): one weight-gradient product dW += dY^T X (+ bias gradient)."""
+    _fields_ = [("dY", c_void_p), ("ld_dy", c_int64), ("n_out", c_int),
+                ("X", c_void_p), ("ld_x", c_int64), ("n_in", c_int),
+                ("dW", c_void_p), ("ld_dw", c_int64),
+                ("dbias", c_void_p)]
 
 
 class FgsError(RuntimeError):

@@ -135,3 +135,17 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers) -
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
     call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0), in0_cols,
          ptr(ws), ws.numel(), stream())
+
+
+def mlp_wgrad(M: int, items) -> None:
+    """All weight / bias gradients of the MLPs in one launch (include/fgs_hip.h fgs_mlp_wgrad).  `items`: list of
+    (dY [M, >= n_out], X [M, >= n_in], dW [n_out, >= n_in] zero-initialised, dbias [n_out] or None, n_out, n_in)."""
+    import ctypes
+    from ._lib import WgradItem
+    n = len(items)
+    arr = (WgradItem * n)()
+    for i, (dY, X, dW, db, n_out, n_in) in enumerate(items):
+        arr[i].dY, arr[i].ld_dy, arr[i].n_out = ptr(dY), dY.stride(0), int(n_out)
+        arr[i].X, arr[i].ld_x, arr[i].n_in = ptr(X), X.stride(0), int(n_in)
+        arr[i].dW, arr[i].ld_dw, arr[i].dbias = ptr(dW), dW.stride(0), ptr(db)
+    call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), stream())

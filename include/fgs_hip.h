@@ -273,6 +273,18 @@ typedef struct fgs_rc_layer {
 int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers);
 int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0, int64_t ld_in0,
                      int in0_cols, float *image_ws, int64_t image_ws_floats, fgs_stream_t stream);
+/* Every weight and bias gradient of the MLPs in ONE launch (csrc/mlp_wgrad.hip): for each item
+ *   dW[n_out, n_in] += dY[M, n_out]^T . X[M, n_in]      dbias[n_out] += column sums of dY   (dbias may be NULL)
+ * with fp32 atomics (zero-initialise dW / dbias).  The samples are split over the chip, a workgroup holds a 256 x 256 block
+ * of one dW in its accumulators and streams dY / X rows straight into MFMA operands.  n_out <= 256; n_in any (blocks of 256
+ * columns); all matrices row-major, 4-byte aligned.  Honours fgs_set_row_count_ptr (M = capacity). */
+typedef struct fgs_wgrad_item {
+  const float *dY; int64_t ld_dy; int n_out;
+  const float *X; int64_t ld_x; int n_in;
+  float *dW; int64_t ld_dw;
+  float *dbias;
+} fgs_wgrad_item_t;
+int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, fgs_stream_t stream);
 /* Diagnostics for the chain kernels: while a device buffer of >= 2048 uint64 is set, workgroup b records into stamps[8 b ..]
  * {shader clock, 100 MHz wall clock} at its start and end -- the clock the chip holds inside the kernel is d(shader) /
  * d(wall) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6) -- and the shader cycles its first wave spent in the

@@ -152,3 +152,35 @@ def test_rc_device_row_count(dev):
     for a, b in zip(outs_a, outs_b):
         assert torch.equal(a[:M, :256], b[:M, :256])
         assert bool(torch.isnan(b[M:, :256]).all())
+
+
+@pytest.mark.parametrize("M", [1, 2, 63, 1000, 50001])
+def test_wgrad_all_layers_one_launch_matches_fp64(dev, M):
+    """fgs_mlp_wgrad: the seven weight gradients and bias gradients of the fine-stage MLPs in one launch (dW += dY^T X with
+    the samples split over the chip, fp32 atomics) against float64; ragged M, the 106- and 307-column inputs (column blocks of
+    128, 256 + 64), strided dY (dZ's first 256 columns), padding columns untouched."""
+    from fgs_nerf_amd import fused_ops as fo
+    g = torch.Generator().manual_seed(M)
+    n_in = [106, 256, 256, 256, 307, 256, 256]
+    ld_x = [108, 256, 256, 256, 308, 256, 256]
+    Xs = [torch.randn(M, ld, generator=g).to(dev) for ld in ld_x]
+    dZ = torch.randn(M, 308, generator=g).to(dev)
+    dYs = [torch.randn(M, 256, generator=g).to(dev) for _ in range(7)]
+    dYs[3] = dZ[:, :256]                                   # a strided dY (ld 308)
+    dWs = [torch.zeros(256, ld, device=dev) for ld in ld_x]
+    dbs = [torch.zeros(256, device=dev) for _ in range(7)]
+    fo.mlp_wgrad(M, [(dYs[i], Xs[i], dWs[i], dbs[i], 256, n_in[i]) for i in range(7)])
+    for i in range(7):
+        ref = dYs[i].double().T @ Xs[i][:, :n_in[i]].double()
+        assert rel_l2(dWs[i][:, :n_in[i]], ref) < 2e-6, (i, rel_l2(dWs[i][:, :n_in[i]], ref))
+        assert float(dWs[i][:, n_in[i]:].abs().max()) == 0.0 if n_in[i] < ld_x[i] else True
+        assert rel_l2(dbs[i], dYs[i].double().sum(0)) < 2e-6, i
+    # coarse-stage widths: 192 x 90 and 192 x 192, accumulating into a non-zero dW
+    W = 192
+    X0, X1 = torch.randn(M, 92, generator=g).to(dev), torch.randn(M, W, generator=g).to(dev)
+    d0, d1 = torch.randn(M, W, generator=g).to(dev), torch.randn(M, W, generator=g).to(dev)
+    g0, g1 = torch.ones(W, 92, device=dev), torch.zeros(W, W, device=dev)
+    b1 = torch.zeros(W, device=dev)
+    fo.mlp_wgrad(M, [(d0, X0, g0, None, W, 90), (d1, X1, g1, b1, W, W)])
+    assert rel_l2(g0[:, :90], 1.0 + d0.double().T @ X0[:, :90].double()) < 2e-6
+    assert rel_l2(g1, d1.double().T @ X1.double()) < 2e-6 and rel_l2(b1, d1.double().sum(0)) < 2e-6
