@@ -62,6 +62,7 @@ def train_step(model, opt, averager, batch, n_rays_global):
     model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)
     opt.step()
     STEP_STATS["survivors"] += int(res['weights'].shape[0])     # a host number already (the forward read it)
+    STEP_STATS["max_survivors"] = max(STEP_STATS.get("max_survivors", 0), int(res['weights'].shape[0]))
     return loss
 
 
@@ -158,6 +159,9 @@ def main():
     ap.add_argument("--composed", action="store_true", help="operator-at-a-time HIP path instead of the fused kernels")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph (default, 1 GPU, fused fine stage): the whole step is one hipGraph replay, nothing of it reaches "
+                         "the host; eager: Python enqueues every launch and reads the survivor count back once per step")
     ap.add_argument("--grid", type=int, default=GRID,
                     help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
     args = ap.parse_args()
@@ -235,9 +239,26 @@ def main():
         opt.zero_grad(set_to_none=True)
         del res
     torch.cuda.synchronize()
+    use_graph = (args.mode == "graph" and world == 1 and not force_dist and not args.composed and args.stage == "fine"
+                 and os.environ.get("FGS_MLP", "rc") == "rc")
+    STEP_STATS["max_survivors"] = 0
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
     torch.cuda.synchronize()
+    captured = None
+    if use_graph:
+        from fgs_nerf_amd.graph_step import CapturedFineStep
+        # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
+        seen = max(STEP_STATS["max_survivors"], 16384)
+        capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
+        captured = CapturedFineStep(model, opt, synth.FINE_LOSS, synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
+                                    global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
+                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity)
+        captured.capture(batches[0])
+        for i in range(2):                       # two untimed replays (the first launch of a graph uploads it)
+            captured.replay(batches[i % N_BATCHES])
+        torch.cuda.synchronize()
+        captured.clear_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -245,7 +266,7 @@ def main():
     # on the stream the kernels are launched on (PyTorch-ROCm's current stream) -> the "roofline" object below
     from fgs_nerf_amd import fused
     fused.PROFILE["gemm_events"].clear()
-    fused.PROFILE["enabled"] = (rank == 0) and not args.composed
+    fused.PROFILE["enabled"] = (rank == 0) and not args.composed and captured is None
     STEP_STATS["survivors"] = 0
     # the cyclic collector stays out of the timed region: a generation-2 pass over torch's object graph takes milliseconds,
     # several steps' worth, and lands in some 30-step runs and not in others (2.29 vs 2.63 ms/step on the same box)
@@ -257,7 +278,10 @@ def main():
     t0 = time.perf_counter()
     samples = 0
     for i in range(args.steps):
-        train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+        if captured is not None:
+            captured.replay(batches[i % N_BATCHES])
+        else:
+            train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
         samples += n_inbbox[i % N_BATCHES]
     torch.cuda.synchronize()
     if world > 1:
@@ -267,6 +291,24 @@ def main():
     if gc_was_enabled:
         gc.enable()
     fused.PROFILE["enabled"] = False
+    roofline_note = "HIP events on the launch stream around each uninterrupted MLP chain in the timed region"
+    if captured is not None:
+        overflow, total = captured.check()
+        if overflow:
+            raise SystemExit(f"survivor capacity {captured.capacity} overflowed during the timed region: rerun with --mode eager")
+        survivors_timed = total
+        # A graph replay cannot carry timing events around individual kernels: the MLP kernels are timed right behind the
+        # timed region, in the same process on the same model and batches, by PROFILE_STEPS eager steps of the same loop
+        PROFILE_STEPS = 10
+        fused.PROFILE["gemm_events"].clear()
+        fused.PROFILE["enabled"] = rank == 0
+        for i in range(PROFILE_STEPS):
+            train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+        torch.cuda.synchronize()
+        fused.PROFILE["enabled"] = False
+        STEP_STATS["survivors"] = survivors_timed        # (the profiling steps above counted theirs)
+        roofline_note = (f"HIP events on the launch stream around each uninterrupted MLP chain, in {PROFILE_STEPS} eager steps "
+                         "of the same loop run right behind the timed region (graph replays cannot carry timing events)")
 
     stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -292,7 +334,11 @@ def main():
                        "mlp_survivors_per_step_per_gpu": int(STEP_STATS["survivors"] / max(args.steps, 1)),
                        "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
         }
+        line["config"]["step_mode"] = ("one hipGraph replay per step, no device->host read" if captured is not None
+                                       else "eager launches, one survivor-count read per step")
         line["roofline"] = fused.roofline_report()
+        if line["roofline"] is not None:
+            line["roofline"]["timing"] = roofline_note
         if line["roofline"] is not None and args.stage == "fine":
             # the path is NOT HBM-bound -- both HBM fractions, for the record (the claimed bound is "mfma" above).
             # sampled path: 688 + 3456 rho algorithmic bytes per in-bbox sample; whole step adds the dense per-step streams

@@ -43,6 +43,11 @@ _SIGNATURES = {
     "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
     "fgs_set_row_count_ptr": [P],
+    "fgs_set_inv_s_ptr": [P],
+    "fgs_step_scalars_tick": [P, I32, I32, P, P, P],
+    "fgs_count_guard": [P, I64, I64, P, P, P],
+    "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, F32, F32, F32, I32, P, P],
+    "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, F32, F32, F32, P, P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P],
@@ -116,7 +121,8 @@ class FgsError(RuntimeError):
 def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
-                                          "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats"])
+                                          "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats",
+                                          "fgs_adam_step_size"])
 
 
 def lib() -> ctypes.CDLL:
@@ -138,6 +144,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_gemm_workspace_bytes.argtypes = []
         handle.fgs_head_bwd_scratch_floats.restype = c_int64
         handle.fgs_head_bwd_scratch_floats.argtypes = [c_int]
+        handle.fgs_adam_step_size.restype = c_float
+        handle.fgs_adam_step_size.argtypes = [c_int, c_float, c_float, c_float]
         handle.fgs_mlp_rc_image_floats.restype = c_int64
         handle.fgs_mlp_rc_image_floats.argtypes = [c_int, c_int, c_void_p]
         handle.fgs_mc_num_blocks.restype = c_int64

@@ -41,7 +41,24 @@ class MaskedAdam(torch.optim.Optimizer):
         self.before_param = None      # optional callable(param), invoked right before a parameter is updated (dist.py)
         self._early = {}              # id(param) -> event of an update already applied by early_update() in this step
         self._early_stream = None
+        self._dev = None              # device-resident schedule (use_device_schedule): {'ss': {group index: ptr}, 'skip': ptr}
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def use_device_schedule(self, step_size_ptrs=None, skip_ptr=None) -> None:
+        """Captured (hipGraph) steps: the step size lr_t * sqrt(1 - b2^t) / (1 - b1^t) of parameter group g is read by the
+        update kernels from the device float at `step_size_ptrs[g]` (written each step by fgs_step_scalars_tick from a table
+        built with fgs_adam_step_size, the host entry points' own arithmetic), and the whole update is skipped while the
+        device int at `skip_ptr` is non-zero.  `step()` then passes no host scalar that changes from step to step, so a
+        captured step replays correctly; the host-side `state[p]['step']` counters are advanced by whoever replays.
+        `use_device_schedule(None)` returns to host scalars."""
+        self._dev = None if step_size_ptrs is None else {'ss': dict(step_size_ptrs), 'skip': skip_ptr}
+
+    def ensure_state(self) -> None:
+        """Create every parameter's moment buffers now (a captured step must not allocate-and-zero them inside the graph)."""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.requires_grad:
+                    self._state_of(p)
 
     def set_pervoxel_lr(self, count):
         self.per_lr = count.float() / count.max()
@@ -55,16 +72,20 @@ class MaskedAdam(torch.optim.Optimizer):
         return st
 
     @staticmethod
-    def _flush_small(batch, b1, b2, eps):
+    def _flush_small(batch, b1, b2, eps, dev=None, ss_ptr=None):
         n = len(batch)
         if n == 0:
             return
         P = ctypes.c_void_p
         tables = [(P * n)(*[row[k].data_ptr() for row in batch]) for k in range(4)]
         sizes = (ctypes.c_int64 * n)(*[row[0].numel() for row in batch])
+        masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
+        if dev is not None:
+            ss = (P * n)(*[ss_ptr] * n)
+            call("fgs_adam_upd_multi_dev", n, *tables, sizes, ss, masked, float(b1), float(b2), float(eps), dev['skip'], stream())
+            return
         steps = (ctypes.c_int * n)(*[row[4] for row in batch])
         lrs = (ctypes.c_float * n)(*[row[5] for row in batch])
-        masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
         call("fgs_adam_upd_multi", n, *tables, sizes, steps, lrs, masked, float(b1), float(b2), float(eps), stream())
 
     def _update_one(self, p, g, group):
@@ -112,8 +133,36 @@ class MaskedAdam(torch.optim.Optimizer):
         self._early[id(p)] = done
         return True
 
+    def _step_device(self):
+        """step() with the device-resident schedule (see use_device_schedule): same kernels, same per-tensor rule."""
+        from ._lib import ptr
+        dev = self._dev
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group['betas']
+            ss_ptr = dev['ss'][gi]
+            masked = group['skip_zero_grad']
+            small = []
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self._state_of(p)
+                g = _as_layout_of(p.grad, p)
+                m, v = st['exp_avg'], st['exp_avg_sq']
+                if self.per_lr is not None and p.shape == self.per_lr.shape:
+                    mode, perlr = 2, _as_layout_of(self.per_lr, p)
+                elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
+                    small.append((p, g, m, v, 0, 0.0, masked))
+                    continue
+                else:
+                    mode, perlr = (1 if masked else 0), None
+                call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(m), ptr(v), ptr(perlr), p.numel(), ss_ptr, float(b1), float(b2),
+                     float(group['eps']), mode, dev['skip'], stream())
+            self._flush_small(small, b1, b2, group['eps'], dev=dev, ss_ptr=ss_ptr)
+
     @torch.no_grad()
     def step(self):
+        if self._dev is not None:
+            return self._step_device()
         early, self._early = self._early, {}
         for group in self.param_groups:
             b1, b2 = group['betas']

@@ -7,9 +7,16 @@
 namespace {
 thread_local char g_last_error[512] = "";
 thread_local const int64_t *g_row_ptr = nullptr;
+thread_local const float *g_inv_s_ptr = nullptr;
 }
 
 const int64_t *fgs_row_ptr() { return g_row_ptr; }
+const float *fgs_inv_s_ptr() { return g_inv_s_ptr; }
+
+FGS_API int fgs_set_inv_s_ptr(const float *inv_s_dev) {
+  g_inv_s_ptr = inv_s_dev;
+  return 0;
+}
 
 FGS_API int fgs_set_row_count_ptr(const int64_t *count_dev) {
   g_row_ptr = count_dev;

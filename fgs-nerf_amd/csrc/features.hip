@@ -27,7 +27,8 @@ struct FeatLayout {
 };
 
 struct SurvArgs {
-  int64_t M;  // survivors
+  int64_t M;  // survivors (the capacity of the buffers when m_dev is set: fgs_set_row_count_ptr)
+  const int64_t *m_dev;
   const int64_t *ray_id;
   const float *pts, *sdf, *gradient, *viewdirs;  // pts/sdf/gradient per survivor, viewdirs per ray
   SceneGeom geom;
@@ -44,6 +45,7 @@ __device__ __forceinline__ int64_t surv_of(int64_t tid, int64_t M, int64_t C) {
 // ---------------------------------------------------------------------------------------------- k0 lookup
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const float *__restrict__ k0, GridDesc kd,
                                                            float *__restrict__ X0) {
+  S.M = fgs_rows(S.M, S.m_dev);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
   const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const flo
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__restrict__ k0_grad, GridDesc kd,
                                                            const float *__restrict__ dX0) {
+  S.M = fgs_rows(S.M, S.m_dev);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
   const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
@@ -73,6 +76,7 @@ __device__ __forceinline__ float group_shfl(float v, int src_in_group) { return 
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_fwd(SurvArgs S, const float *__restrict__ sdf_grid,
                                                              float *__restrict__ X0) {
+  S.M = fgs_rows(S.M, S.m_dev);
   const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
   const int K = S.L.K;
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
                                                              const float *__restrict__ tot_sdf,
                                                              const float *__restrict__ tot_grad,
                                                              float *__restrict__ sdf_grad_grid) {
+  S.M = fgs_rows(S.M, S.m_dev);
   __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
   const int64_t m_first = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5) * TAPS_GROUP;
   const int j = threadIdx.x & 31;
@@ -282,6 +287,7 @@ __device__ __forceinline__ Normal3 normal_of(float gx, float gy, float gz) {
 // components, the normal and the scalar columns are written by the first lanes / the last lane.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X0, float *Z /* == X0 in coarse mode */,
                                                             float *__restrict__ normal_out) {
+  S.M = fgs_rows(S.M, S.m_dev);
   const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
   if (m >= S.M) return;
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
                                                             const float *__restrict__ dX0, const float *__restrict__ dZ,
                                                             const float *__restrict__ g_normal, float *__restrict__ g_sdf,
                                                             float *__restrict__ g_gradient) {
+  S.M = fgs_rows(S.M, S.m_dev);
   const int64_t m_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
   const bool live = m_raw < S.M;
@@ -407,7 +414,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
 // out = R3 . V4^T + c4 ; rgb = sigmoid(out).  One wavefront per row, lane l owns columns 4l..4l+3 (W <= 256).
 __global__ __launch_bounds__(FGS_BLOCK) void k_head_fwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
                                                         const float *__restrict__ V, const float *__restrict__ bias,
-                                                        float *__restrict__ rgb) {
+                                                        float *__restrict__ rgb, const int64_t *__restrict__ m_dev) {
+  M = fgs_rows(M, m_dev);
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
@@ -444,7 +452,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_head_bwd(const float *__restrict_
                                                         const float *__restrict__ V, const float *__restrict__ d_out,
                                                         float *__restrict__ dR, float *__restrict__ dV,
                                                         float *__restrict__ dbias, float *__restrict__ dR_colsum,
-                                                        float *__restrict__ scratch /* [gridDim.x][4W + 4] or null */) {
+                                                        float *__restrict__ scratch /* [gridDim.x][4W + 4] or null */,
+                                                        const int64_t *__restrict__ m_dev) {
+  M = fgs_rows(M, m_dev);
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
@@ -620,6 +630,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_composite_fwd(CompositeArgs C) {
 
 struct CompositeBwdArgs {
   int64_t M;
+  const int64_t *m_dev;
   const int64_t *ray_id;
   const float *weights, *rgb;
   const float *pre_rgb, *pre_sig;                   // [n_rays,3]
@@ -632,6 +643,7 @@ struct CompositeBwdArgs {
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_composite_bwd(CompositeBwdArgs C) {
+  C.M = fgs_rows(C.M, C.m_dev);
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= C.M) return;
   const int64_t r = C.ray_id[m];
@@ -723,7 +735,7 @@ FGS_API int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *p
   FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && k0_grid && X0 && normal_out,
               FGS_E_INVALID, "fgs_feat_coarse_fwd: null pointer");
   SurvArgs S;
-  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
   if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -745,7 +757,7 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && k0_grad_grid &&
                   g_gradient, FGS_E_INVALID, "fgs_feat_coarse_bwd: null pointer");
   SurvArgs S;
-  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
   if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -769,7 +781,7 @@ FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts
   FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && sdf_grid &&
                   k0_grid && X0 && Zbuf && normal_out, FGS_E_INVALID, "fgs_feat_fine_fwd: null pointer");
   SurvArgs S;
-  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -796,7 +808,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && Zbuf && dX0 &&
                   dZ && sdf_grad_grid && k0_grad_grid && g_sdf && g_gradient, FGS_E_INVALID, "fgs_feat_fine_bwd: null pointer");
   SurvArgs S;
-  S.M = M; S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -819,7 +831,7 @@ FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_m
   FGS_REQUIRE(pts && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && sdf_grad_grid && (!tot_sdf == !tot_grad),
               FGS_E_INVALID, "fgs_sdf_scatter_surv: null pointer");
   SurvArgs S;
-  S.M = M; S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
+  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
   hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks((M + TAPS_GROUP - 1) / TAPS_GROUP * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
@@ -836,7 +848,7 @@ FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const fl
   FGS_REQUIRE(R && V && bias && rgb, FGS_E_INVALID, "fgs_head_fwd: null pointer");
   const int64_t want = (M + 3) / 4;
   const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb);
+  hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb, fgs_row_ptr());
   FGS_LAUNCH_OK("fgs_head_fwd");
   return 0;
 }
@@ -855,7 +867,7 @@ FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const fl
   unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (scratch && blocks > 1024) blocks = 1024;      // fgs_head_bwd_scratch_floats() sizes the scratch for 1024 blocks
   hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
-                     dR_colsum, scratch);
+                     dR_colsum, scratch, fgs_row_ptr());
   FGS_LAUNCH_OK("fgs_head_bwd");
   if (scratch) {
     hipLaunchKernelGGL(k_head_bwd_reduce, dim3((4 * W + 3 + 63) / 64, 8), dim3(FGS_BLOCK), 0, fgs_s(stream), scratch,
@@ -889,7 +901,7 @@ FGS_API int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *wei
   if (M == 0) return 0;
   FGS_REQUIRE(ray_id && weights && rgb && pre_rgb && pre_sig && d_out && d_w, FGS_E_INVALID, "fgs_composite_bwd: null pointer");
   CompositeBwdArgs C;
-  C.M = M; C.ray_id = ray_id; C.weights = weights; C.rgb = rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
+  C.M = M; C.m_dev = fgs_row_ptr(); C.ray_id = ray_id; C.weights = weights; C.rgb = rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
   C.g_rgb_marched = g_rgb_marched; C.g_sigmoid_rgb = g_sigmoid_rgb; C.g_raw_rgb = g_raw_rgb;
   C.g_weights_direct = g_weights_direct; C.bg = bg; C.d_out = d_out; C.d_w = d_w;
   hipLaunchKernelGGL(k_composite_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), C);

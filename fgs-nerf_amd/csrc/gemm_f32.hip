@@ -30,6 +30,7 @@ constexpr int TILE_FLOATS = 128 * LDK;  // >= 32 * LDI
 
 struct GemmArgs {
   int64_t M, N, K;
+  const int64_t *m_dev;       // fgs_set_row_count_ptr (NT / NN only): M is the capacity, the kernel clamps to *m_dev
   const float *A; int64_t lda;
   const float *B; int64_t ldb;
   float *C; int64_t ldc;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &l
     const int within = b - grp * 8 * g.tiles_n;
     tile_m = grp * 8 + (within & 7);
     tile_n = within >> 3;
-    if (tile_m >= g.tiles_m) return;
+    if (tile_m >= g.tiles_m || (int64_t)tile_m * BM >= g.M) return;
   }
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   floatx16 acc[2][2];
@@ -329,6 +330,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &l
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) LdsImage lds;
+  if (EPI != EPI_ATOMIC) g.M = fgs_rows(g.M, g.m_dev);       // row tiles beyond the device-side count return at once
   gemm_block<A_KC, B_KC, EPI>(g, (int)blockIdx.x, lds);
 }
 
@@ -492,7 +494,7 @@ unsigned setup_splitk(GemmArgs &g, int default_wgs = 512) {
 GemmArgs make_args(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb, float *C,
                    int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum) {
   GemmArgs g;
-  g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.m_dev = nullptr; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.colsum = colsum; g.k_per_split = 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
@@ -526,6 +528,14 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
 
   GemmArgs g = make_args(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm, colsum);
   hipStream_t st = fgs_s(stream);
+  // device-side row count (fgs_set_row_count_ptr): supported by the one-tile-per-workgroup NT / NN form (rows = M); the
+  // split-K reduction over the rows (TN) and the stream-K grid take their partition from the host count
+  if (fgs_row_ptr()) {
+    FGS_REQUIRE(op != FGS_GEMM_TN && !workspace, FGS_E_INVALID,
+                "fgs_gemm_f32: TN / stream-K are not available under fgs_set_row_count_ptr (use fgs_mlp_wgrad)");
+    FGS_REQUIRE(!colsum, FGS_E_INVALID, "fgs_gemm_f32: colsum is not available under fgs_set_row_count_ptr");
+    g.m_dev = fgs_row_ptr();
+  }
   if (op != FGS_GEMM_TN && workspace) {
     // the caller asked for stream-K (by passing a workspace); used when it can balance: more than a handful of tiles,
     // a K loop worth cutting, every range non-empty

@@ -110,9 +110,12 @@ template <int MODE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad,
                                                          float4 *__restrict__ exp_avg, float4 *__restrict__ exp_avg_sq,
                                                          const float4 *__restrict__ perlr, int64_t n4, float step_size,
-                                                         float beta1, float beta2, float eps) {
+                                                         float beta1, float beta2, float eps,
+                                                         const float *__restrict__ ss_dev, const int *__restrict__ skip) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  if (skip && *skip) return;              // a step whose survivor list overflowed its capacity updates nothing
+  if (ss_dev) step_size = *ss_dev;        // device-resident schedule (fgs_step_scalars_tick)
   const float4 g = grad[i];
   if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
   float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
@@ -130,9 +133,12 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_vec4(float4 *__restrict__ pa
 template <int MODE>
 __global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
                               float *__restrict__ exp_avg_sq, const float *__restrict__ perlr, int64_t begin, int64_t n,
-                              float step_size, float beta1, float beta2, float eps) {
+                              float step_size, float beta1, float beta2, float eps, const float *__restrict__ ss_dev,
+                              const int *__restrict__ skip) {
   const int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip && *skip) return;
+  if (ss_dev) step_size = *ss_dev;
   const float g = grad[i];
   if (MODE == 1 && g == 0.f) return;
   float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
@@ -144,20 +150,21 @@ __global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict
 
 template <int MODE>
 int launch_adam(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
-                float step_size, float beta1, float beta2, float eps, hipStream_t st) {
+                float step_size, float beta1, float beta2, float eps, hipStream_t st, const float *ss_dev = nullptr,
+                const int *skip = nullptr) {
   const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq |
                          (uintptr_t)(MODE == 2 ? perlr : nullptr)) & 15) == 0;
   const int64_t n4 = aligned ? n / 4 : 0;
   if (n4 > 0) {
     hipLaunchKernelGGL(k_adam_vec4<MODE>, dim3(fgs_blocks(n4)), dim3(FGS_BLOCK), 0, st, (float4 *)param,
                        (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, (const float4 *)perlr, n4, step_size,
-                       beta1, beta2, eps);
+                       beta1, beta2, eps, ss_dev, skip);
     FGS_LAUNCH_OK("fgs_adam_upd/vec4");
   }
   const int64_t done = n4 * 4;
   if (done < n) {
     hipLaunchKernelGGL(k_adam_scalar<MODE>, dim3(fgs_blocks(n - done)), dim3(FGS_BLOCK), 0, st, param, grad, exp_avg,
-                       exp_avg_sq, perlr, done, n, step_size, beta1, beta2, eps);
+                       exp_avg_sq, perlr, done, n, step_size, beta1, beta2, eps, ss_dev, skip);
     FGS_LAUNCH_OK("fgs_adam_upd/tail");
   }
   return 0;
@@ -227,6 +234,8 @@ struct MultiAdam {
   int64_t size[MULTI_MAX];
   unsigned blk_start[MULTI_MAX + 1];
   float step_size[MULTI_MAX];
+  const float *ss_dev[MULTI_MAX];   // device-resident step size per tensor (or null: step_size above)
+  const int *skip;
   int masked[MULTI_MAX];
 };
 
@@ -235,22 +244,24 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_multi(MultiAdam A, float bet
   while (t + 1 < A.n_tensors && blockIdx.x >= A.blk_start[t + 1]) ++t;  // uniform per block
   const int64_t i = (int64_t)(blockIdx.x - A.blk_start[t]) * blockDim.x + threadIdx.x;
   if (i >= A.size[t]) return;
+  if (A.skip && *A.skip) return;
   const float g = A.grad[t][i];
   if (A.masked[t] && g == 0.f) return;
   float p = A.param[t][i], m = A.m[t][i], v = A.v[t][i];
-  adam_one<0>(p, g, m, v, 1.f, A.step_size[t], beta1, beta2, eps);
+  adam_one<0>(p, g, m, v, 1.f, A.ss_dev[t] ? *A.ss_dev[t] : A.step_size[t], beta1, beta2, eps);
   A.param[t][i] = p;
   A.m[t][i] = m;
   A.v[t][i] = v;
 }
 }  // namespace
 
-FGS_API int fgs_adam_upd_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
-                               float *const *exp_avg_sqs, const int64_t *sizes, const int *steps, const float *lrs,
-                               const int *masked, float beta1, float beta2, float eps, fgs_stream_t stream) {
+static int adam_multi_impl(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                           float *const *exp_avg_sqs, const int64_t *sizes, const int *steps, const float *lrs,
+                           const float *const *ss_dev, const int *skip, const int *masked, float beta1, float beta2,
+                           float eps, fgs_stream_t stream) {
   FGS_REQUIRE(n_tensors >= 0, FGS_E_INVALID, "fgs_adam_upd_multi: n_tensors=%d", n_tensors);
   if (n_tensors == 0) return 0;
-  FGS_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && sizes && steps && lrs && masked, FGS_E_INVALID,
+  FGS_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && sizes && (ss_dev || (steps && lrs)) && masked, FGS_E_INVALID,
               "fgs_adam_upd_multi: null table");
   for (int base = 0; base < n_tensors; base += MULTI_MAX) {
     MultiAdam A;
@@ -264,14 +275,101 @@ FGS_API int fgs_adam_upd_multi(int n_tensors, float *const *params, const float 
       A.size[t] = sizes[s];
       A.masked[t] = masked[s];
       // adam_upd_kernel.cu:72, per tensor (each keeps its own step count)
-      A.step_size[t] = lrs[s] * sqrtf(1.f - powf(beta2, (float)steps[s])) / (1.f - powf(beta1, (float)steps[s]));
+      A.ss_dev[t] = ss_dev ? ss_dev[s] : nullptr;
+      A.step_size[t] = ss_dev ? 0.f : lrs[s] * sqrtf(1.f - powf(beta2, (float)steps[s])) / (1.f - powf(beta1, (float)steps[s]));
       A.blk_start[t] = blocks;
       blocks += fgs_blocks(sizes[s]);
     }
     A.blk_start[A.n_tensors] = blocks;
+    A.skip = skip;
     if (blocks == 0) continue;
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), A, beta1, beta2, eps);
     FGS_LAUNCH_OK("fgs_adam_upd_multi");
   }
   return 0;
+}
+
+FGS_API int fgs_adam_upd_multi(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                               float *const *exp_avg_sqs, const int64_t *sizes, const int *steps, const float *lrs,
+                               const int *masked, float beta1, float beta2, float eps, fgs_stream_t stream) {
+  return adam_multi_impl(n_tensors, params, grads, exp_avgs, exp_avg_sqs, sizes, steps, lrs, nullptr, nullptr, masked, beta1,
+                         beta2, eps, stream);
+}
+
+// ---- device-resident schedule: the forms a captured (hipGraph) training step uses -----------------------------------
+// The per-iteration scalars of a step -- Adam's step size lr_t sqrt(1 - b2^t) / (1 - b1^t) of every parameter group, NeuS
+// 1/s -- are rows of a table the HOST computes once, with exactly the arithmetic of the per-call entry points
+// (fgs_adam_step_size), for all iterations of a stage.  fgs_step_scalars_tick copies row min(counter, n_rows - 1) into `out`
+// and advances the counter; the kernels of the step read their scalar from `out`.  Bit-identical to the host-driven step.
+FGS_API float fgs_adam_step_size(int step, float beta1, float beta2, float lr) {
+  return lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));   // adam_upd_kernel.cu:72
+}
+
+namespace {
+__global__ void k_scalars_tick(const float *__restrict__ table, int n_rows, int n_cols, int64_t *__restrict__ counter,
+                               float *__restrict__ out) {
+  int64_t row = *counter;
+  if (row > n_rows - 1) row = n_rows - 1;
+  if (row < 0) row = 0;
+  for (int c = threadIdx.x; c < n_cols; c += blockDim.x) out[c] = table[row * n_cols + c];
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = *counter + 1;
+}
+
+// offsets[0..n): the per-ray survivor offsets, offsets[n-1] = the survivor count.  flags[0]: sticky "some step overflowed";
+// flags[1]: this step overflowed (the optimizer kernels skip on it); total += the rows the step really processed; and every
+// offset is cut at the capacity, so that the per-ray segments every later kernel walks end inside the buffers
+__global__ void k_count_guard(int64_t *__restrict__ offsets, int64_t n, int64_t capacity, int *__restrict__ flags,
+                              int64_t *__restrict__ total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = offsets[i];
+  if (i == n - 1) {                       // the total
+    const int over = v > capacity ? 1 : 0;
+    flags[1] = over;
+    if (over) flags[0] = 1;
+    if (total) *total += over ? capacity : v;
+  }
+  if (v > capacity) offsets[i] = capacity;   // every consumer of the offsets stays inside the buffers
+}
+}  // namespace
+
+FGS_API int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out,
+                                  fgs_stream_t stream) {
+  FGS_REQUIRE(table && counter && out && n_rows > 0 && n_cols > 0, FGS_E_INVALID, "fgs_step_scalars_tick: bad argument");
+  hipLaunchKernelGGL(k_scalars_tick, dim3(1), dim3(64), 0, fgs_s(stream), table, n_rows, n_cols, counter, out);
+  FGS_LAUNCH_OK("fgs_step_scalars_tick");
+  return 0;
+}
+
+FGS_API int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream) {
+  FGS_REQUIRE(offsets && flags && capacity >= 0 && n > 0, FGS_E_INVALID, "fgs_count_guard: bad argument");
+  hipLaunchKernelGGL(k_count_guard, dim3(fgs_blocks(n)), dim3(FGS_BLOCK), 0, fgs_s(stream), offsets, n, capacity, flags, total);
+  FGS_LAUNCH_OK("fgs_count_guard");
+  return 0;
+}
+
+FGS_API int fgs_adam_upd_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
+                             const float *step_size_dev, float beta1, float beta2, float eps, int mode, const int *skip_dev,
+                             fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_adam_upd_dev: n=%lld", (long long)n);
+  FGS_REQUIRE(mode >= 0 && mode <= 2, FGS_E_INVALID, "fgs_adam_upd_dev: mode=%d", mode);
+  if (n == 0) return 0;
+  FGS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_size_dev && (mode != FGS_ADAM_PERLR || perlr), FGS_E_INVALID,
+              "fgs_adam_upd_dev: null pointer");
+  hipStream_t st = fgs_s(stream);
+  switch (mode) {
+    case FGS_ADAM_DENSE:  return launch_adam<0>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
+    case FGS_ADAM_MASKED: return launch_adam<1>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
+    default:              return launch_adam<2>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
+  }
+}
+
+FGS_API int fgs_adam_upd_multi_dev(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                                   float *const *exp_avg_sqs, const int64_t *sizes, const float *const *step_size_dev,
+                                   const int *masked, float beta1, float beta2, float eps, const int *skip_dev,
+                                   fgs_stream_t stream) {
+  FGS_REQUIRE(step_size_dev, FGS_E_INVALID, "fgs_adam_upd_multi_dev: null step-size table");
+  return adam_multi_impl(n_tensors, params, grads, exp_avgs, exp_avg_sqs, sizes, nullptr, nullptr, step_size_dev, skip_dev,
+                         masked, beta1, beta2, eps, stream);
 }

@@ -14,6 +14,7 @@ namespace {
 
 struct LossArgs {
   int64_t N, M;
+  const int64_t *m_dev;   // fgs_set_row_count_ptr: M is then the capacity
   const float *rgb_marched, *sigmoid_rgb, *target, *alphainv_cum;  // per ray
   const float *weights, *normal, *raw_rgb;                         // per survivor
   const int64_t *ray_id;
@@ -36,6 +37,7 @@ __device__ __forceinline__ float block_sum_to(float v, float *dst) {
 }
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_fwd(LossArgs L, float *loss) {
+  L.M = fgs_rows(L.M, L.m_dev);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over N*3 elements
   float acc = 0.f;
   if (i < L.N * 3) {
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_fwd(LossArgs L, float *
 }
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_fwd(LossArgs L, float *loss) {
+  L.M = fgs_rows(L.M, L.m_dev);
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
   if (m < L.M) {
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_bwd(LossArgs L, const f
                                                              float *__restrict__ g_rgb_marched,
                                                              float *__restrict__ g_sigmoid_rgb,
                                                              float *__restrict__ g_last) {
+  L.M = fgs_rows(L.M, L.m_dev);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const float go = grad_out[0];
   if (i < L.N * 3) {
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_bwd(LossArgs L, const f
 __global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_bwd(LossArgs L, const float *__restrict__ grad_out,
                                                              float *__restrict__ g_normal,
                                                              float *__restrict__ g_raw_rgb) {
+  L.M = fgs_rows(L.M, L.m_dev);
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= L.M) return;
   const float go = grad_out[0];
@@ -135,7 +140,7 @@ int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const floa
   if (!(rgb_marched && sigmoid_rgb && target && alphainv_cum && viewdirs && w5) ||
       (M > 0 && !(weights && normal && raw_rgb && ray_id)))
     return fgs_set_error(FGS_E_INVALID, "fine loss: null pointer");
-  L->N = N; L->M = M; L->rgb_marched = rgb_marched; L->sigmoid_rgb = sigmoid_rgb; L->target = target;
+  L->N = N; L->M = M; L->m_dev = fgs_row_ptr(); L->rgb_marched = rgb_marched; L->sigmoid_rgb = sigmoid_rgb; L->target = target;
   L->alphainv_cum = alphainv_cum; L->weights = weights; L->normal = normal; L->raw_rgb = raw_rgb; L->ray_id = ray_id;
   L->viewdirs = viewdirs;
   L->w_main = w5[0]; L->w_rgbper = w5[1]; L->w_ent = w5[2]; L->w_ori = w5[3]; L->w_sig = w5[4];

@@ -27,6 +27,7 @@ struct MarchArgs {
   const float *sdf;
   float dist;    // stepsize * voxel_size (fp32), model/nerf.py:795
   float inv_s;   // 1 / s_val (fp32 division), model/nerf.py:522
+  const float *inv_s_dev;   // fgs_set_inv_s_ptr: read inv_s from the device (schedule table of a captured step)
   float thres;   // fast_color_thres
   // optional mask cache (model/nerf.py:1192-1209): max-pooled sdf_mask grid with its own bbox
   const float *mask_grid;
@@ -45,6 +46,7 @@ struct MarchArgs {
 
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
+  if (A.inv_s_dev) A.inv_s = *A.inv_s_dev;
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (ray >= A.n_rays) return;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
 // ---- survivor list: position t in [0, M_s) -> (ray, record) and the per-survivor arrays of the result dict --------
 struct CompactArgs {
   int64_t n_rays, n_surv_total;
+  const int64_t *m_dev;     // fgs_set_row_count_ptr: n_surv_total is then the capacity of the output arrays
   const int64_t *surv_off;  // [n_rays + 1] exclusive scan of n_surv
   int max_steps;
   const int *surv_slot, *a_step;
@@ -156,7 +159,7 @@ struct CompactArgs {
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_surv_compact(CompactArgs C) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= C.n_surv_total) return;
+  if (t >= fgs_rows(C.n_surv_total, C.m_dev)) return;
   int64_t lo = 0, hi = C.n_rays;  // largest r with surv_off[r] <= t and a non-empty segment
   while (hi - lo > 1) {
     const int64_t mid = (lo + hi) >> 1;
@@ -189,6 +192,7 @@ struct MarchBwdArgs {
   int64_t n_rays;
   SceneGeom geom;
   float near, far, stepdist, dist, inv_s;
+  const float *inv_s_dev;
   int max_steps;
   const int *a_step, *a_surv;
   const float *a_alpha, *a_T, *a_weight, *a_sdf, *a_grad;
@@ -204,6 +208,7 @@ struct MarchBwdArgs {
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
+  if (A.inv_s_dev) A.inv_s = *A.inv_s_dev;
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (ray >= A.n_rays) return;
@@ -211,6 +216,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
   if (n_alive == 0) return;
   const int64_t rec0 = ray * A.max_steps;
   const int64_t s_off = fgs_uniform(A.surv_off[ray]);
+  // survivors this ray has in the survivor arrays: all of them, unless the step overflowed its capacity and the guard cut the
+  // offsets (fgs_count_guard) -- then the ranks beyond the cut have no slot and must not be touched
+  const int n_slots = (int)(fgs_uniform(A.surv_off[ray + 1]) - s_off);
   const float o[3] = {A.rays_o[3 * ray], A.rays_o[3 * ray + 1], A.rays_o[3 * ray + 2]};
   const float d[3] = {A.rays_d[3 * ray], A.rays_d[3 * ray + 1], A.rays_d[3 * ray + 2]};
   const float vx = A.viewdirs[3 * ray], vy = A.viewdirs[3 * ray + 1], vz = A.viewdirs[3 * ray + 2];
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
     int rank = -1;
     if (act) {
       rank = A.a_surv[rec];
+      if (rank >= n_slots) rank = -1;
       gw = (rank >= 0) ? A.g_weights[s_off + rank] : 0.f;   // non-survivors were dropped before any consumer
       w = A.a_weight[rec];
       tt = A.a_T[rec];
@@ -322,7 +331,7 @@ FGS_API int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const f
   MarchArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.thres = thres;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
   A.mask_grid = mask_grid;
   A.mask_geom = A.geom;
   A.mask_thres = mask_thres;
@@ -356,7 +365,7 @@ FGS_API int fgs_march_count(const float *rays_o, const float *rays_d, const floa
   MarchArgs A = {};
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.thres = thres;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
   A.mask_grid = mask_grid;
   A.mask_geom = A.geom;
   A.mask_thres = mask_thres;
@@ -383,7 +392,7 @@ FGS_API int fgs_surv_compact(int64_t n_rays, int64_t n_surv_total, const int64_t
                   xyz_max_host && ray_id && step_id && rec_idx && weights && alpha && sdf && gradient && pts,
               FGS_E_INVALID, "fgs_surv_compact: null pointer");
   CompactArgs C;
-  C.n_rays = n_rays; C.n_surv_total = n_surv_total; C.surv_off = surv_off; C.max_steps = max_steps;
+  C.n_rays = n_rays; C.n_surv_total = n_surv_total; C.m_dev = fgs_row_ptr(); C.surv_off = surv_off; C.max_steps = max_steps;
   C.surv_slot = surv_slot; C.a_step = a_step; C.a_alpha = a_alpha; C.a_weight = a_weight; C.a_sdf = a_sdf; C.a_grad = a_grad;
   C.rays_o = rays_o; C.rays_d = rays_d;
   C.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
@@ -411,7 +420,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
   MarchBwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.max_steps = max_steps;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.max_steps = max_steps;
   A.a_step = a_step; A.a_surv = a_surv; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf;
   A.a_grad = a_grad; A.n_alive = n_alive; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_sdf = g_sdf; A.g_gradient = g_gradient; A.grad_sdf_grid = grad_sdf_grid;

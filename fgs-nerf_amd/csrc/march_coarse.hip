@@ -28,6 +28,7 @@ struct CoarseArgs {
   const float *sdf_smooth;  // [X,Y,Z]
   const float *gradvol;     // [3,X,Y,Z]
   float dist, inv_s, thres;
+  const float *inv_s_dev;
   const float *mask_grid;
   SceneGeom mask_geom;
   float mask_thres;
@@ -51,6 +52,7 @@ __device__ __forceinline__ bool chain_step(float &T_cum, float alpha_j) {
 }
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_fwd(CoarseArgs A) {
+  if (A.inv_s_dev) A.inv_s = *A.inv_s_dev;
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (ray >= A.n_rays) return;
@@ -165,6 +167,7 @@ struct CoarseBwdArgs {
   int64_t n_rays;
   SceneGeom geom;
   float near, far, stepdist, dist, inv_s;
+  const float *inv_s_dev;
   int max_steps;
   const int *a_step;
   const float *a_alpha, *a_T, *a_weight, *a_sdf, *a_grad;
@@ -175,6 +178,7 @@ struct CoarseBwdArgs {
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A) {
+  if (A.inv_s_dev) A.inv_s = *A.inv_s_dev;
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (ray >= A.n_rays) return;
@@ -288,7 +292,7 @@ FGS_API int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = geom_make(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
   A.near = near; A.far = far; A.stepdist = stepdist; A.sdf_smooth = sdf_smooth; A.gradvol = gradvol;
-  A.dist = dist; A.inv_s = inv_s; A.thres = thres;
+  A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
   A.mask_grid = mask_grid; A.mask_geom = A.geom; A.mask_thres = mask_thres;
   if (mask_grid) {
     FGS_REQUIRE(mask_min_host && mask_max_host && mX > 1 && mY > 1 && mZ > 1, FGS_E_INVALID, "fgs_march_coarse_fwd: bad mask cache");
@@ -324,7 +328,7 @@ FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const
   CoarseBwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = geom_make(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.max_steps = max_steps;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.max_steps = max_steps;
   A.a_step = a_step; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf; A.a_grad = a_grad;
   A.n_alive = n_alive; A.n_surv = n_surv; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_gradient = g_gradient;

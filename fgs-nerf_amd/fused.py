@@ -122,6 +122,58 @@ class _Run:
     """Everything one forward produced that the backward needs (plain attribute bag)."""
 
 
+class _DeviceScalars:
+    """Sync-free mode: while active on this host thread, the kernels behind the C ABI take the survivor
+    count from device memory (fgs_set_row_count_ptr: the host value is the capacity of the buffers) and the NeuS 1/s from a
+    device float (fgs_set_inv_s_ptr).  No-op when both are None."""
+
+    def __init__(self, count=None, inv_s=None):
+        self.count, self.inv_s = count, inv_s
+
+    def __enter__(self):
+        if self.count is not None:
+            call("fgs_set_row_count_ptr", self.count)
+        if self.inv_s is not None:
+            call("fgs_set_inv_s_ptr", self.inv_s)
+        return self
+
+    def __exit__(self, *exc):
+        if self.count is not None:
+            call("fgs_set_row_count_ptr", None)
+        if self.inv_s is not None:
+            call("fgs_set_inv_s_ptr", None)
+        return False
+
+
+def set_sync_free(model, capacity=None, inv_s_dev=None) -> None:
+    """Switch the fused fine-stage path of `model` to the sync-free form (or back, with capacity=None): the survivor count
+    is never read by the host; result tensors, activations and gradients of the survivors are allocated for `capacity` rows
+    and every kernel clamps to the device-side count; a device-side guard records a count above the capacity (see
+    `sync_free_state`) and makes the optimizer skip that step.  `inv_s_dev`: optional 1-element float32 device tensor the
+    march kernels read 1/s from (a captured step cannot pass the iteration-dependent s_val by value).
+    Needs the register-resident MLP path (FGS_MLP=rc, the default) -- the split-K GEMMs partition by a host count."""
+    cache = model.__dict__.setdefault('_fused_cache', {})
+    if capacity is None:
+        cache.pop('sync_free', None)
+        return
+    dev = model.sdf.grid.device
+    buf = cache.get('sync_free_buffers')      # the guard's counters live as long as the model (captured kernels point at them)
+    if buf is None:
+        buf = cache['sync_free_buffers'] = dict(flags=torch.zeros(2, dtype=torch.int32, device=dev),
+                                                total=torch.zeros(1, dtype=I64, device=dev))
+    cache['sync_free'] = dict(capacity=int(capacity), inv_s_dev=inv_s_dev, flags=buf['flags'], total=buf['total'])
+
+
+def sync_free_state(model):
+    """(overflowed: bool, survivors_processed: int) since the counters were last cleared -- ONE device->host read; call it
+    at a logging interval, not per step."""
+    st = model.__dict__.get('_fused_cache', {}).get('sync_free_buffers')
+    if st is None:
+        return False, 0
+    flags, total = st['flags'].cpu(), st['total'].cpu()
+    return bool(flags[0]), int(total[0])
+
+
 def _detached(d):
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
 
@@ -180,6 +232,10 @@ def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
 _LINEAR_BWD_MODE = os.environ.get("FGS_LINEAR_BWD", "one")
 # forward chain of the fine stage: one persistent k_mlp_fwd launch (default) or one k_gemm launch per layer (FGS_MLP_FWD=layers)
 _MLP_FWD_ONE_LAUNCH = os.environ.get("FGS_MLP_FWD", "one") == "one"
+# MLP kernels: "rc" (default) = register-resident chains (csrc/mlp_rc.hip: forward chain and backward data-gradient chain, one
+# launch each) + every weight / bias gradient in one launch (csrc/mlp_wgrad.hip); "lds" = the LDS-resident forward chain and
+# one k_linear_bwd launch per layer (csrc/mlp_fused.hip, gemm_f32.hip)
+_MLP_IMPL = os.environ.get("FGS_MLP", "rc")
 _SIDE = {}   # device index -> (side stream, list of tensors to keep alive until the join)
 
 
@@ -268,6 +324,59 @@ def _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, a
     return dZ, dX0
 
 
+def _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
+    """Shapes the register-resident chains cover (a function of the model only: identical on every rank)."""
+    return (_MLP_IMPL == "rc" and rw == fw and rw % 32 == 0 and rw <= 256 and ldx0 <= 256 and 0 < ldz - rw <= 64 and
+            n_rgb + n_ref - 1 <= 8)
+
+
+def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
+                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs):
+    """FGS_MLP=rc: every 256-wide data gradient of the two MLPs in ONE register-resident launch (fgs_mlp_rc_chain on the
+    transposed weight images, ReLU masks from the 16-byte-per-lane sign bits the forward chain saved), the two narrow
+    products (the reflection-encoding columns of dZ, dX0) as plain NN GEMMs on the dY tensors the chain wrote out, then every
+    weight and bias gradient in ONE fgs_mlp_wgrad launch, written straight into the views of the flat gradient buffer."""
+    S = run.saved
+    dev = dY.device
+    bits = S['relu_bits']
+    layers = []
+    dY_ref = [None] * (n_ref - 1)            # dY_ref[i]: gradient w.r.t. the pre-activation output of refnet layer i
+    dY_ref[n_ref - 2] = dY
+    for i in range(n_ref - 2, 0, -1):        # g . W_i, masked by the ReLU of layer i - 1
+        out = torch.empty(M, fw, dtype=F32, device=dev)
+        layers.append(dict(W=ref_w[i], mask_bits=bits[n_rgb + i - 1], out=out, n_store=fw))
+        dY_ref[i - 1] = out
+    dZ = torch.empty(M, ldz, dtype=F32, device=dev)
+    layers.append(dict(W=ref_w[0][:, :rw], out=dZ, n_store=rw))      # no activation under refnet layer 0: no mask
+    dY_rgb = [None] * n_rgb                  # dY_rgb[i]: gradient w.r.t. the output of rgbnet layer i
+    dY_rgb[n_rgb - 1] = dZ[:, :rw]
+    for i in range(n_rgb - 1, 0, -1):
+        out = torch.empty(M, rw, dtype=F32, device=dev)
+        layers.append(dict(W=rgb_w[i], mask_bits=bits[i - 1], out=out, n_store=rw))
+        dY_rgb[i - 1] = out
+    fo.rc_chain(True, M, dY, fw, layers)
+    grp = PROFILE.get("open")
+    if grp is not None:
+        grp[0] += 1
+        grp[1] += 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
+    # narrow products
+    z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
+    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
+    dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+    _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw))
+    # all weight / bias gradients (the bias gradient of the top refnet layer came out of the head kernel)
+    items = []
+    for i in range(n_ref - 1):
+        items.append((dY_ref[i], acts_ref[i], gw_ref[i], None if i == n_ref - 2 else gb_ref[i], fw, ref_w[i].shape[1]))
+    for i in range(n_rgb):
+        items.append((dY_rgb[i], acts_rgb[i], gw_rgb[i], gb_rgb[i], rw, rgb_w[i].shape[1]))
+    fo.mlp_wgrad(M, items)
+    if grp is not None:
+        grp[0] += 1
+        grp[1] += 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w))
+    return dZ, dX0
+
+
 def _flush_tn(dev) -> None:
     """"late" mode: all weight-gradient products on the side stream, started when the data-gradient chain is done, so
     that they run under the atomics-bound scatter kernels that follow on the main stream."""
@@ -346,6 +455,8 @@ class _FusedFine(torch.autograd.Function):
         _own_workspace(run, any(ctx.needs_input_grad))
         # 1. march (alphainv_last is an output of this call: a fresh tensor per step, the other records live in `ws`)
         alphainv_last = torch.empty(N, dtype=F32, device=dev)
+        if run.sync_free and run.sync_free.get('inv_s_dev') is not None:
+            call("fgs_set_inv_s_ptr", ptr(run.sync_free['inv_s_dev']))    # reset by forward_fine()
         call("fgs_march_fine_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, ptr(sdf_grid), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
@@ -362,12 +473,20 @@ class _FusedFine(torch.autograd.Function):
         ref_b = [mlp[2 * (n_rgb + i) + 1] for i in range(n_ref)]
         rw, fw = rgb_w[0].shape[0], ref_w[0].shape[0]
         ldx0, ldz = run.ldx0, run.ldz
-        token = _count_begin(run, ws['surv_off'], N)
+        sf = run.sync_free
+        token = None if sf else _count_begin(run, ws['surv_off'], N)
         W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one fill + one copy launch each
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
         pre_k0 = _zeros_like_strided(k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M = _count_end(token)                      # the one host read of the step
+        if sf:
+            # sync-free: the count stays on the device (last entry of the survivor offsets); M is the CAPACITY from here on
+            M = sf['capacity']
+            run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
+            call("fgs_count_guard", ptr(ws['surv_off']), N + 1, M, ptr(sf['flags']), ptr(sf['total']), st)
+            call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_fine() when this forward returns
+        else:
+            M = _count_end(token)                  # the one host read of the step
         run.M = M
         # 2. survivors
         ray_id = torch.empty(M, dtype=I64, device=dev)
@@ -392,13 +511,35 @@ class _FusedFine(torch.autograd.Function):
              g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
              ptr(X0), ptr(Z), ptr(normal), st)
         # 4. MLPs
-        one_launch = (_MLP_FWD_ONE_LAUNCH and rw == 256 and fw == 256 and ldx0 <= 128 and 0 < ldz - rw <= 64 and
+        use_rc = _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and M > 0
+        one_launch = (not use_rc and _MLP_FWD_ONE_LAUNCH and rw == 256 and fw == 256 and ldx0 <= 128 and 0 < ldz - rw <= 64 and
                       n_rgb + n_ref - 1 <= 8)
-        grp = _gemm_group("forward chain (" + ("k_mlp_fwd: all layers in one launch" if one_launch
+        grp = _gemm_group("forward chain (" + ("k_mlp_rc: register-resident, all layers in one launch" if use_rc else
+                                               "k_mlp_fwd: all layers in one launch" if one_launch
                                                else "NT: k_gemm<true,true,0>") + ")").__enter__()
         acts_rgb = [X0] + [torch.empty(M, rw, dtype=F32, device=dev) for _ in range(n_rgb - 1)]   # input of each rgbnet layer
         acts_ref = [Z] + [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]    # input of each refnet layer
-        if one_launch:
+        relu_bits = None
+        if use_rc:
+            # ReLU sign bits of every hidden layer, 16 bytes per lane of each 32-sample group, one buffer for all layers
+            per = fo.rc_mask_bits(M, dev).numel()
+            relu_bits = torch.empty(n_rgb + n_ref - 1, per, dtype=torch.int32, device=dev)
+            layers = []
+            for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
+                last = i == n_rgb - 1
+                layers.append(dict(W=rgb_w[i].detach(), bias=rgb_b[i].detach(), relu=not last,
+                                   mask_bits=None if last else relu_bits[i], out=Z if last else acts_rgb[i + 1], n_store=rw))
+            for i in range(n_ref - 1):
+                L = dict(W=ref_w[i].detach(), bias=ref_b[i].detach(), relu=True, mask_bits=relu_bits[n_rgb + i],
+                         out=acts_ref[i + 1], n_store=fw)
+                if i == 0:
+                    L.update(ext=Z[:, rw:], ext_cols=ldz - rw)
+                layers.append(L)
+            fo.rc_chain(False, M, X0, ldx0, layers)
+            if PROFILE.get("open") is not None:
+                PROFILE["open"][0] += 1
+                PROFILE["open"][1] += 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
+        elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
                 layers.append((W0p if i == 0 else rgb_w[i].detach(), ldx0 if i == 0 else rw, rgb_b[i].detach(),
@@ -455,7 +596,8 @@ class _FusedFine(torch.autograd.Function):
         # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
-                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, WT=WT, pre_rgb=pre_rgb, pre_sig=pre_sig,
+                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, WT=WT, relu_bits=relu_bits,
+                                   pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
@@ -487,8 +629,11 @@ class _FusedFine(torch.autograd.Function):
         gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
         gb_rgb = views[n_rgb + n_ref:2 * n_rgb + n_ref]
         gb_ref = views[2 * n_rgb + n_ref:2 * n_rgb + 2 * n_ref]
-        gW0p, gV0p, cs = views[-3], views[-2], views[-1]       # where the other ranks' first-layer / last-bias gradients live
-        gw_rgb[0], gw_ref[0], gb_rgb[-1] = gW0p[:, :rgb_w[0].shape[1]], gV0p[:, :ref_w[0].shape[1]], cs[:rw]
+        if not _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref):
+            # the GEMM path keeps the first-layer weight gradients in K-padded slots and the last rgbnet bias gradient in the
+            # column-sum slot: that is where the other ranks' contributions arrive
+            gW0p, gV0p, cs = views[-3], views[-2], views[-1]
+            gw_rgb[0], gw_ref[0], gb_rgb[-1] = gW0p[:, :rgb_w[0].shape[1]], gV0p[:, :ref_w[0].shape[1]], cs[:rw]
         grads = [None, grad_sdf, grad_k0]
         for i in range(n_rgb):
             grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
@@ -498,7 +643,15 @@ class _FusedFine(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
+    def backward(ctx, *grads):
+        run = ctx.run
+        sf = run.sync_free
+        inv = ptr(sf['inv_s_dev']) if (sf and sf.get('inv_s_dev') is not None) else None
+        with _DeviceScalars(count=run.count_ptr if sf else None, inv_s=inv):    # (the autograd thread has its own setting)
+            return _FusedFine._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
         run = ctx.run
         if run.done:
             raise RuntimeError("fused forward_fine: backward called twice on the same forward (its march records are released "
@@ -552,7 +705,10 @@ class _FusedFine(torch.autograd.Function):
         gW0p, gV0p, cs = views[-3], views[-2], views[-1]
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
-        if S.get('WT') is not None and ldx0 <= 256:
+        if S.get('relu_bits') is not None:
+            dZ, dX0 = _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
+                                   gw_rgb, gb_rgb, gw_ref, gb_ref, cs)
+        elif S.get('WT') is not None and ldx0 <= 256:
             dZ, dX0 = _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
                                       gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs)
         else:
@@ -580,7 +736,8 @@ class _FusedFine(torch.autograd.Function):
                     d_in = torch.empty(M, rw, dtype=F32, device=dev)
                     _linear_bwd(dY, rgb_w[i], a_in, d_in, gw_rgb[i], M, rw, rw, mask=a_in, colsum=gb_rgb[i - 1])
                     dY = d_in
-        gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
+        if S.get('relu_bits') is None:
+            gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
@@ -952,6 +1109,8 @@ def _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, defa
     run.inv_s = float(np.float32(1.0) / s32)
     run.max_steps = int(math.ceil(run.geom.diag / run.stepdist)) + 2
     run.workspace = _workspace(model, N, run.max_steps, rays_o.device)
+    run.sync_free = run.cache.get('sync_free')
+    run.count_ptr = None
     run.render_grad = bool(render_kwargs.get('render_grad', False))
     run.render_depth = bool(render_kwargs.get('render_depth', default_depth))
     return run, s_val
@@ -1041,8 +1200,16 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     mlp = []
     for layer in rl + fl:
         mlp += [layer.weight, layer.bias]
-    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
-        run, model.sdf.grid, model.k0.grid, *mlp)
+    if run.sync_free and not _rc_eligible(rl[0].out_features, fl[0].out_features, run.ldx0, run.ldz, len(rl), len(fl)):
+        raise RuntimeError("the sync-free fine-stage path needs the register-resident MLP kernels (FGS_MLP=rc and equal "
+                           "rgbnet / refnet widths that are multiples of 32, <= 256)")
+    try:
+        (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
+            run, model.sdf.grid, model.k0.grid, *mlp)
+    finally:
+        if run.sync_free:
+            call("fgs_set_row_count_ptr", None)
+            call("fgs_set_inv_s_ptr", None)
     ex = run.extras
     depth = ex['depth']
 
@@ -1078,7 +1245,10 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
-             'survivor_pts': run.saved['pts']}
+             'survivor_pts': run.saved['pts'],
+             # sync-free mode: the per-survivor entries above have CAPACITY rows; the rows that count are the first
+             # *survivor_count_ptr (a device int64), which consumers pass on through fgs_set_row_count_ptr
+             'survivor_count_ptr': run.count_ptr}
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks, 'viewdirs': lambda: run.viewdirs[ray_id]})
 
 

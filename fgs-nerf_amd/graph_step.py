@@ -1,0 +1,156 @@
+"""A whole fine-stage training iteration as ONE hipGraph replay (the step with no host round trip).
+
+The reference's iteration (model/nerf_training.py:237-300,374-385) touches the host about a dozen times; the fused path of
+this build still read the survivor count back once per step and spent ~2 ms of Python per 2.3 ms step.  Here nothing of a
+step's data ever reaches the host:
+
+* the survivor count M_s stays in device memory; result tensors, activations and gradients are allocated once for a fixed
+  CAPACITY of rows and every kernel behind the C ABI clamps to the device-side count (fgs_set_row_count_ptr);
+* the per-iteration scalars -- Adam's step size of every parameter group, NeuS 1/s -- are rows of a table the host fills once
+  per stage with the same float arithmetic the per-call entry points use (fgs_adam_step_size; the reference's s_val formula);
+  a one-wave kernel copies this iteration's row into device scalars and advances a device counter (fgs_step_scalars_tick);
+* with no host-visible value left in the step, forward + losses + backward + TV + MaskedAdam are captured in a hipGraph
+  (torch.cuda.CUDAGraph: PyTorch provides the capture plumbing and the private memory pool; every node is one of this
+  library's kernels or a memset) and an iteration is: four small device copies of the ray batch + one graph launch.
+* a survivor count above the capacity cannot corrupt anything: a guard kernel flags it, the optimizer kernels skip the update
+  of that step, and the host learns about it at its next `check()` (one read, at a logging interval) and can redo the batch
+  eagerly or re-capture with a larger capacity.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import fused
+from ._lib import call, lib, ptr, stream
+from .losses import fused_render_losses
+
+
+class CapturedFineStep:
+    """One captured iteration of the fine stage.
+
+    model, optimizer : a fused-path `nerf` model (stage 'fine') and its MaskedAdam
+    loss_cfg         : the loss weights (config keys of model/nerf_training.py:308-327)
+    render_kwargs    : near / far / bg / stepsize ... as passed to model.forward
+    n_rays           : rays per step (static)
+    n_iters          : rows of the schedule table (iterations this stage may run; the last row repeats beyond it)
+    global_step_of   : iteration index (0-based) -> global_step handed to the render (s_val schedule, model/nerf.py:514)
+    lr_of            : (iteration index, param-group dict) -> learning rate used by that iteration's Adam update
+    tv               : None, or (weight, dense) for model.sdf_total_variation_add_grad after the backward pass
+    capacity         : rows the survivor buffers hold (see fused.set_sync_free)
+    """
+
+    def __init__(self, model, optimizer, loss_cfg: Dict, render_kwargs: Dict, n_rays: int, n_iters: int,
+                 global_step_of: Callable[[int], int], lr_of: Callable[[int, Dict], float], tv=None,
+                 capacity: int = 131072):
+        if not fused.supports(model):
+            raise RuntimeError("CapturedFineStep needs a model the fused fine-stage path covers")
+        self.model, self.opt, self.loss_cfg, self.kw, self.tv = model, optimizer, dict(loss_cfg), dict(render_kwargs), tv
+        self.n_rays, self.capacity = int(n_rays), int(capacity)
+        dev = model.sdf.grid.device
+        self.dev = dev
+        # ---- schedule table: column 0 = inv_s, column 1 + g = Adam step size of param group g
+        groups = optimizer.param_groups
+        optimizer.ensure_state()
+        base_step = [max([optimizer.state[p]['step'] for p in g['params'] if p in optimizer.state] or [0]) for g in groups]
+        step_size = lib().fgs_adam_step_size
+        table = np.zeros((n_iters, 1 + len(groups)), dtype=np.float32)
+        for it in range(n_iters):
+            s_val = model._s_val_for(global_step_of(it), True)
+            table[it, 0] = np.float32(1.0) / np.float32(s_val)          # model/nerf.py:522: ones(1) / s_val in float32
+            for gi, g in enumerate(groups):
+                b1, b2 = g['betas']
+                table[it, 1 + gi] = step_size(base_step[gi] + it + 1, float(b1), float(b2), float(lr_of(it, g)))
+        self.table = torch.from_numpy(table).to(dev)
+        self.n_iters, self.n_cols = n_iters, table.shape[1]
+        self.scalars = torch.zeros(self.n_cols, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.iteration = 0
+        # ---- static inputs
+        self.rays_o, self.rays_d, self.viewdirs, self.target = (torch.zeros(n_rays, 3, device=dev) for _ in range(4))
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss = None
+
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _enter(self):
+        fused.set_sync_free(self.model, self.capacity, inv_s_dev=self.scalars[0:1])
+        st = self.model._fused_cache['sync_free']
+        self.opt.use_device_schedule({gi: self.scalars[1 + gi:2 + gi].data_ptr() for gi in range(len(self.opt.param_groups))},
+                                     skip_ptr=st['flags'][1:2].data_ptr())
+
+    def _leave(self):
+        fused.set_sync_free(self.model, None)
+        self.opt.use_device_schedule(None)
+
+    def _body(self, update: bool):
+        if True:     # (the warm-up pass ticks too, so that it renders with a real 1/s; capture() rewinds the counter)
+            call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
+                 stream())
+        # (global_step only selects the training branch here: 1/s comes from the device scalars)
+        res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
+        # model.s_val mirrors the schedule (model/nerf.py:520 refreshes it in every forward): 1 / (1/s) from the device scalar
+        torch.reciprocal(self.scalars[0:1], out=self.model.s_val.data)
+        loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if update:
+            if self.tv is not None:
+                self.model.sdf_total_variation_add_grad(self.tv[0], self.tv[1])
+            self.opt.step()
+        return loss
+
+    def capture(self, batch: Sequence[torch.Tensor]) -> None:
+        """Warm up (one eager forward + backward in the sync-free form on `batch`, no update: allocator pools, cached host
+        copies of the geometry) and capture the step."""
+        self.load(batch)
+        self._enter()
+        try:
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._body(update=False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.opt.zero_grad(set_to_none=True)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._body(update=True)
+        finally:
+            self._leave()
+        # the capture pass itself launches nothing; schedule and counters start from a clean state
+        self.counter.zero_()
+        self.clear_counters()
+
+    # ------------------------------------------------------------------------------------------------ per iteration
+    def load(self, batch: Sequence[torch.Tensor]) -> None:
+        ro, rd, vd, target = batch
+        self.rays_o.copy_(ro, non_blocking=True)
+        self.rays_d.copy_(rd, non_blocking=True)
+        self.viewdirs.copy_(vd, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+
+    def replay(self, batch: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """One training iteration: (optionally) copy the batch into the static inputs, launch the graph.  Returns the
+        device scalar holding this iteration's loss (overwritten by the next replay)."""
+        if batch is not None:
+            self.load(batch)
+        self.graph.replay()
+        self.iteration += 1
+        for g in self.opt.param_groups:                    # host mirror of the step counters (state_dict, schedules)
+            for p in g['params']:
+                st = self.opt.state.get(p)
+                if st:
+                    st['step'] += 1
+        return self.loss
+
+    def clear_counters(self) -> None:
+        buf = self.model._fused_cache['sync_free_buffers']
+        buf['flags'].zero_()
+        buf['total'].zero_()
+
+    def check(self):
+        """(overflowed, survivors processed since the last clear) -- one device->host read; not for every step."""
+        return fused.sync_free_state(self.model)

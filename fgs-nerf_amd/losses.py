@@ -40,17 +40,25 @@ def _w5(cfg):
                                 float(cfg.get('sigmoid_rgb_loss', 0)))
 
 
+def _rows(count_ptr):
+    """Sync-free results carry the device address of their survivor count: their per-survivor arrays have CAPACITY rows."""
+    from .fused import _DeviceScalars
+    return _DeviceScalars(count=count_ptr)
+
+
 class _FineLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_marched, sigmoid_rgb, alphainv_cum, normal, raw_rgb, weights, ray_id, ray_viewdirs, target, w5):
+    def forward(ctx, rgb_marched, sigmoid_rgb, alphainv_cum, normal, raw_rgb, weights, ray_id, ray_viewdirs, target, w5,
+                count_ptr=None):
         N, M = rgb_marched.shape[0], weights.shape[0]
         loss = torch.empty((), dtype=torch.float32, device=rgb_marched.device)
         args = (rgb_marched.contiguous(), sigmoid_rgb.contiguous(), target.contiguous(), alphainv_cum.contiguous(),
                 weights.contiguous(), normal.contiguous(), raw_rgb.contiguous(), ray_id.contiguous(),
                 ray_viewdirs.contiguous())
-        call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), stream())
+        with _rows(count_ptr):
+            call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), stream())
         ctx.save_for_backward(*args)
-        ctx.w5 = w5
+        ctx.w5, ctx.count_ptr = w5, count_ptr
         return loss
 
     @staticmethod
@@ -64,9 +72,10 @@ class _FineLoss(torch.autograd.Function):
         g_last = torch.empty(N, dtype=torch.float32, device=dev)
         g_normal = torch.empty(M, 3, dtype=torch.float32, device=dev)
         g_raw = torch.empty(M, 3, dtype=torch.float32, device=dev) if ctx.w5[1] > 0 else None
-        call("fgs_fine_loss_bwd", N, M, *(ptr(a) for a in args), ctx.w5, ptr(grad_out.contiguous()), ptr(g_rm), ptr(g_sr),
-             ptr(g_last), ptr(g_normal), ptr(g_raw), stream())
-        return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None
+        with _rows(ctx.count_ptr):
+            call("fgs_fine_loss_bwd", N, M, *(ptr(a) for a in args), ctx.w5, ptr(grad_out.contiguous()), ptr(g_rm), ptr(g_sr),
+                 ptr(g_last), ptr(g_normal), ptr(g_raw), stream())
+        return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None, None
 
 
 def fused_render_losses(res, target, cfg, model=None):
@@ -75,4 +84,4 @@ def fused_render_losses(res, target, cfg, model=None):
     if rv is None or not res['rgb_marched'].is_cuda:
         return render_losses(res, target, cfg, model)
     return _FineLoss.apply(res['rgb_marched'], res['sigmoid_rgb'], res['alphainv_cum'], res['normal'], res['raw_rgb'],
-                           res['weights'], res['ray_id'], rv, target, _w5(cfg))
+                           res['weights'], res['ray_id'], rv, target, _w5(cfg), res.get('survivor_count_ptr'))

@@ -201,6 +201,7 @@ class nerf(torch.nn.Module):
         self.voxel_size = ((self.xyz_max - self.xyz_min).prod() / num_voxels).pow(1 / 3)
         self.world_size = ((self.xyz_max - self.xyz_min) / self.voxel_size).long()
         self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
+        self._world_size_max = None         # host copy of world_size.max(), fetched once per resolution (TV weights)
 
     def get_kwargs(self):
         """model/nerf.py:309-328."""
@@ -386,13 +387,25 @@ class nerf(torch.nn.Module):
 
     def k0_total_variation_add_grad(self, weight, dense_mode=True):
         """model/nerf.py:461-463."""
-        w = weight * self.world_size.max() / 128
+        w = self._tv_weight(weight)
         self.k0.total_variation_add_grad(w, w, w, dense_mode)
 
     def sdf_total_variation_add_grad(self, weight, dense_mode):
         """model/nerf.py:465-467."""
-        w = weight * self.world_size.max() / 128
+        w = self._tv_weight(weight)
         self.sdf.total_variation_add_grad(w, w, w, dense_mode)
+
+    def _tv_weight(self, weight) -> float:
+        """`weight * self.world_size.max() / 128` (model/nerf.py:462,466) with the reference's float32 tensor arithmetic
+        (python scalar x int64 tensor -> float32 product, float32 division) done on the host."""
+        return float(np.float32(weight) * np.float32(self._world_max()) / np.float32(128))
+
+    def _world_max(self) -> int:
+        """world_size.max() as a host integer: the reference multiplies a Python float by the (device) tensor and hands the
+        0-d result to the TV kernel wrapper, one device->host read per call; the value only changes with the resolution."""
+        if getattr(self, '_world_size_max', None) is None:
+            self._world_size_max = int(self.world_size.max())
+        return self._world_size_max
 
     def orientation_loss(self, render_result):
         """model/nerf.py:469-478 (Ref-NeRF orientation regulariser)."""

@@ -43,6 +43,30 @@ int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wa
  * number, so nothing in a step waits for a device->host copy and the whole step can be captured in a hipGraph.
  * NULL (the default) restores plain host counts.  The pointer must stay valid while launches issued under it run. */
 int fgs_set_row_count_ptr(const int64_t *count_dev);
+/* The same for the NeuS sharpness: while set, the march kernels (fgs_march_*) read inv_s = 1 / s_val from this device float
+ * instead of their argument (model/nerf.py:514,522: s_val follows the iteration number, which a captured step cannot pass by
+ * value).  NULL restores the argument. */
+int fgs_set_inv_s_ptr(const float *inv_s_dev);
+/* Device-resident schedule of a captured training step (model/nerf_training.py:389-436, model/adam.py:205-221).  `table` is
+ * [n_rows][n_cols] floats the host fills once per stage -- row = iteration, columns = whatever per-iteration scalars the
+ * step's kernels read (Adam step sizes from fgs_adam_step_size, inv_s).  fgs_step_scalars_tick copies row
+ * min(*counter, n_rows - 1) to out[0..n_cols) and increments *counter.
+ * fgs_count_guard: `offsets` [n] are the per-ray survivor offsets of the march kernels, offsets[n-1] the survivor count.
+ * flags[1] = (count > capacity), flags[0] |= flags[1] (sticky), *total += min(count, capacity) (total may be NULL), and every
+ * offset above the capacity is cut to it, so the per-ray segments later kernels walk stay inside buffers of `capacity` rows.
+ * The optimizer entry points below skip their update while *skip_dev != 0: a step whose survivor list did not fit changes
+ * nothing and the host can redo it (it learns about it from flags[0] whenever it next looks). */
+float fgs_adam_step_size(int step, float beta1, float beta2, float lr);      /* adam_upd_kernel.cu:72, all-float */
+int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, fgs_stream_t stream);
+int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream);
+/* fgs_adam_upd / fgs_adam_upd_multi with the step size read from device memory (one float per call / per tensor) and an
+ * optional skip flag; everything else as in the host-scalar forms. */
+int fgs_adam_upd_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
+                     const float *step_size_dev, float beta1, float beta2, float eps, int mode, const int *skip_dev,
+                     fgs_stream_t stream);
+int fgs_adam_upd_multi_dev(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
+                           float *const *exp_avg_sqs, const int64_t *sizes, const float *const *step_size_dev,
+                           const int *masked, float beta1, float beta2, float eps, const int *skip_dev, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * render_utils_cuda  (model/cuda/render_utils.cpp:170-184)

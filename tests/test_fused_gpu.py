@@ -340,6 +340,7 @@ def test_backward_chain_mode_matches_default_mode(dev, monkeypatch):
     target = torch.rand(700, 3, generator=torch.Generator().manual_seed(9)).to(dev)
     lossw = dict(synth.FINE_LOSS, weight_rgbper=0.05)
     got = {}
+    monkeypatch.setattr(fused, "_MLP_IMPL", "lds")           # these are modes of the LDS-resident / per-layer GEMM path
     for mode in ("one", "chain"):
         monkeypatch.setattr(fused, "_LINEAR_BWD_MODE", mode)
         model = synth.build_model(48, synth.FINE_MODEL, device=dev)
@@ -430,3 +431,24 @@ def test_two_forwards_before_their_backwards_keep_their_own_records(dev, stage):
     l3.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="backward called twice"):
         l3.backward()
+
+
+@pytest.mark.parametrize("G,N", [(48, 700), (32, 33)])
+def test_register_resident_mlp_path_matches_the_gemm_path(dev, monkeypatch, G, N):
+    """FGS_MLP=rc (default: register-resident forward / backward chains + one-launch weight gradients) against FGS_MLP=lds
+    (LDS-resident forward chain, one k_linear_bwd per layer) on the same step.  The two sum every dot product in a different
+    order, so outputs agree to fp32 rounding (1e-6), gradients to the order / ReLU-flip tolerance of the other mode tests."""
+    from fgs_nerf_amd import fused, synth
+    rays = tuple(r.to(dev) for r in synth.random_rays(N, seed=5))
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    lossw = dict(synth.FINE_LOSS, weight_rgbper=0.05)
+    got = {}
+    for impl in ("rc", "lds"):
+        monkeypatch.setattr(fused, "_MLP_IMPL", impl)
+        model = synth.build_model(G, synth.FINE_MODEL, device=dev)
+        res, loss = run_step(model, rays, target, lossw)
+        got[impl] = (res["rgb_marched"].clone(), res["raw_rgb"].clone(), float(loss), {k: v.clone() for k, v in grads_of(model).items()})
+    assert rel_l2(got["rc"][0], got["lds"][0]) < 1e-6 and rel_l2(got["rc"][1], got["lds"][1]) < 2e-6
+    assert abs(got["rc"][2] - got["lds"][2]) < 1e-6
+    for k, v in got["lds"][3].items():
+        assert rel_l2(got["rc"][3][k], v) < 1e-4, (k, rel_l2(got["rc"][3][k], v))
