@@ -121,7 +121,7 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   d.lim_a = M * b.ld_dy - 4; d.lim_b = M * b.ld_x - 4;
   int64_t issue_c = c0;
   int issue_slot = 0;
-  auto dma_begin = [&]() {
+  auto dma_begin = [&]() __attribute__((always_inline)) {
     d.off_a = issue_c * WG_ROWS * b.ld_dy; d.off_b = issue_c * WG_ROWS * b.ld_x;
     d.dst = lds + issue_slot * WG_SLOT;
     d.p = wave;
@@ -148,7 +148,14 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
 #pragma unroll
     for (int t = 0; t < NCTW; ++t) fb[0][t] = S[offB[t]];
   }
-  for (int64_t c = c0; c < c1; ++c) {
+  // FAST form of a chunk: both leading dimensions are 256 (LDS row offsets become instruction immediates: no address
+  // arithmetic per k-step), every row and column of the block exists and the chunk lies fully inside the sample range (no
+  // zeroing selects) -- 8 ds_read_b32 and 4 adds beside the 16 MFMAs of a k-step instead of ~40 instructions.  That is the
+  // shape of five of the seven fine-stage products; everything else, and the last partial chunk, takes the general form.
+  const bool block_fast = NCTW == 4 && ld_a == 256 && ld_b == 256 && b.n_out == 256 && b.col0 + 256 <= b.n_in;
+  auto chunk = [&](int64_t c, auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int lda = FAST ? 256 : ld_a, ldb = FAST ? 256 : ld_b;
     const float *S = lds + slot * WG_SLOT;
     slot = slot + 1 == WG_SLOTS ? 0 : slot + 1;
     const float *S_next = (c + 1 < c1) ? lds + slot * WG_SLOT : nullptr;
@@ -163,15 +170,15 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
       const bool live = 2 * s + h < rows_left;           // rows beyond M hold whatever the clamped DMA brought: zero them
       float av[4], bv[NCTW];
 #pragma unroll
-      for (int ta = 0; ta < 4; ++ta) av[ta] = (live && okA[ta]) ? fa[s & 1][ta] : 0.f;
+      for (int ta = 0; ta < 4; ++ta) av[ta] = (FAST || (live && okA[ta])) ? fa[s & 1][ta] : 0.f;
 #pragma unroll
-      for (int tb = 0; tb < NCTW; ++tb) bv[tb] = (live && okB[tb]) ? fb[s & 1][tb] : 0.f;
+      for (int tb = 0; tb < NCTW; ++tb) bv[tb] = (FAST || (live && okB[tb])) ? fb[s & 1][tb] : 0.f;
       __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < WG_ROWS / 2) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fa[(s + 1) & 1][t] = S[(2 * s + 2) * ld_a + offA[t]];
+        for (int t = 0; t < 4; ++t) fa[(s + 1) & 1][t] = S[(2 * s + 2) * lda + offA[t]];
 #pragma unroll
-        for (int t = 0; t < NCTW; ++t) fb[(s + 1) & 1][t] = S[(2 * s + 2) * ld_b + offB[t]];
+        for (int t = 0; t < NCTW; ++t) fb[(s + 1) & 1][t] = S[(2 * s + 2) * ldb + offB[t]];
       } else if (S_next) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) fa[(s + 1) & 1][t] = S_next[offA[t]];
@@ -201,6 +208,14 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+  };
+  {
+    int64_t c = c0;
+    if (NCTW == 4 && block_fast) {
+      const int64_t c_full = M / WG_ROWS < c1 ? M / WG_ROWS : c1;     // chunks [c0, c_full) have all 16 sample rows
+      for (; c < c_full; ++c) chunk(c, std::integral_constant<bool, NCTW == 4>{});
+    }
+    for (; c < c1; ++c) chunk(c, std::integral_constant<bool, false>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- flush: dW block and bias sums, fp32 atomics (two 128-byte row segments per instruction)

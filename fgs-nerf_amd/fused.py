@@ -875,15 +875,28 @@ class _FusedCoarse(torch.autograd.Function):
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         call("fgs_feat_coarse_fwd", M, ptr(ray_id), ptr(pts), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c, g.X, g.Y,
              g.Z, run.layout_i, ptr(k0_grid), ksC, ksX, ksY, ksZ, ptr(X0), ptr(normal), st)
-        grp = _gemm_group("forward chain (NT: k_gemm<true,true,0>)").__enter__()
+        use_rc = _MLP_IMPL == "rc" and fw % 32 == 0 and fw <= 256 and ldx0 <= 256 and n_ref - 1 <= 8 and M > 0
+        grp = _gemm_group("forward chain (" + ("k_mlp_rc: register-resident, all layers in one launch" if use_rc
+                                               else "NT: k_gemm<true,true,0>") + ")").__enter__()
         acts = [X0]
         a = X0
-        for i in range(n_ref - 1):
-            out = torch.empty(M, fw, dtype=F32, device=dev)
-            _gemm(fo.GEMM_NT, a, V0p if i == 0 else ref_w[i].detach(), out, M, fw, ldx0 if i == 0 else fw,
-                  bias=ref_b[i].detach(), relu=True, logical=(M, fw, ref_w[i].shape[1]))
-            a = out
-            acts.append(out)
+        relu_bits = None
+        if use_rc:       # widths 192 (coarse) and 128 (geometry_searching): the same register-resident chain as the fine stage
+            relu_bits = torch.empty(n_ref - 1, fo.rc_mask_bits(M, dev).numel(), dtype=torch.int32, device=dev)
+            acts += [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]
+            fo.rc_chain(False, M, X0, ldx0, [dict(W=ref_w[i].detach(), bias=ref_b[i].detach(), relu=True, mask_bits=relu_bits[i],
+                                                   out=acts[i + 1], n_store=fw) for i in range(n_ref - 1)])
+            a = acts[-1]
+            if PROFILE.get("open") is not None:
+                PROFILE["open"][0] += 1
+                PROFILE["open"][1] += 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1])
+        else:
+            for i in range(n_ref - 1):
+                out = torch.empty(M, fw, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NT, a, V0p if i == 0 else ref_w[i].detach(), out, M, fw, ldx0 if i == 0 else fw,
+                      bias=ref_b[i].detach(), relu=True, logical=(M, fw, ref_w[i].shape[1]))
+                a = out
+                acts.append(out)
         grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
         call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
@@ -900,7 +913,7 @@ class _FusedCoarse(torch.autograd.Function):
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
                        pre_k0 if pre_k0 is not None else _zeros_like_strided(k0_grid))
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
-                                   V0p=V0p, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
+                                   V0p=V0p, relu_bits=relu_bits, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
@@ -946,7 +959,8 @@ class _FusedCoarse(torch.autograd.Function):
                 hook('join', None)
             elif opt_hook is not None:
                 opt_hook(k0_grid, grad_k0)
-            gw[0] = gV0p[:, :ref_w[0].shape[1]]
+            if not (_MLP_IMPL == "rc" and fw % 32 == 0 and fw <= 256 and ldx0 <= 256 and n_ref - 1 <= 8):
+                gw[0] = gV0p[:, :ref_w[0].shape[1]]          # (the GEMM path keeps dW0 in the K-padded slot)
             grads = [None, torch.zeros(1, 1, g.X, g.Y, g.Z, dtype=F32, device=dev),
                      torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev), grad_k0]
             for i in range(n_ref):
@@ -962,17 +976,42 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
              ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), st)
         dX0 = None
-        grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
-        for i in range(n_ref - 2, -1, -1):
-            a_in = acts[i]
-            if i == 0:
-                dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _linear_bwd(dY, S['V0p'], a_in, dX0, gV0p, M, fw, ldx0, logical_k_in=ref_w[0].shape[1])
-            else:
-                d_in = torch.empty(M, fw, dtype=F32, device=dev)
-                _linear_bwd(dY, ref_w[i], a_in, d_in, gw[i], M, fw, fw, mask=a_in, colsum=gb[i - 1])
-                dY = d_in
-        gw[0] = gV0p[:, :ref_w[0].shape[1]]
+        grp = _gemm_group("backward chain (" + ("rc" if S.get('relu_bits') is not None else _LINEAR_BWD_MODE) + ")").__enter__()
+        if S.get('relu_bits') is not None:
+            # register-resident data-gradient chain (layers n_ref-2 .. 1), dX0 as one narrow NN product, every weight / bias
+            # gradient in one fgs_mlp_wgrad launch straight into the views of the flat buffer
+            bits = S['relu_bits']
+            dYs = [None] * (n_ref - 1)
+            dYs[n_ref - 2] = dY
+            layers = []
+            for i in range(n_ref - 2, 0, -1):
+                out = torch.empty(M, fw, dtype=F32, device=dev)
+                layers.append(dict(W=ref_w[i], mask_bits=bits[i - 1], out=out, n_store=fw))
+                dYs[i - 1] = out
+            g_ = PROFILE.get("open")
+            if layers:
+                fo.rc_chain(True, M, dY, fw, layers)
+                if g_ is not None:
+                    g_[0] += 1
+                    g_[1] += 2.0 * M * fw * fw * len(layers)
+            dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+            _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
+            fo.mlp_wgrad(M, [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
+                             for i in range(n_ref - 1)])
+            if g_ is not None:
+                g_[0] += 1
+                g_[1] += 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1])
+        else:
+            for i in range(n_ref - 2, -1, -1):
+                a_in = acts[i]
+                if i == 0:
+                    dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+                    _linear_bwd(dY, S['V0p'], a_in, dX0, gV0p, M, fw, ldx0, logical_k_in=ref_w[0].shape[1])
+                else:
+                    d_in = torch.empty(M, fw, dtype=F32, device=dev)
+                    _linear_bwd(dY, ref_w[i], a_in, d_in, gw[i], M, fw, fw, mask=a_in, colsum=gb[i - 1])
+                    dY = d_in
+            gw[0] = gV0p[:, :ref_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
