@@ -66,6 +66,7 @@ _SIGNATURES = {
     "fgs_brick_scatter": [P, I32, I32, I32, I32, P, I64, P, F32, P],
     "fgs_brick_flags_pts": [P, I64, P, P, I32, I32, I32, P, P],
     "fgs_brick_compact": [P, I64, P, P, P],
+    "fgs_adam_upd_bricks": [P, P, P, P, I32, I32, I32, I32, P, P, I64, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_multi": [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P],
     "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_fine_loss_bwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],

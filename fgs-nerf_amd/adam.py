@@ -88,6 +88,32 @@ class MaskedAdam(torch.optim.Optimizer):
         lrs = (ctypes.c_float * n)(*[row[5] for row in batch])
         call("fgs_adam_upd_multi", n, *tables, sizes, steps, lrs, masked, float(b1), float(b2), float(eps), stream())
 
+    def _bricks(self, p, g, group, st, dev=None, ss_ptr=None) -> bool:
+        """The masked update of a feature grid whose gradient lives in fused.py's persistent self-cleaning buffer: visit
+        only the 4x4x4-voxel bricks recorded for this step (`p._fgs_touched`, fused._publish_touched / dist.GradAverager)
+        and zero the gradient consumed (fgs_adam_upd_bricks; per element the arithmetic of masked_adam_upd,
+        model/cuda/adam_upd_kernel.cu:25-40).  False -> the record is absent or no longer describes `g` (something else
+        wrote into the gradient): the caller takes the dense kernels, and the buffer is zero-filled before its next use."""
+        t = getattr(p, '_fgs_touched', None)
+        if t is None:
+            return False
+        p._fgs_touched = None
+        gb = t['state']
+        if not (t['valid'] and group['skip_zero_grad'] and g.data_ptr() == t['grad_ptr'] and gb['buf']._version == t['version']
+                and tuple(p.shape) == gb['key'][0] and p.stride() == gb['key'][1] and p.data_ptr() != g.data_ptr()):
+            return False
+        if (self.per_lr is not None and p.shape == self.per_lr.shape) or (t['exchange'] and t['idx'] is None):
+            return False
+        from ._lib import ptr
+        b1, b2 = group['betas']
+        idx, n = t['idx'], t['n']
+        call("fgs_adam_upd_bricks", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'],
+             ptr(idx) if idx is not None else None, None, int(n) if idx is not None else 0, ptr(t['flags']),
+             int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']),
+             ss_ptr if dev is not None else None, dev['skip'] if dev is not None else None, stream())
+        gb['clean'] = True
+        return True
+
     def _update_one(self, p, g, group):
         """The reference's per-tensor rule (model/adam.py:205-221) for one big tensor."""
         b1, b2 = group['betas']
@@ -96,7 +122,9 @@ class MaskedAdam(torch.optim.Optimizer):
         st['step'] += 1
         g = _as_layout_of(g, p)
         m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
-        if self.per_lr is not None and p.shape == self.per_lr.shape:
+        if self._bricks(p, g, group, st):
+            pass
+        elif self.per_lr is not None and p.shape == self.per_lr.shape:
             adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
         elif group['skip_zero_grad']:
             adam_upd_cuda.masked_adam_upd(p, g, m, v, t, *hyper)
@@ -148,6 +176,8 @@ class MaskedAdam(torch.optim.Optimizer):
                 st = self._state_of(p)
                 g = _as_layout_of(p.grad, p)
                 m, v = st['exp_avg'], st['exp_avg_sq']
+                if self._bricks(p, g, group, st, dev=dev, ss_ptr=ss_ptr):
+                    continue
                 if self.per_lr is not None and p.shape == self.per_lr.shape:
                     mode, perlr = 2, _as_layout_of(self.per_lr, p)
                 elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
@@ -178,7 +208,9 @@ class MaskedAdam(torch.optim.Optimizer):
                 st['step'] += 1
                 g = _as_layout_of(p.grad, p)
                 m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
-                if self.per_lr is not None and p.shape == self.per_lr.shape:
+                if self._bricks(p, g, group, st):
+                    pass
+                elif self.per_lr is not None and p.shape == self.per_lr.shape:
                     adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
                 elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
                     small.append((p, g, m, v, t, group['lr'], masked))

@@ -64,10 +64,11 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_brick_copy(float *__restrict__ gr
 // flags[b] = 1 for every brick holding one of the 8 trilinear corners of a sample point: the bricks a DenseGrid backward
 // (fgs_trilerp_bwd / k_feat_k0_bwd) can write for these points -- known as soon as the forward has its survivor list,
 // i.e. ~2 ms before the gradient itself exists.  Plain stores of the same value: the race is benign.
-__global__ __launch_bounds__(FGS_BLOCK) void k_brick_flags_pts(const float *__restrict__ pts, int64_t M, SceneGeom sg,
+__global__ __launch_bounds__(FGS_BLOCK) void k_brick_flags_pts(const float *__restrict__ pts, int64_t M,
+                                                               const int64_t *__restrict__ m_dev, SceneGeom sg,
                                                                BrickGrid g, int *__restrict__ flags) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+  if (m >= fgs_rows(M, m_dev)) return;
   const GridDesc d = fgs_sdf_desc(sg);
   const PointIdx p = fgs_point_to_index(pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], sg.lo, sg.hi, d);
   const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
@@ -119,6 +120,12 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_brick_compact(const int *__
   if (t == 0 && tile0 + COMPACT_THREADS >= total) *count = base + tile_total;     // the last tile knows the total
 }
 
+int make_grid_any(const char *who, int C, int X, int Y, int Z, BrickGrid *g) {
+  if (C <= 0 || X <= 0 || Y <= 0 || Z <= 0) return fgs_set_error(FGS_E_INVALID, "%s: bad grid %dx%dx%dx%d", who, X, Y, Z, C);
+  g->C = C; g->X = X; g->Y = Y; g->Z = Z; g->nbx = (X + 3) / 4; g->nby = (Y + 3) / 4; g->nbz = (Z + 3) / 4;
+  return 0;
+}
+
 int make_grid(const char *who, int C, int X, int Y, int Z, BrickGrid *g) {
   if (C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || (X & 3) || (Y & 3) || (Z & 3))
     return fgs_set_error(FGS_E_INVALID, "%s: grid %dx%dx%dx%d must have sides that are multiples of 4", who, X, Y, Z, C);
@@ -166,8 +173,8 @@ FGS_API int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int
 // (caller zeroes it once per step); xyz_min/max on the host, grid [X,Y,Z] as for the trilinear kernels.
 FGS_API int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X,
                                 int Y, int Z, int *flags, fgs_stream_t stream) {
-  BrickGrid g;
-  if (int e = make_grid("fgs_brick_flags_pts", 1, X, Y, Z, &g)) return e;
+  BrickGrid g;      // sides that are not multiples of 4 are fine here: the last brick of an axis is then partial
+  if (int e = make_grid_any("fgs_brick_flags_pts", 1, X, Y, Z, &g)) return e;
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_brick_flags_pts: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(pts && xyz_min_host && xyz_max_host && flags && X > 1 && Y > 1 && Z > 1, FGS_E_INVALID,
@@ -175,7 +182,8 @@ FGS_API int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_mi
   SceneGeom sg;
   for (int c = 0; c < 3; ++c) { sg.lo[c] = xyz_min_host[c]; sg.hi[c] = xyz_max_host[c]; }
   sg.X = X; sg.Y = Y; sg.Z = Z; sg.voxel_size = 0.f;
-  hipLaunchKernelGGL(k_brick_flags_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, sg, g, flags);
+  hipLaunchKernelGGL(k_brick_flags_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, fgs_row_ptr(), sg, g,
+                     flags);
   FGS_LAUNCH_OK("fgs_brick_flags_pts");
   return 0;
 }
@@ -187,5 +195,92 @@ FGS_API int fgs_brick_compact(const int *flags, int64_t total, int64_t *idx, int
   const unsigned tiles = (unsigned)((total + COMPACT_THREADS - 1) / COMPACT_THREADS);
   hipLaunchKernelGGL(k_brick_compact, dim3(tiles ? tiles : 1), dim3(COMPACT_THREADS), 0, fgs_s(stream), flags, total, idx, count);
   FGS_LAUNCH_OK("fgs_brick_compact");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// masked_adam_upd (model/cuda/adam_upd_kernel.cu:25-40) restricted to a LIST of bricks, and self-cleaning: the update of
+// the multi-channel feature grid visits only the bricks the step's rays touched (the survivor points' trilinear corners,
+// fgs_brick_flags_pts + fgs_brick_compact: ~18 % of a 160^3 grid, less at 320^3) instead of reading all of k0.grad, and
+// zeroes every gradient element it consumed -- so the gradient buffer is all-zero again when the step ends and the next
+// backward pass needs no 197 MB (1.57 GB at 320^3) zero fill.  Arithmetic per element = gridopt.hip adam_one<1>
+// (skip where grad == 0): bit-identical to the dense masked update on the same gradient.
+namespace {
+__device__ __forceinline__ void adam_masked_one(float &p, float g, float &m, float &v, float step_size, float beta1,
+                                                float beta2, float eps) {
+  m = fmaf(beta1, m, (1.f - beta1) * g);
+  v = fmaf(beta2, v, (1.f - beta2) * g * g);
+  p -= (step_size * m) / (sqrtf(v) + eps);
+}
+
+// idx != NULL: the listed bricks (count from count_dev or n_host).  idx == NULL: every brick whose flag is set.  flags != NULL:
+// the flag of a processed brick is cleared (the occupancy buffer is self-cleaning like the gradient).  Partial bricks at the
+// upper faces of a grid whose sides are not multiples of 4: rows beyond X / Y and the float4s beyond Z are skipped (C % 4
+// == 0 keeps every run 16-byte aligned).
+__global__ __launch_bounds__(FGS_BLOCK) void k_adam_bricks(float *__restrict__ param, float *__restrict__ grad,
+                                                           float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
+                                                           BrickGrid g, const int64_t *__restrict__ idx,
+                                                           const int64_t *__restrict__ count_dev, int64_t n_host,
+                                                           int *__restrict__ flags, float step_size,
+                                                           const float *__restrict__ ss_dev, float beta1, float beta2,
+                                                           float eps, const int *__restrict__ skip) {
+  const int64_t total = (int64_t)g.nbx * g.nby * g.nbz;
+  const int64_t n = idx ? (count_dev ? min(*count_dev, total) : n_host) : total;
+  const bool no_update = skip && *skip;           // an overflowed step: consume (zero) the gradient, change nothing else
+  if (ss_dev) step_size = *ss_dev;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
+  for (int64_t i = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6); i < n; i += waves) {
+    int64_t b = i;
+    if (idx) b = idx[i];
+    else if (!flags[i]) continue;                 // wave-uniform
+    const int bz = (int)(b % g.nbz), by = (int)((b / g.nbz) % g.nby), bx = (int)(b / ((int64_t)g.nbz * g.nby));
+    const int zrun4 = min(4, g.Z - bz * 4) * g.C / 4;       // float4s of one (x', y') run that lie inside the grid
+    for (int q = lane; q < 16 * g.C; q += FGS_WAVE) {
+      const int run = q / g.C, w4 = q - run * g.C;
+      if (bx * 4 + (run >> 2) >= g.X || by * 4 + (run & 3) >= g.Y || w4 >= zrun4) continue;
+      const int64_t off = brick_f4_offset(g, bx, by, bz, q);
+      const float4 gr = *reinterpret_cast<const float4 *>(grad + off);
+      if (gr.x == 0.f && gr.y == 0.f && gr.z == 0.f && gr.w == 0.f) continue;
+      if (!no_update) {
+        float4 p = *reinterpret_cast<const float4 *>(param + off), m = *reinterpret_cast<const float4 *>(exp_avg + off),
+               v = *reinterpret_cast<const float4 *>(exp_avg_sq + off);
+        if (gr.x != 0.f) adam_masked_one(p.x, gr.x, m.x, v.x, step_size, beta1, beta2, eps);
+        if (gr.y != 0.f) adam_masked_one(p.y, gr.y, m.y, v.y, step_size, beta1, beta2, eps);
+        if (gr.z != 0.f) adam_masked_one(p.z, gr.z, m.z, v.z, step_size, beta1, beta2, eps);
+        if (gr.w != 0.f) adam_masked_one(p.w, gr.w, m.w, v.w, step_size, beta1, beta2, eps);
+        *reinterpret_cast<float4 *>(param + off) = p;
+        *reinterpret_cast<float4 *>(exp_avg + off) = m;
+        *reinterpret_cast<float4 *>(exp_avg_sq + off) = v;
+      }
+      *reinterpret_cast<float4 *>(grad + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (flags && lane == 0) flags[b] = 0;
+  }
+}
+}  // namespace
+
+FGS_API float fgs_adam_step_size(int step, float beta1, float beta2, float lr);
+
+// param / grad / exp_avg / exp_avg_sq: channel-last [X][Y][Z][C] grids, C a multiple of 4.  Either idx (ascending brick
+// indices, fgs_brick_compact; count read from count_dev when non-NULL, else n_host) or, with idx == NULL, flags (one int per
+// brick, fgs_brick_flags_pts) selects the bricks; flags, when given, are cleared for the processed bricks.  step = the Adam
+// step number (host scalar form) unless step_size_dev != NULL (device float, fgs_step_scalars_tick).  skip_dev as in
+// fgs_adam_upd_dev, except that the gradient is consumed (zeroed) even then.
+FGS_API int fgs_adam_upd_bricks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int C, int X, int Y, int Z,
+                                const int64_t *idx, const int64_t *count_dev, int64_t n_host, int *flags, int step,
+                                float beta1, float beta2, float lr, float eps, const float *step_size_dev,
+                                const int *skip_dev, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid_any("fgs_adam_upd_bricks", C, X, Y, Z, &g)) return e;
+  FGS_REQUIRE(param && grad && exp_avg && exp_avg_sq && (idx || flags) && (C & 3) == 0, FGS_E_INVALID,
+              "fgs_adam_upd_bricks: null pointer, or C=%d not a multiple of 4", C);
+  FGS_REQUIRE(!idx || count_dev || (n_host >= 0 && n_host <= (int64_t)g.nbx * g.nby * g.nbz), FGS_E_RANGE,
+              "fgs_adam_upd_bricks: n=%lld", (long long)n_host);
+  if (idx && !count_dev && n_host == 0) return 0;
+  const float step_size = step_size_dev ? 0.f : fgs_adam_step_size(step, beta1, beta2, lr);     // gridopt.hip
+  hipLaunchKernelGGL(k_adam_bricks, dim3(2048), dim3(FGS_BLOCK), 0, fgs_s(stream), param, grad, exp_avg, exp_avg_sq, g, idx,
+                     count_dev, n_host, flags, step_size, step_size_dev, beta1, beta2, eps, skip_dev);
+  FGS_LAUNCH_OK("fgs_adam_upd_bricks");
   return 0;
 }

@@ -173,6 +173,7 @@ class GradAverager:
             self.last_sparse_fill = n / max(total, 1)
             if n > self.sparse_max_fill * total:
                 return False
+            self._note_union(param, g, h['idx'], n)
             if n == 0:
                 return True
             idx = h['idx'][:n]
@@ -194,6 +195,8 @@ class GradAverager:
         self.last_sparse_fill = n / max(total, 1)
         if n > self.sparse_max_fill * total:
             return False
+        if on_gpu:
+            self._note_union(param, g, idx, n)
         if n == 0:
             return True
         if on_gpu:
@@ -211,6 +214,15 @@ class GradAverager:
         buf.mul_(inv)
         bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
         return True
+
+    @staticmethod
+    def _note_union(param, g, idx, n) -> None:
+        """After a brick-sparse exchange the gradient is non-zero only inside the union's bricks: hand that list to
+        MaskedAdam's brick update (adam.MaskedAdam._bricks; the record was opened by fused._publish_touched).  A dense
+        exchange reports nothing, and the update then goes dense as well."""
+        t = getattr(param, '_fgs_touched', None) if param is not None else None
+        if t is not None and t['exchange'] and t['grad_ptr'] == g.data_ptr():
+            t['idx'], t['n'] = idx, int(n)
 
     def _disarm(self, param) -> None:
         h = self._hints.get(id(param)) if param is not None else None

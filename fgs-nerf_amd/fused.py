@@ -433,6 +433,101 @@ def _zeros_like_strided(t):
     return torch.empty_strided(t.shape, t.stride(), dtype=F32, device=t.device).zero_()
 
 
+# ---- the feature grid's gradient: one persistent, self-cleaning buffer instead of a fresh zero-filled one per step ----------
+# Rays touch a thin shell of the feature grid, yet a step used to zero-fill all of k0.grad (197 MB at 160^3, 1.57 GB at
+# 320^3) and MaskedAdam then read all of it back to find the few non-zero elements (model/adam.py:205-221 has no other way to
+# know).  Here the backward pass scatters into a buffer that is all-zero by construction, records the 4x4x4-voxel bricks the
+# survivors' trilinear corners fall into (fgs_brick_flags_pts), and MaskedAdam's update of this tensor visits those bricks
+# only and zeroes what it consumed (fgs_adam_upd_bricks).  Anything that breaks the "non-zero only inside the recorded
+# bricks" invariant (a dense TV term, an autograd accumulation into the same tensor, a dense gradient exchange) is detected
+# or declared (`_fgs_touched['valid']`, tensor version, storage use count) and falls back to dense update + zero fill.
+_BRICK_ADAM = os.environ.get("FGS_BRICK_ADAM", "1") != "0"
+
+
+def _storage_users(t) -> int:
+    try:
+        return int(torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+    except Exception:       # private API: without it the buffer is never reused while anything could still alias it
+        return 1 << 30
+
+
+def _grid_grad_state(cache, k0_grid, create: bool):
+    key = (tuple(k0_grid.shape), tuple(k0_grid.stride()), k0_grid.device)
+    gb = cache.get('k0_grad')
+    if gb is not None and gb['key'] == key:
+        return gb
+    if not create or not _BRICK_ADAM:
+        return None
+    _, C, X, Y, Z = k0_grid.shape
+    if k0_grid.stride() != (C * X * Y * Z, 1, Y * Z * C, Z * C, C) or C % 4 or k0_grid.dtype != F32 or min(X, Y, Z) < 2:
+        return None           # not channel-last / channel count not float4-able: the plain path
+    buf = _zeros_like_strided(k0_grid)
+    flags = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4), dtype=torch.int32, device=k0_grid.device)
+    gb = cache['k0_grad'] = dict(key=key, buf=buf, flags=flags, clean=True, dims=(C, X, Y, Z), base_users=None)
+    gb['base_users'] = _storage_users(buf)
+    return gb
+
+
+def _grid_grad_idle(gb) -> bool:
+    """Nobody but the cache holds the buffer (last step's p.grad has been dropped)."""
+    return gb is not None and _storage_users(gb['buf']) <= gb['base_users']
+
+
+def _take_grid_grad(cache, k0_grid):
+    """(gradient tensor to scatter into -- all zero --, state or None).  With a state, the tensor aliases the persistent
+    buffer (a detached alias: autograd's AccumulateGrad adopts it as p.grad without a copy)."""
+    gb = _grid_grad_state(cache, k0_grid, create=True)
+    if gb is None:
+        return _zeros_like_strided(k0_grid), None
+    if not _grid_grad_idle(gb):
+        # somebody still holds the old buffer (last step's p.grad before zero_grad, a gradient being accumulated): it is
+        # theirs now; a fresh zero-filled tensor becomes the persistent buffer
+        gb['buf'] = _zeros_like_strided(k0_grid)
+        gb['base_users'] = _storage_users(gb['buf'])
+        if not gb['clean']:
+            gb['flags'].zero_()
+    elif not gb['clean']:
+        gb['buf'].zero_()
+        gb['flags'].zero_()
+    gb['clean'] = False
+    return gb['buf'].detach(), gb
+
+
+def _publish_touched(gb, k0_grid, grad_k0, pts, M, g, st, exchange: bool):
+    """Record which bricks `grad_k0` can be non-zero in and attach the record to the parameter for MaskedAdam
+    (adam.MaskedAdam._bricks).  `exchange`: a gradient exchange follows (dist.GradAverager): the union over ranks then
+    replaces the local occupancy, or invalidates the record if the exchange goes dense."""
+    if gb is None:
+        k0_grid._fgs_touched = None
+        return
+    C, X, Y, Z = gb['dims']
+    call("fgs_brick_flags_pts", ptr(pts), M, g.lo_c, g.hi_c, X, Y, Z, ptr(gb['flags']), st)
+    k0_grid._fgs_touched = dict(state=gb, grad_ptr=grad_k0.data_ptr(), version=gb['buf']._version, dims=gb['dims'],
+                                flags=gb['flags'], idx=None, n=None, valid=True, exchange=exchange)
+
+
+def _prefill_grid_grad(run, k0_grid):
+    """Forward-time half of the k0.grad preparation (the slot behind the survivor-count copy, see _count_begin): a clean
+    buffer needs nothing now (the backward pass takes it, and a forward pass that is never differentiated costs nothing);
+    anything else is taken -- i.e. zero-filled -- here, where the fill is free."""
+    gb = _grid_grad_state(run.cache, k0_grid, create=True)
+    if gb is not None and gb['clean']:
+        # (not necessarily idle yet: the reference's loop drops last step's gradients -- optimizer.zero_grad(set_to_none=True),
+        # model/nerf_training.py:374 -- between this forward pass and backward)
+        return None
+    return _take_grid_grad(run.cache, k0_grid)
+
+
+def reset_grid_grad(model) -> None:
+    """Bring the persistent feature-grid gradient buffer back to all-zero (after a backward pass whose gradient no
+    optimizer step consumed, before capturing a step in a hipGraph)."""
+    gb = model.__dict__.get('_fused_cache', {}).get('k0_grad')
+    if gb is not None and not gb['clean']:
+        gb['buf'].zero_()
+        gb['flags'].zero_()
+        gb['clean'] = True
+
+
 def _head_scratch(width, dev):
     """Per-workgroup partial sums of fgs_head_bwd (4 MB at width 256); uninitialised, consumed inside the same call."""
     from ._lib import lib
@@ -477,7 +572,7 @@ class _FusedFine(torch.autograd.Function):
         token = None if sf else _count_begin(run, ws['surv_off'], N)
         W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one fill + one copy launch each
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
-        pre_k0 = _zeros_like_strided(k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
+        pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         if sf:
             # sync-free: the count stays on the device (last entry of the survivor offsets); M is the CAPACITY from here on
@@ -584,8 +679,7 @@ class _FusedFine(torch.autograd.Function):
         # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
         run.pre = None
         if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
-            run.pre = (torch.zeros_like(sdf_grid),
-                       pre_k0 if pre_k0 is not None else _zeros_like_strided(k0_grid))
+            run.pre = (torch.zeros_like(sdf_grid), pre_k0)
         WT = None
         if run.pre is not None and _LINEAR_BWD_MODE == "chain" and rw == 256 and fw == 256 and n_ref - 1 + n_rgb <= 8:
             # transposed weights in the order the backward chain walks the layers (dX = dY . W as a forward-shaped product)
@@ -746,11 +840,11 @@ class _FusedFine(torch.autograd.Function):
 
         # 5. features -> grids
         if run.pre is not None:
-            grad_sdf, grad_k0 = run.pre           # zero-filled at the end of the forward pass
+            grad_sdf, pre_k0 = run.pre            # zero-filled at the end of the forward pass
             run.pre = None
         else:
-            grad_sdf = torch.zeros_like(sdf_grid)
-            grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+            grad_sdf, pre_k0 = torch.zeros_like(sdf_grid), None
+        grad_k0, k0_state = pre_k0 if pre_k0 is not None else _take_grid_grad(run.cache, k0_grid)
         g_sdf_s = torch.empty(M, dtype=F32, device=dev)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         tot_sdf = torch.empty(M, dtype=F32, device=dev)
@@ -759,6 +853,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
              g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
              ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
+        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)       # final: its exchange runs under the sdf scatter kernels below
         elif opt_hook is not None:
@@ -853,7 +948,7 @@ class _FusedCoarse(torch.autograd.Function):
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
         fw, ldx0 = ref_w[0].shape[0], run.ldx0
         V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
-        pre_k0 = _zeros_like_strided(k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
+        pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         M = _count_end(token)                      # the one host read of the step
         run.M = M
@@ -910,8 +1005,7 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
         run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
         if any(ctx.needs_input_grad) and M > 0:
-            run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev),
-                       pre_k0 if pre_k0 is not None else _zeros_like_strided(k0_grid))
+            run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev), pre_k0)
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
                                    V0p=V0p, relu_bits=relu_bits, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
@@ -1018,16 +1112,17 @@ class _FusedCoarse(torch.autograd.Function):
         if hook is not None:
             hook('mlp', mlp, flat)
         if run.pre is not None:
-            d4, grad_k0 = run.pre
+            d4, pre_k0 = run.pre
             run.pre = None
         else:
-            d4 = torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev)
-            grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
+            d4, pre_k0 = torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev), None
+        grad_k0, k0_state = pre_k0 if pre_k0 is not None else _take_grid_grad(run.cache, k0_grid)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
         call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
              g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
              ptr(g_grad_s), st)
+        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:
             hook('k0', [k0_grid], grad_k0)
         elif opt_hook is not None:

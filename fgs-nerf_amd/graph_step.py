@@ -115,6 +115,7 @@ class CapturedFineStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.opt.zero_grad(set_to_none=True)
+            fused.reset_grid_grad(self.model)      # the warm-up's k0.grad was not consumed: the captured step starts clean
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body(update=True)

@@ -125,6 +125,10 @@ class DenseGrid(nn.Module):
         if grad.stride() != self.grid.stride():
             grad = torch.empty_strided(self.grid.shape, self.grid.stride(), dtype=grad.dtype, device=grad.device).copy_(grad)
             self.grid.grad = grad
+        if dense_mode and getattr(self.grid, '_fgs_touched', None) is not None:
+            # a dense TV term makes the gradient non-zero outside the bricks the rays touched: MaskedAdam must take the
+            # dense update for this step (the sparse mode only adds where grad != 0 and keeps the record valid)
+            self.grid._fgs_touched = None
         if mask is None:
             ops.total_variation_cuda.total_variation_add_grad(self.grid, grad, wx, wy, wz, dense_mode)
         else:

@@ -525,6 +525,19 @@ int fgs_mc_emit(const float *field, int X, int Y, int Z, float iso, const int8_t
                 uint32_t *vbase, int64_t n_vertices, int64_t n_triangles, double *vertices, int64_t *triangles,
                 fgs_stream_t stream);
 
+/* masked_adam_upd (adam_upd_kernel.cu:25-40) over a SET of 4x4x4-voxel bricks of a channel-last [X][Y][Z][C] grid (C a
+ * multiple of 4; sides need not be multiples of 4), and self-cleaning: only the selected bricks are visited, elements with
+ * grad == 0 are skipped as in the dense masked update (bit-identical results on the same gradient), and every consumed
+ * gradient element is set back to zero, so a persistent gradient buffer needs no zero fill per step.
+ * Selection: idx != NULL -> ascending brick indices (fgs_brick_compact), count from count_dev (device int64) when non-NULL,
+ * else n_host; idx == NULL -> every brick whose entry of `flags` (one int per brick, fgs_brick_flags_pts on the step's
+ * survivor points) is non-zero.  `flags`, when given, is cleared for the processed bricks.  Step size from step_size_dev
+ * (device float) when non-NULL, else from (step, lr); while *skip_dev != 0 the gradient is consumed but nothing is updated. */
+int fgs_adam_upd_bricks(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int C, int X, int Y, int Z,
+                        const int64_t *idx, const int64_t *count_dev, int64_t n_host, int *flags, int step, float beta1,
+                        float beta2, float lr, float eps, const float *step_size_dev, const int *skip_dev,
+                        fgs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Integrated directional encoding -- generate_ide_fn / integrated_dir_enc_fn (model/utils.py:515-574; built at
  * model/nerf.py:179, never evaluated by the reference's forward passes).  mat: [n_pow][n] coefficient matrix
