@@ -49,6 +49,7 @@ _SIGNATURES = {
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, F32, F32, F32, I32, P, P],
     "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, F32, F32, F32, P, P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
+    "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],

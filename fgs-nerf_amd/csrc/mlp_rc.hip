@@ -34,6 +34,19 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// The A-operand reads of the chunk loop are issued as inline asm and waited for by hand.  Left to hipcc, the two reads in
+// flight at any time (operands of the next two steps) were drained by an `s_waitcnt lgkmcnt(0)` every second step -- i.e. the
+// matrix pipe waited for a ds_read_b128 issued 128 cycles earlier, ~50 idle cycles per step, 15 % of the chunk phase --
+// where `lgkmcnt(1)` (the older of the two has landed; LDS returns in order) is all a step needs.
+__device__ __forceinline__ unsigned rc_lds_addr(const float *p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void rc_read_a(floatx4 &dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF_BYTES) : "memory");
+}
 
 constexpr int RC_MAXL = 8;            // layers per chain
 constexpr int RC_MAXCH = 80;          // chunks per pass over all layers
@@ -182,24 +195,45 @@ __device__ __forceinline__ void rc_dma(RcState &s) {     // a whole chunk at onc
 // read to its use and the pipe then waits for LDS after every step.
 template <int NTT, int PHASE, int NS, int STORE_TILE>
 __device__ __forceinline__ void rc_chunk(RcState &s, const float *__restrict__ S, const float *__restrict__ S_next,
-                                         const int (&rdoff)[4], const floatx16 &B, floatx16 (&acc)[NTT], float4 (&A)[3],
+                                         const int (&rdoff)[4], const floatx16 &B, floatx16 (&acc)[NTT], floatx4 (&A)[3],
                                          int h) {
   constexpr int STEPS = 4 * NTT;
   constexpr int HALF = STEPS / 2;
+  // LDS byte addresses of this lane's 16 bytes in row tile 0 of the chunk, per k-group q; row tile t adds 4096 (immediate)
+  unsigned ra[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ra[q] = rc_lds_addr(S + rdoff[q]);
+  const unsigned ra_next = rc_lds_addr((S_next ? S_next : S) + rdoff[0]);
 #pragma unroll
   for (int i = 0; i < STEPS; ++i) {
     const int q = i / NTT, t = i % NTT;
-    const float4 a = A[(PHASE + i) % 3];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");      // this step's operand has landed (the next step's may be in flight)
+    const floatx4 a = A[(PHASE + i) % 3];
     __builtin_amdgcn_sched_barrier(0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * q + 0], acc[t], 0, 0, 0);
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * q + 1], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (i + 2 < STEPS) {
-      const int q2 = (i + 2) / NTT, t2 = (i + 2) % NTT;
-      A[(PHASE + i + 2) % 3] = *reinterpret_cast<const float4 *>(S + t2 * 1024 + rdoff[q2]);
+      constexpr int dummy = 0; (void)dummy;
+      const int q2 = (i + 2) / NTT;
+      switch ((i + 2) % NTT) {        // (compile-time after unrolling: the row tile is the instruction's immediate offset)
+        case 0: rc_read_a<0 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 1: rc_read_a<1 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 2: rc_read_a<2 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 3: rc_read_a<3 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 4: rc_read_a<4 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 5: rc_read_a<5 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        case 6: rc_read_a<6 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+        default: rc_read_a<7 * 4096>(A[(PHASE + i + 2) % 3], ra[q2]); break;
+      }
     } else if (S_next) {
-      A[(PHASE + i + 2) % 3] = *reinterpret_cast<const float4 *>(S_next + (i + 2 - STEPS) * 1024 + rdoff[0]);
+      if (i + 2 - STEPS == 0) rc_read_a<0>(A[(PHASE + i + 2) % 3], ra_next);
+      else rc_read_a<4096>(A[(PHASE + i + 2) % 3], ra_next);
     }
+    // (the chunk's vector-memory instructions stay spread over its steps, one per step: in an isolated probe --
+    // scripts/diag/rc_step_probe.hip -- one burst per chunk was cheaper, 230 vs 480 idle cycles for 8 LDS-DMA pieces, but in
+    // this kernel, with the pieces' address arithmetic around them, the burst form measured 1.5 % slower)
     if (STORE_TILE >= 0 && i < 4 * 2 && (i & 1) == 1) {       // steps 1, 3, 5, 7: the four float4 of the pending tile
       const int qs = i >> 1;
       const int col = 32 * STORE_TILE + 8 * qs + 4 * h;
@@ -248,7 +282,7 @@ __device__ __forceinline__ void rc_load_ext(const RcLayer &L, int c, int64_t row
 // seven chunks (~25 us) before chunks 8 and 9 multiply by them.
 template <int NTT, bool BWD, int C>
 __device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
-                                          floatx16 (&acc)[NTT], float4 (&A)[3], int64_t rowc, int h) {
+                                          floatx16 (&acc)[NTT], floatx4 (&A)[3], int64_t rowc, int h) {
   if constexpr (C < 10) {
     if (C < L.nch) {
       const float *S = s.ring + s.slot * RC_SLOT_FLOATS;
@@ -269,7 +303,7 @@ __device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, const in
 
 template <int NTT, bool BWD>
 __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
-                                         float4 (&A)[3], int64_t row, int64_t rowc, bool row_ok, int64_t group, int h) {
+                                         floatx4 (&A)[3], int64_t row, int64_t rowc, bool row_ok, int64_t group, int h) {
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   if (s.timed) t0 = __builtin_amdgcn_s_memtime();
   floatx16 acc[NTT];
@@ -284,8 +318,9 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
   if (s.timed) t2 = __builtin_amdgcn_s_memtime();
   {   // the two operands prefetched for the next layer's first steps sit at rotation index (nch * 4 NTT) % 3: make that 0
     const int ph = (L.nch * 4 * NTT) % 3;
-    if (ph == 1) { const float4 t0 = A[1], t1 = A[2]; A[0] = t0; A[1] = t1; }
-    else if (ph == 2) { const float4 t0 = A[2], t1 = A[0]; A[0] = t0; A[1] = t1; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the hand-issued reads must have landed before they are copied)
+    if (ph == 1) { const floatx4 t0 = A[1], t1 = A[2]; A[0] = t0; A[1] = t1; }
+    else if (ph == 2) { const floatx4 t0 = A[2], t1 = A[0]; A[0] = t0; A[1] = t1; }
   }
   // ---- epilogue, one tile at a time: bias (from the LDS copy made at kernel start), activation / mask, sign bits, store;
   // the tile's 16 VGPRs then ARE the next layer's B operand
@@ -370,9 +405,10 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   // chunks 0 and 1 of the stream are in flight; the first mid-chunk barrier (inside chunk 0) covers chunk 1, this one chunk 0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  float4 A[3];
-  A[0] = *reinterpret_cast<const float4 *>(ring + rdoff[0]);
-  A[1] = *reinterpret_cast<const float4 *>(ring + 1024 + rdoff[0]);
+  floatx4 A[3];
+  rc_read_a<0>(A[0], rc_lds_addr(ring + rdoff[0]));
+  rc_read_a<4096>(A[1], rc_lds_addr(ring + rdoff[0]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   A[2] = A[0];
   floatx16 prev[8];
 #pragma unroll

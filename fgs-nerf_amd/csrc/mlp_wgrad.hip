@@ -3,23 +3,31 @@
 //
 // Shape of the problem: outputs are tiny (256 x 108..308), the reduction runs over the M ~ 50-60 K surviving samples.  So the
 // SAMPLES are split over the chip: a workgroup takes one (layer, block of <= 256 weight columns) and a contiguous range of
-// samples, keeps the whole 256 x 256 output block in its accumulators (4 waves as 2 x 2, 128 x 128 = 16 MFMA tiles = 256
-// accumulator registers per wave) and streams its sample range straight from HBM/L2 into MFMA operands:
+// samples, keeps the whole output block in its accumulators (16 MFMA tiles = 256 accumulator registers per wave) and streams
+// its sample range through LDS into MFMA operands:
 //   A operand (32x32x2: lane (j, h) holds A[i = j][k = h])  = dY[sample 2s + h][out-feature tile + j]
 //   B operand                                               = X [sample 2s + h][in-feature tile + j]
-// -- both are 128-byte row segments of the row-major activations, so no transpose is needed anywhere: panels of 16 sample
-// rows are copied by LDS-DMA exactly as they lie in memory (a contiguous byte range per panel, three slots in rotation, one
-// barrier per 16 samples, DMA issued piece by piece between the MFMAs) and the operands are conflict-free ds_read_b32.
-// (Fetching the operands straight from global memory into registers, four k-steps ahead, ran at 45 TFLOP/s: hipcc's in-order
-// vmcnt waits collapse the prefetch.)  At the end a workgroup adds its block to dW with fp32 atomics (two 128-byte
-// row segments per instruction: the full-rate shape) -- one partial per CU, 256 KB, instead of one per 128 x 128 tile and
-// K slice.  All layers share the launch, so every CU is busy from start to end and the per-layer launch gaps are gone;
-// workgroups are dealt to (layer, block) in proportion to the block's MFMA count.
-// Bias gradients ride along: the A fragments ARE dY, so a wave adds them up (4 VALU adds per 16 MFMAs) and the column-block-0
-// workgroups add the sums to db.
+// -- both are row segments of the row-major activations, so no transpose is needed anywhere.  Panels of 16 sample rows are
+// gathered by LDS-DMA (global_load_lds_dwordx4: every lane names its own 16 source bytes, the data lands lane-linear) into
+// COMPACT panels with compile-time pitch -- A [16][256], B [16][64 | 128 | 256] holding only the block's columns -- so every
+// operand read is a ds_read_b32 with an immediate offset: no address arithmetic in the loop.  Four slots in rotation, one
+// barrier per 16 samples, the DMA of a chunk issued three chunks ahead.
+// Every k-step is 16 MFMAs per wave whatever the block's width -- the wave arrangement adapts:
+//   mode A (129..256 columns): waves 2 x 2 over (rows, columns), 4 x 4 tiles each, all 8 k-steps of a chunk;
+//   mode B ( 65..128 columns): waves 2 (rows) x 2 (k-steps: even / odd), 4 x 4 tiles each;
+//   mode C (  1.. 64 columns): 4 waves on k-steps s = wave (mod 4), 8 x 2 tiles each
+// (a narrow block computed 2 x 2 like a wide one issued 4 or 8 MFMAs per k-step and was bound by the per-sample streaming
+// work: ~700 cycles per k-step instead of 256 / 512).  Everything that is not an MFMA -- the 8..10 operand reads of the next
+// k-step, the DMA pieces, the bias-sum adds -- is placed BETWEEN the MFMAs of a k-step, one item per MFMA, so it executes in
+// the 64-cycle shadow of the matrix pipe (issued in a burst between the MFMA groups it cost ~250 of 1274 cycles per k-step).
+// At the end a workgroup adds its block to dW with fp32 atomics (two 128-byte row segments per instruction: the full-rate
+// shape) -- one partial per workgroup.  All layers share the launch, so every CU is busy from start to end; workgroups are
+// dealt to (layer, block) in proportion to the block's chunk time.
+// Bias gradients ride along: the A fragments ARE dY, so a wave adds them up and adds the sums to db.
+// Rows / columns of a tile that do not exist (n_out < 256, a block's last partial tile) are NOT masked: an MFMA output
+// element depends only on its own row of A and column of B, so whatever the panel holds there only reaches accumulators that
+// the flush skips.  Sample rows beyond M (the last chunk) do reach real outputs: they are zeroed in LDS once the chunk landed.
 #include "fgs_common.h"
-
-#include <type_traits>
 
 namespace {
 
@@ -35,209 +43,241 @@ struct WgBlock {
   float *dbias;          // null unless this is column block 0 of a layer with a bias gradient
   int64_t ld_dy, ld_x, ld_dw;
   int n_out, n_in;       // valid rows / columns of dW
-  int col0, nctw;        // first column of the block; column tiles per wave (1, 2 or 4; the block spans 2 * nctw tiles)
+  int col0, mode;        // first column of the block; wave arrangement (0 = A, 1 = B, 2 = C)
   int wg0, n_wg;         // workgroups [wg0, wg0 + n_wg) split the samples of this block
 };
 
 struct WgArgs {
   int64_t M;
   const int64_t *m_dev;
+  unsigned long long *stamps;     // diagnostics (fgs_mlp_wgrad_debug_stamps): 8 words per workgroup
   int n_blocks;
   WgBlock B[WG_MAXBLK];
 };
 
-// LDS: 3 slots x {A panel, B panel}; a panel = 16 consecutive sample rows of dY / X exactly as they lie in memory (pitch =
-// the matrix's leading dimension <= 320 floats), copied by LDS-DMA as a contiguous byte range in 1 KB pieces.
 constexpr int WG_ROWS = 16;                       // samples per chunk = 8 k-steps
-constexpr int WG_PANEL = WG_ROWS * 320;           // floats per panel (20 KB)
-constexpr int WG_SLOT = 2 * WG_PANEL;
-constexpr int WG_SLOTS = 3;
+constexpr int WG_NS = 4;                          // ring slots
+constexpr int WG_PA = WG_ROWS * 256;              // floats of the A panel
+constexpr int WG_LDS_FLOATS = WG_NS * 2 * WG_PA + 4 * 256;     // mode A slots (the largest) + 1 KB dump area per wave
 
+template <int MODE> struct WgMode;
+template <> struct WgMode<0> { static constexpr int RT = 4, CT = 4, KS = 1, PWB = 256; };
+template <> struct WgMode<1> { static constexpr int RT = 4, CT = 4, KS = 2, PWB = 128; };
+template <> struct WgMode<2> { static constexpr int RT = 8, CT = 2, KS = 4, PWB = 64; };
+
+// The chunk whose panels are being fetched: uniform base pointers + per-lane byte offsets, clamped per lane to the tensor's
+// last 16 bytes (lanes of a row that straddles the end re-read the last float4 into places nobody uses or that get zeroed).
 struct WgDma {
-  const float *src_a, *src_b;     // this lane's source of piece 0 of the chunk being fetched (A panel, B panel)
-  float *dst;                     // slot base
-  int p, np_a, np_b;              // next piece of this wave; pieces per panel
-  int64_t lim_a, lim_b;           // float offset of the tensors' last float4 (keeps every lane's copy inside them)
-  int64_t off_a, off_b;           // float offset of the chunk in dY / X
+  const char *base_a, *base_b;    // dY / X at the chunk's first sample row
+  unsigned lim_a, lim_b;          // largest byte offset from base that keeps a 16-byte load inside the tensor
+  float *dst;                     // slot base, or null: no chunk left (the pieces then go to the dump area)
 };
 
-// one 1 KB piece of the chunk being fetched (branch-free; a wave without a piece left re-fetches piece 0 into the dump area)
-__device__ __forceinline__ void wg_dma_piece(WgDma &d, const float *dY, const float *X, float *dump, int lane) {
-  const int np = d.np_a + d.np_b;
-  const bool ok = d.p < np;
-  const int p = ok ? d.p : 0;
-  const bool is_b = p >= d.np_a;
-  const int q = is_b ? p - d.np_a : p;
-  // per-LANE clamp to the tensor's last 16 bytes: the lanes of a piece that straddles the end still bring the rows that
-  // exist to their places; the others re-read the last float4 into rows beyond M, which the MFMA loop zeroes
-  int64_t off = (is_b ? d.off_b : d.off_a) + (int64_t)q * 256 + lane * 4;
-  const int64_t lim = is_b ? d.lim_b : d.lim_a;
-  off = off < lim ? off : lim;
-  const float *src = (is_b ? X : dY) + off;
-  float *dst = ok ? d.dst + (is_b ? WG_PANEL : 0) + q * 256 : dump;
+template <int MODE, int I>
+__device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsigned vb0, unsigned step_a, unsigned step_b,
+                                             int wave, float *dump) {
+  using Md = WgMode<MODE>;
+  constexpr int NB = Md::PWB / 64;            // B pieces per wave (A: 4 -- one sample row of 256 floats each)
+  static_assert(I < 4 + NB, "piece index");
+  const char *src;
+  float *dst;
+  if (I < 4) {
+    unsigned off = va0 + I * step_a;
+    off = off < d.lim_a ? off : d.lim_a;
+    src = d.base_a + off;
+    dst = d.dst + (wave + 4 * I) * 256;
+  } else {
+    unsigned off = vb0 + (I - 4) * step_b;
+    off = off < d.lim_b ? off : d.lim_b;
+    src = d.base_b + off;
+    dst = d.dst + WG_PA + (wave + 4 * (I - 4)) * 256;
+  }
+  if (!d.dst) dst = dump;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-  d.p += 4;
 }
 
-template <int NCTW>
-__device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_in_block, float *lds) {
+template <int MODE, int I, int N>
+struct WgPieces {       // pieces [I, N) of the pending chunk, back to back (prologue)
+  static __device__ __forceinline__ void run(const WgDma &d, unsigned va0, unsigned vb0, unsigned sa, unsigned sb, int wave,
+                                             float *dump) {
+    wg_dma_piece<MODE, I>(d, va0, vb0, sa, sb, wave, dump);
+    WgPieces<MODE, I + 1, N>::run(d, va0, vb0, sa, sb, wave, dump);
+  }
+};
+template <int MODE, int N>
+struct WgPieces<MODE, N, N> {
+  static __device__ __forceinline__ void run(const WgDma &, unsigned, unsigned, unsigned, unsigned, int, float *) {}
+};
+
+template <int MODE>
+__device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_in_block, float *lds,
+                                            unsigned long long *stamps) {
+  using Md = WgMode<MODE>;
+  constexpr int RT = Md::RT, CT = Md::CT, KS = Md::KS, PWB = Md::PWB;
+  constexpr int KPC = 8 / KS;                       // k-steps of a chunk that this wave computes
+  constexpr int NP = 4 + PWB / 64;                  // DMA pieces per wave and chunk
+  constexpr int PPK = (NP + KPC / 2 - 1) / (KPC / 2);   // pieces per k-step of a chunk's second half
+  constexpr int SLOT = WG_PA + WG_ROWS * PWB;       // floats per slot
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
-  const int wr = wave >> 1, wc = wave & 1;
-  // chunk range of this workgroup (chunks of 16 samples: every panel starts 16-byte aligned)
+  // position of the wave: row half wr, column half wc, k-step residue kg
+  const int wr = MODE == 0 ? wave >> 1 : MODE == 1 ? (wave & 1) : 0;
+  const int wc = MODE == 0 ? (wave & 1) : 0;
+  const int kg = MODE == 0 ? 0 : MODE == 1 ? wave >> 1 : wave;
+  const int row_base = wr * RT * 32, colp_base = wc * CT * 32;     // first row of the wave / first panel column
+  // chunk range of this workgroup
   const int64_t NC = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t c0 = NC * j_in_block / b.n_wg, c1 = NC * (j_in_block + 1) / b.n_wg;
   if (c0 >= c1) return;
-  float *dump = lds + WG_SLOTS * WG_SLOT + wave * 256;
-  const int ld_a = (int)b.ld_dy, ld_b = (int)b.ld_x;
+  float *dump = lds + WG_LDS_FLOATS - 4 * 256 + wave * 256;
+  const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
-  int offA[4], offB[NCTW];          // float offset of this lane's operand inside a panel row pair (row h)
-  bool okA[4], okB[NCTW];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = 128 * wr + 32 * t + l31;
-    okA[t] = n < b.n_out;
-    offA[t] = h * ld_a + (okA[t] ? n : 0);
-  }
-#pragma unroll
-  for (int t = 0; t < NCTW; ++t) {
-    const int c = b.col0 + 32 * (NCTW * wc + t) + l31;
-    okB[t] = c < b.n_in;
-    offB[t] = WG_PANEL + h * ld_b + (okB[t] ? c : 0);
-  }
-  floatx16 acc[4][NCTW];
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int tb = 0; tb < NCTW; ++tb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
+  // ---- DMA: per-lane source offsets inside a chunk (bytes)
+  //   A piece i: sample row wave + 4 i, 256 floats from its start:                      lane * 16
+  //   B piece i: sample rows (wave + 4 i) * rpp ..+rpp, PWB floats from column col0:    rpp = 256 / PWB rows per 1 KB piece
+  constexpr int RPP = 256 / PWB, LPR = PWB / 4;      // rows per B piece, lanes per row
+  const unsigned va0 = wave * ld_a4 + lane * 16;
+  const unsigned vb0 = (wave * RPP + lane / LPR) * ld_b4 + (b.col0 + (lane % LPR) * 4) * 4;
+  const unsigned step_a = 4 * ld_a4, step_b = 4 * RPP * ld_b4;
+  const int64_t bytes_a = M * (int64_t)ld_a4, bytes_b = M * (int64_t)ld_b4;
   WgDma d;
-  d.np_a = (WG_ROWS * ld_a + 255) / 256; d.np_b = (WG_ROWS * ld_b + 255) / 256;
-  d.lim_a = M * b.ld_dy - 4; d.lim_b = M * b.ld_x - 4;
   int64_t issue_c = c0;
   int issue_slot = 0;
   auto dma_begin = [&]() __attribute__((always_inline)) {
-    d.off_a = issue_c * WG_ROWS * b.ld_dy; d.off_b = issue_c * WG_ROWS * b.ld_x;
-    d.dst = lds + issue_slot * WG_SLOT;
-    d.p = wave;
+    if (issue_c < c1) {
+      const int64_t oa = issue_c * WG_ROWS * (int64_t)ld_a4, ob = issue_c * WG_ROWS * (int64_t)ld_b4;
+      const int64_t la = bytes_a - 16 - oa, lb = bytes_b - 16 - ob;          // >= 0: the chunk's first row exists
+      d.base_a = (const char *)b.dY + oa; d.base_b = (const char *)b.X + ob;
+      d.lim_a = la < 0x7fffffff ? (unsigned)la : 0x7fffffffu; d.lim_b = lb < 0x7fffffff ? (unsigned)lb : 0x7fffffffu;
+      d.dst = lds + issue_slot * SLOT;
+    } else {
+      d.base_a = (const char *)b.dY; d.base_b = (const char *)b.X;
+      d.lim_a = (unsigned)(bytes_a - 16 < 0x7fffffff ? bytes_a - 16 : 0x7fffffff);
+      d.lim_b = (unsigned)(bytes_b - 16 < 0x7fffffff ? bytes_b - 16 : 0x7fffffff);
+      d.dst = nullptr;
+    }
     ++issue_c;
-    issue_slot = issue_slot + 1 == WG_SLOTS ? 0 : issue_slot + 1;
+    issue_slot = issue_slot + 1 == WG_NS ? 0 : issue_slot + 1;
   };
-  // prologue: chunks c0 and c0 + 1 in flight, chunk c0 complete before the first read
-  dma_begin();
-  while (d.p < d.np_a + d.np_b) wg_dma_piece(d, b.dY, b.X, dump, lane);
-  if (issue_c < c1) {
-    dma_begin();
-    while (d.p < d.np_a + d.np_b) wg_dma_piece(d, b.dY, b.X, dump, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  d.p = d.np_a + d.np_b;          // nothing pending
+  // rows of chunk c beyond M are zeroed in its slot (after it landed, before anybody reads it); uniform per workgroup
+  auto zero_tail = [&](int64_t c, int slot_of_c) __attribute__((always_inline)) {
+    const int rows_left = (int)(M - c * WG_ROWS);
+    if (rows_left >= WG_ROWS) return;
+    float *S = lds + slot_of_c * SLOT;
+    for (int i = rows_left * 256 + tid; i < WG_ROWS * 256; i += WG_THREADS) S[i] = 0.f;
+    for (int i = rows_left * PWB + tid; i < WG_ROWS * PWB; i += WG_THREADS) S[WG_PA + i] = 0.f;
+    __syncthreads();
+  };
 
+  floatx16 acc[RT][CT];
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < CT; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
+  float bsum[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) bsum[t] = 0.f;
+
+  // ---- prologue: chunks c0 .. c0 + 2 in flight, c0 complete (and its tail zeroed) before the first read
+#pragma unroll
+  for (int k = 0; k < WG_NS - 1; ++k) {
+    dma_begin();
+    WgPieces<MODE, 0, NP>::run(d, va0, vb0, step_a, step_b, wave, dump);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+  __builtin_amdgcn_s_barrier();
+  zero_tail(c0, 0);
+  if (stamps && tid == 0) { stamps[2] = __builtin_amdgcn_s_memtime(); stamps[6] = (unsigned long long)(c1 - c0); }
+
+  // this lane's operand addresses inside a slot (floats): row 2 kg + h of the chunk, first tile of the wave
+  const int offA = (2 * kg + h) * 256 + row_base + l31;
+  const int offB = WG_PA + (2 * kg + h) * PWB + colp_base + l31;
   int slot = 0;
-  float fa[2][4], fb[2][NCTW];    // operands of the current / next k-step
+  float fa[2][RT], fb[2][CT];     // operands of the current / next k-step
   {
     const float *S = lds;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) fa[0][t] = S[offA[t]];
+    for (int t = 0; t < RT; ++t) fa[0][t] = S[offA + 32 * t];
 #pragma unroll
-    for (int t = 0; t < NCTW; ++t) fb[0][t] = S[offB[t]];
+    for (int t = 0; t < CT; ++t) fb[0][t] = S[offB + 32 * t];
   }
-  // FAST form of a chunk: both leading dimensions are 256 (LDS row offsets become instruction immediates: no address
-  // arithmetic per k-step), every row and column of the block exists and the chunk lies fully inside the sample range (no
-  // zeroing selects) -- 8 ds_read_b32 and 4 adds beside the 16 MFMAs of a k-step instead of ~40 instructions.  That is the
-  // shape of five of the seven fine-stage products; everything else, and the last partial chunk, takes the general form.
-  const bool block_fast = NCTW == 4 && ld_a == 256 && ld_b == 256 && b.n_out == 256 && b.col0 + 256 <= b.n_in;
-  auto chunk = [&](int64_t c, auto fast_tag) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    const int lda = FAST ? 256 : ld_a, ldb = FAST ? 256 : ld_b;
-    const float *S = lds + slot * WG_SLOT;
-    slot = slot + 1 == WG_SLOTS ? 0 : slot + 1;
-    const float *S_next = (c + 1 < c1) ? lds + slot * WG_SLOT : nullptr;
-    const int64_t rows_left = M - c * WG_ROWS;          // sample rows of this chunk that exist (>= 1)
+  for (int64_t c = c0; c < c1; ++c) {
+    const float *S = lds + slot * SLOT;
+    const int slot_next = slot + 1 == WG_NS ? 0 : slot + 1;
+    const float *S_next = lds + slot_next * SLOT;
 #pragma unroll
-    for (int s = 0; s < WG_ROWS / 2; ++s) {
-      // order of a k-step: (1) zeroing selects on THIS k-step's operands -- hipcc waits lgkmcnt(0) for them, and the only
-      // LDS reads outstanding at that point are these, issued a whole k-step ago; (2) the reads of the NEXT k-step (of the
-      // next chunk for the last one) and this k-step's share of DMA pieces; (3) the 16 MFMAs, under which (2) completes.
-      // (With the reads in front of the selects the lgkmcnt(0) waited for the reads just issued: ~500 cycles per k-step.)
-      __builtin_amdgcn_sched_barrier(0);
-      const bool live = 2 * s + h < rows_left;           // rows beyond M hold whatever the clamped DMA brought: zero them
-      float av[4], bv[NCTW];
+    for (int sl = 0; sl < KPC; ++sl) {
+      constexpr int dummy = 0; (void)dummy;
+      const int cur = sl & 1, nxt = cur ^ 1;
+      // operands of the next k-step of this wave: same chunk, 2 KS rows further down -- or the first of the next chunk
+      const float *Sn = sl + 1 < KPC ? S + (sl + 1) * 2 * KS * 256 : S_next;
+      const float *SnB = sl + 1 < KPC ? S + (sl + 1) * 2 * KS * PWB : S_next;
 #pragma unroll
-      for (int ta = 0; ta < 4; ++ta) av[ta] = (FAST || (live && okA[ta])) ? fa[s & 1][ta] : 0.f;
+      for (int ta = 0; ta < RT; ++ta) {
 #pragma unroll
-      for (int tb = 0; tb < NCTW; ++tb) bv[tb] = (FAST || (live && okB[tb])) ? fb[s & 1][tb] : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < WG_ROWS / 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fa[(s + 1) & 1][t] = S[(2 * s + 2) * lda + offA[t]];
-#pragma unroll
-        for (int t = 0; t < NCTW; ++t) fb[(s + 1) & 1][t] = S[(2 * s + 2) * ldb + offB[t]];
-      } else if (S_next) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fa[(s + 1) & 1][t] = S_next[offA[t]];
-#pragma unroll
-        for (int t = 0; t < NCTW; ++t) fb[(s + 1) & 1][t] = S_next[offB[t]];
+        for (int tb = 0; tb < CT; ++tb) {
+          const int i = ta * CT + tb;               // MFMA i of the k-step; everything below runs in its shadow
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ta], fb[cur][tb], acc[ta][tb], 0, 0, 0);
+          if (i < RT) fa[nxt][i] = Sn[offA + 32 * i];
+          else if (i < RT + CT) fb[nxt][i - RT] = SnB[offB + 32 * (i - RT)];
+          if (tb == CT - 1) bsum[ta] += fa[cur][ta];
+          if (sl >= KPC / 2 && i >= 16 - PPK) {     // second half of the chunk: the pieces of the chunk three ahead
+            const int piece = (sl - KPC / 2) * PPK + (i - (16 - PPK));
+            switch (piece) {      // (compile-time after unrolling)
+              case 0: wg_dma_piece<MODE, 0>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 1: wg_dma_piece<MODE, 1>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 2: wg_dma_piece<MODE, 2>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 3: wg_dma_piece<MODE, 3>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 4: wg_dma_piece<MODE, 4>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 5: if (NP > 5) wg_dma_piece<MODE, (NP > 5 ? 5 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 6: if (NP > 6) wg_dma_piece<MODE, (NP > 6 ? 6 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 7: if (NP > 7) wg_dma_piece<MODE, (NP > 7 ? 7 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              default: break;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      if (s >= WG_ROWS / 4) {       // second half of the chunk: the DMA pieces of the chunk after next, a few per k-step
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wg_dma_piece(d, b.dY, b.X, dump, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta) {
-        bsum[ta] += av[ta];
-#pragma unroll
-        for (int tb = 0; tb < NCTW; ++tb)
-          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta][tb], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s == WG_ROWS / 4 - 1) {
-        // middle of the chunk: the next chunk (DMA issued a chunk ago) is complete for everybody past this barrier, and
-        // everybody has left the previous chunk, whose slot the chunk after next now overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (sl == KPC / 2 - 1) {
+        // middle of the chunk: the next chunk (its DMA was issued 1.5 chunks ago; only the newest chunk's NP pieces may still
+        // be in flight) is complete for everybody past this barrier, and everybody has left the previous chunk, whose slot
+        // the chunk three ahead now overwrites
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (issue_c < c1) dma_begin();
-        else d.p = d.np_a + d.np_b;
+        if (c + 1 < c1) zero_tail(c + 1, slot_next);
+        dma_begin();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-  };
-  {
-    int64_t c = c0;
-    if (NCTW == 4 && block_fast) {
-      const int64_t c_full = M / WG_ROWS < c1 ? M / WG_ROWS : c1;     // chunks [c0, c_full) have all 16 sample rows
-      for (; c < c_full; ++c) chunk(c, std::integral_constant<bool, NCTW == 4>{});
-    }
-    for (; c < c1; ++c) chunk(c, std::integral_constant<bool, false>{});
+    slot = slot_next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();
   // ---- flush: dW block and bias sums, fp32 atomics (two 128-byte row segments per instruction)
 #pragma unroll
-  for (int ta = 0; ta < 4; ++ta) {
+  for (int ta = 0; ta < RT; ++ta) {
 #pragma unroll
-    for (int tb = 0; tb < NCTW; ++tb) {
-      if (okB[tb]) {
-        const int col = b.col0 + 32 * (NCTW * wc + tb) + l31;
+    for (int tb = 0; tb < CT; ++tb) {
+      const int col = b.col0 + colp_base + 32 * tb + l31;
+      if (col < b.n_in) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int n = 128 * wr + 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
+          const int n = row_base + 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
           if (n < b.n_out) atomicAdd(b.dW + (int64_t)n * b.ld_dw + col, acc[ta][tb][r]);
         }
       }
     }
-    if (b.dbias && wc == 0 && okA[ta]) atomicAdd(b.dbias + 128 * wr + 32 * ta + l31, bsum[ta]);
+    const int n = row_base + 32 * ta + l31;
+    if (b.dbias && wc == 0 && n < b.n_out) atomicAdd(b.dbias + n, bsum[ta]);
   }
 }
 
 __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[WG_SLOTS * WG_SLOT + 4 * 256];    // + 1 KB dump area per wave
+  __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
   const int64_t M = fgs_rows(a.M, a.m_dev);
   if (M <= 0) return;
   int blk = 0;
@@ -245,10 +285,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
   const WgBlock &b = a.B[blk];
   const int j = (int)blockIdx.x - b.wg0;
   if (j >= b.n_wg) return;
-  switch (b.nctw) {
-    case 1: wgrad_block<1>(b, M, j, lds); break;
-    case 2: wgrad_block<2>(b, M, j, lds); break;
-    default: wgrad_block<4>(b, M, j, lds); break;
+  unsigned long long *stamps = a.stamps ? a.stamps + 8 * blockIdx.x : nullptr;
+  if (stamps && threadIdx.x == 0) {
+    stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)blk;
+  }
+  switch (b.mode) {
+    case 2: wgrad_block<2>(b, M, j, lds, stamps); break;
+    case 1: wgrad_block<1>(b, M, j, lds, stamps); break;
+    default: wgrad_block<0>(b, M, j, lds, stamps); break;
+  }
+  if (stamps && threadIdx.x == 0) {       // (the atomics of the flush have been ISSUED here, not necessarily performed)
+    stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -270,10 +317,20 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_wgrad_small(WgArgs a) {
   if (b.dbias && k == b.col0) atomicAdd(b.dbias + n, sb);
 }
 
+unsigned long long *g_wg_stamps = nullptr;
+
 bool wg_aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
 bool wg_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+// Diagnostics: while a device buffer of >= 8 * 256 uint64 is set, workgroup w records into stamps[8 w ..] the shader clock at
+// its start [0], after the prologue [2], after the sample loop [3] and after issuing the flush [4], the 100 MHz wall clock at
+// start [1] and end [5], its number of chunks [6] and its block [7].  NULL switches it off.
+FGS_API int fgs_mlp_wgrad_debug_stamps(unsigned long long *stamps) {
+  g_wg_stamps = stamps;
+  return 0;
+}
 
 FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_items >= 1 && n_items <= WG_MAXBLK, FGS_E_RANGE,
@@ -281,7 +338,7 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
   if (M == 0) return 0;
   FGS_REQUIRE(items, FGS_E_INVALID, "fgs_mlp_wgrad: null pointer");
   WgArgs a;
-  a.M = M; a.m_dev = fgs_row_ptr();
+  a.M = M; a.m_dev = fgs_row_ptr(); a.stamps = g_wg_stamps;
   int nb = 0, cost_total = 0;
   int cost[WG_MAXBLK];
   for (int i = 0; i < n_items; ++i) {
@@ -298,10 +355,9 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
       WgBlock &b = a.B[nb];
       b.dY = U.dY; b.X = U.X; b.dW = U.dW; b.dbias = col0 == 0 ? U.dbias : nullptr;
       b.ld_dy = U.ld_dy; b.ld_x = U.ld_x; b.ld_dw = U.ld_dw; b.n_out = U.n_out; b.n_in = U.n_in; b.col0 = col0;
-      b.nctw = tiles <= 2 ? 1 : tiles <= 4 ? 2 : 4;
-      // time per k-step, measured: 16 MFMAs (1024 cycles) + ~250 for a full block; a narrow block is bound by the per-sample
-      // streaming work (panel DMA, operand reads, barrier), ~700 cycles, not by its 4 or 8 MFMAs
-      cost[nb] = b.nctw == 4 ? 10 : 7;
+      b.mode = tiles <= 2 ? 2 : tiles <= 4 ? 1 : 0;
+      // time per chunk of 16 samples: 8 / 4 / 2 k-steps of 16 MFMAs per wave, plus the chunk's fixed work (barrier, DMA issue)
+      cost[nb] = b.mode == 0 ? 33 : b.mode == 1 ? 18 : 10;
       cost_total += cost[nb];
       ++nb;
     }

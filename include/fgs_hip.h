@@ -309,6 +309,10 @@ typedef struct fgs_wgrad_item {
   float *dbias;
 } fgs_wgrad_item_t;
 int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, fgs_stream_t stream);
+/* Diagnostics for fgs_mlp_wgrad: while a device buffer of >= 2048 uint64 is set, workgroup w records into stamps[8 w ..]
+ * the shader clock at its start [0], after its prologue [2], after its sample loop [3] and after issuing its flush [4], the
+ * 100 MHz wall clock at start [1] and end [5], its chunk count [6] and its block index [7].  NULL switches it off. */
+int fgs_mlp_wgrad_debug_stamps(unsigned long long *stamps);
 /* Diagnostics for the chain kernels: while a device buffer of >= 2048 uint64 is set, workgroup b records into stamps[8 b ..]
  * {shader clock, 100 MHz wall clock} at its start and end -- the clock the chip holds inside the kernel is d(shader) /
  * d(wall) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6) -- and the shader cycles its first wave spent in the
