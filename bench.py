@@ -66,7 +66,7 @@ def train_step(model, opt, averager, batch, n_rays_global):
     return loss
 
 
-def cpu_baseline(n_rays=1024, iters=3):
+def cpu_baseline(n_rays=4096, iters=10, warm=3):
     """The oracle (CPU port of the reference path: packed sampling -> F.grid_sample -> NeuS alpha -> early-stop scan ->
     nn.Linear MLPs -> index_add_ -> backward) on a bounded sample of the same workload, host cores of this box."""
     from fgs_nerf_amd import synth
@@ -86,13 +86,13 @@ def cpu_baseline(n_rays=1024, iters=3):
     ro, rd, vd = synth.random_rays(n_rays, seed=synth.SEED + 1000)
     target = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(3))
     times, n_in = [], 0
-    for it in range(iters + 1):
+    for it in range(warm + iters):       # 3 warm-up + 10 timed iterations of one full 4096-ray batch
         for t in leaves:
             t.grad = None
         t0 = time.perf_counter()
         res = O.forward_fine(P, ro, rd, vd, global_step=GLOBAL_STEP, near=2.0, stepsize=0.5, bg=1)
         render_losses(res, target, synth.FINE_LOSS).backward()
-        if it > 0:
+        if it >= warm:
             times.append(time.perf_counter() - t0)
         n_in = res['n_inbbox']
     med = sorted(times)[len(times) // 2]
@@ -104,8 +104,67 @@ def cpu_baseline(n_rays=1024, iters=3):
         pass
     return {"value": round(n_in / med / 1e6, 4), "unit": "M ray-samples/s", "cores": torch.get_num_threads(),
             "cpu_model": cpu_model,
-            "kind": "port", "sample": f"{n_rays} rays x {iters} fwd+bwd iterations of the same {GRID}^3 workload "
+            "kind": "port", "sample": f"{n_rays} rays x ({warm} warm-up + {iters} timed) fwd+bwd iterations of the same {GRID}^3 workload "
                                       f"({n_in} in-bbox samples/iter, median {med * 1e3:.0f} ms), torch CPU + C oracle"}
+
+
+# HBM traffic of the MLP matrix-core kernels, measured live: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need more TCC
+# counter slots than one pass has) over a short eager run of this same workload, started as child processes before this
+# process touches the GPU.  Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE is in KB and
+# tallies a 128-byte request at 64 bytes (x 2); WRITE_SIZE (KB) is exact for 16-byte-per-lane stores and float atomics.
+PMC_KERNELS = (("k_mlp_rc<false", "k_mlp_rc forward chain"), ("k_mlp_rc<true", "k_mlp_rc backward chain"),
+               ("k_mlp_wgrad", "k_mlp_wgrad"), ("k_mlp_fwd", "k_mlp_fwd"), ("k_linear_bwd", "k_linear_bwd"), ("k_gemm", "k_gemm"))
+
+
+def pmc_traffic_live(args, timeout_s=300):
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return {"error": "rocprofv3 not found"}
+    here = os.path.abspath(__file__)
+    out = {}
+    root = tempfile.mkdtemp(prefix="fgs_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(root, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, here,
+                   "--pmc-child", "--no-cpu-baseline", "--mode", "eager", "--steps", "4", "--warmup", "2",
+                   "--stage", args.stage, "--grid", str(args.grid)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {"error": f"rocprofv3 --pmc {counter} pass timed out"}
+            files = sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True))
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter} pass failed (exit {r.returncode})"}
+            acc = {}
+            with open(files[-1]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    name = row["Kernel_Name"].replace("(anonymous namespace)::", "")
+                    for key, label in PMC_KERNELS:
+                        if key in name:
+                            a = acc.setdefault(label, {})
+                            did = row.get("Dispatch_Id", len(a))
+                            a[did] = a.get(did, 0.0) + float(row["Counter_Value"])     # (one row per XCD on some versions)
+                            break
+            out[counter] = {k: (len(v), sum(v.values()) / len(v)) for k, v in acc.items()}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    kernels = {}
+    for k in sorted(set(out["FETCH_SIZE"]) & set(out["WRITE_SIZE"])):
+        rd, wr = out["FETCH_SIZE"][k][1] * 1024 * 2, out["WRITE_SIZE"][k][1] * 1024
+        kernels[k] = {"launches_sampled": out["FETCH_SIZE"][k][0], "hbm_read_bytes": round(rd), "hbm_write_bytes": round(wr),
+                      "bytes_per_launch": round(rd + wr)}
+    return {"kernels": kernels,
+            "method": "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two child passes of 6 eager steps of this "
+                      "workload); bytes = FETCH_SIZE KB x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE KB x 1024"}
 
 
 def launch_ranks(n_gpus: int, argv) -> int:
@@ -164,6 +223,8 @@ def main():
                          "the host; eager: Python enqueues every launch and reads the survivor count back once per step")
     ap.add_argument("--grid", type=int, default=GRID,
                     help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     globals()["GRID"] = args.grid
 
@@ -173,6 +234,11 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if os.environ.get("FGS_BENCH_DRY"):
         sys.exit(dry_rank(args))
+
+    pmc = None
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.pmc_child or args.no_pmc or args.composed)
+            and os.environ.get("FGS_FORCE_DIST") != "1"):
+        pmc = pmc_traffic_live(args)          # child processes; this process has not touched the GPU yet
 
     # host side of this path is one Python thread + the autograd thread; the box grants a 16-CPU quota per GPU and
     # torch would otherwise spawn one OpenMP worker per visible core (256) for the synthetic-scene setup
@@ -265,8 +331,7 @@ def main():
     # HIP events around every launch of the dominant kernel (the MLP GEMM template) inside the timed region, recorded
     # on the stream the kernels are launched on (PyTorch-ROCm's current stream) -> the "roofline" object below
     from fgs_nerf_amd import fused
-    fused.PROFILE["gemm_events"].clear()
-    fused.PROFILE["enabled"] = (rank == 0) and not args.composed and captured is None
+    fused.set_profiling((rank == 0) and not args.composed and captured is None, clear=True)
     STEP_STATS["survivors"] = 0
     # the cyclic collector stays out of the timed region: a generation-2 pass over torch's object graph takes milliseconds,
     # several steps' worth, and lands in some 30-step runs and not in others (2.29 vs 2.63 ms/step on the same box)
@@ -290,8 +355,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if gc_was_enabled:
         gc.enable()
-    fused.PROFILE["enabled"] = False
-    roofline_note = "HIP events on the launch stream around each uninterrupted MLP chain in the timed region"
+    fused.set_profiling(False)
+    roofline_note = "HIP events on the launch stream immediately around every MLP matrix-core launch in the timed region"
     if captured is not None:
         overflow, total = captured.check()
         if overflow:
@@ -300,14 +365,13 @@ def main():
         # A graph replay cannot carry timing events around individual kernels: the MLP kernels are timed right behind the
         # timed region, in the same process on the same model and batches, by PROFILE_STEPS eager steps of the same loop
         PROFILE_STEPS = 10
-        fused.PROFILE["gemm_events"].clear()
-        fused.PROFILE["enabled"] = rank == 0
+        fused.set_profiling(rank == 0, clear=True)
         for i in range(PROFILE_STEPS):
             train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
         torch.cuda.synchronize()
-        fused.PROFILE["enabled"] = False
+        fused.set_profiling(False)
         STEP_STATS["survivors"] = survivors_timed        # (the profiling steps above counted theirs)
-        roofline_note = (f"HIP events on the launch stream around each uninterrupted MLP chain, in {PROFILE_STEPS} eager steps "
+        roofline_note = (f"HIP events on the launch stream immediately around every MLP matrix-core launch, in {PROFILE_STEPS} eager steps "
                          "of the same loop run right behind the timed region (graph replays cannot carry timing events)")
 
     stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
@@ -336,7 +400,7 @@ def main():
         }
         line["config"]["step_mode"] = ("one hipGraph replay per step, no device->host read" if captured is not None
                                        else "eager launches, one survivor-count read per step")
-        line["roofline"] = fused.roofline_report()
+        line["roofline"] = fused.roofline_report(pmc)
         if line["roofline"] is not None:
             line["roofline"]["timing"] = roofline_note
         if line["roofline"] is not None and args.stage == "fine":

@@ -33,7 +33,7 @@ from .ops import grid_strides
 F32, I64, I32 = torch.float32, torch.int64, torch.int32
 
 # event pairs recorded around the dominant kernel family (the MLP GEMMs) when profiling is switched on by bench.py
-PROFILE = {"enabled": False, "gemm_events": [], "open": None}
+PROFILE = {"enabled": False, "gemm_events": [], "open": None}      # see set_profiling()
 
 
 def supports(model) -> bool:
@@ -178,6 +178,16 @@ def _detached(d):
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
+def set_profiling(on: bool, clear: bool = False) -> None:
+    """bench.py's switch for the roofline timing: HIP events around the matrix-core launches (fused_ops._timed for the
+    one-launch kernels of the default path, _gemm_group for the per-product k_gemm chains of the other paths)."""
+    PROFILE["enabled"] = bool(on)
+    fo.TIMING["enabled"] = bool(on)
+    if clear:
+        PROFILE["gemm_events"].clear()
+        fo.TIMING["events"].clear()
+
+
 class _gemm_group:
     """HIP-event bracket around an uninterrupted run of k_gemm launches (the forward chain, the backward chain): two
     events per chain instead of two per launch -- 42 event records per step cost ~0.5 ms of launch latency."""
@@ -208,10 +218,13 @@ class _gemm_group:
 
 def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
     """`logical` = un-padded (M, N, K) of the product, for the algorithmic FLOP count of the roofline report."""
+    lm, ln, lk = logical or (M, N, K)
+    if _MLP_IMPL == "rc" and fo.TIMING["enabled"]:      # the rc path times every launch on its own (fused_ops._timed)
+        fo._timed("k_gemm (first-layer data gradients)", 2.0 * lm * ln * lk, lambda: fo.gemm(op, A, B, C, M, N, K, **kw))
+        return
     fo.gemm(op, A, B, C, M, N, K, **kw)
     grp = PROFILE.get("open")
     if grp is not None:
-        lm, ln, lk = logical or (M, N, K)
         grp[0] += 1
         grp[1] += 2.0 * lm * ln * lk
 
@@ -354,11 +367,7 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         out = torch.empty(M, rw, dtype=F32, device=dev)
         layers.append(dict(W=rgb_w[i], mask_bits=bits[i - 1], out=out, n_store=rw))
         dY_rgb[i - 1] = out
-    fo.rc_chain(True, M, dY, fw, layers)
-    grp = PROFILE.get("open")
-    if grp is not None:
-        grp[0] += 1
-        grp[1] += 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
+    fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1)))
     # narrow products
     z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
     _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
@@ -370,10 +379,7 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         items.append((dY_ref[i], acts_ref[i], gw_ref[i], None if i == n_ref - 2 else gb_ref[i], fw, ref_w[i].shape[1]))
     for i in range(n_rgb):
         items.append((dY_rgb[i], acts_rgb[i], gw_rgb[i], gb_rgb[i], rw, rgb_w[i].shape[1]))
-    fo.mlp_wgrad(M, items)
-    if grp is not None:
-        grp[0] += 1
-        grp[1] += 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w))
+    fo.mlp_wgrad(M, items, flop=2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w)))
     return dZ, dX0
 
 
@@ -630,10 +636,8 @@ class _FusedFine(torch.autograd.Function):
                 if i == 0:
                     L.update(ext=Z[:, rw:], ext_cols=ldz - rw)
                 layers.append(L)
-            fo.rc_chain(False, M, X0, ldx0, layers)
-            if PROFILE.get("open") is not None:
-                PROFILE["open"][0] += 1
-                PROFILE["open"][1] += 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
+            fo.rc_chain(False, M, X0, ldx0, layers,
+                        flop=2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1])))
         elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
@@ -980,11 +984,9 @@ class _FusedCoarse(torch.autograd.Function):
             relu_bits = torch.empty(n_ref - 1, fo.rc_mask_bits(M, dev).numel(), dtype=torch.int32, device=dev)
             acts += [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]
             fo.rc_chain(False, M, X0, ldx0, [dict(W=ref_w[i].detach(), bias=ref_b[i].detach(), relu=True, mask_bits=relu_bits[i],
-                                                   out=acts[i + 1], n_store=fw) for i in range(n_ref - 1)])
+                                                   out=acts[i + 1], n_store=fw) for i in range(n_ref - 1)],
+                        flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]))
             a = acts[-1]
-            if PROFILE.get("open") is not None:
-                PROFILE["open"][0] += 1
-                PROFILE["open"][1] += 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1])
         else:
             for i in range(n_ref - 1):
                 out = torch.empty(M, fw, dtype=F32, device=dev)
@@ -1082,19 +1084,12 @@ class _FusedCoarse(torch.autograd.Function):
                 out = torch.empty(M, fw, dtype=F32, device=dev)
                 layers.append(dict(W=ref_w[i], mask_bits=bits[i - 1], out=out, n_store=fw))
                 dYs[i - 1] = out
-            g_ = PROFILE.get("open")
             if layers:
-                fo.rc_chain(True, M, dY, fw, layers)
-                if g_ is not None:
-                    g_[0] += 1
-                    g_[1] += 2.0 * M * fw * fw * len(layers)
+                fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers))
             dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
             _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
             fo.mlp_wgrad(M, [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
-                             for i in range(n_ref - 1)])
-            if g_ is not None:
-                g_[0] += 1
-                g_[1] += 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1])
+                             for i in range(n_ref - 1)], flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]))
         else:
             for i in range(n_ref - 2, -1, -1):
                 a_in = acts[i]
@@ -1386,11 +1381,14 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks, 'viewdirs': lambda: run.viewdirs[ray_id]})
 
 
-def roofline_report():
-    """Achieved fp32 FLOP/s of the dominant kernel (the k_gemm template: MLP forward, data- and weight-gradient products)
-    from the HIP events recorded around every k_gemm chain in bench.py's timed region, against the gfx950 fp32
-    matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32 at 64 FLOP/clk/SIMD)."""
-    ev = PROFILE["gemm_events"]
+def roofline_report(pmc=None):
+    """Achieved fp32 FLOP/s of the dominant kernels -- the MLP matrix-core kernels: k_mlp_rc (register-resident forward chain
+    and backward data-gradient chain, one launch each), k_mlp_wgrad (all weight / bias gradients, one launch), k_gemm (the two
+    first-layer data gradients) -- from the HIP events recorded around every uninterrupted run of them, against the gfx950
+    fp32 matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32 at 256 FLOP/clk/CU, 2.4 GHz).
+    `pmc`: bench.pmc_traffic_live()'s per-kernel HBM bytes (or None / {'error': ...}): `traffic` is then the mean over the
+    launches of one step, measured in this run; without it `traffic` is null (never a number from another run)."""
+    ev = PROFILE["gemm_events"] + fo.TIMING["events"]
     if not ev:
         return None
     per = {}
@@ -1408,43 +1406,30 @@ def roofline_report():
         tot_n += n
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = 157.3
-    traffic = _pmc_traffic(per)
-    return _roofline_dict(achieved, peak, traffic, tot_n, tot_ms, tot_fl, per)
-
-
-def _pmc_traffic(per=None):
-    """HBM bytes per launch of the MLP matrix-core kernels from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
-    collected separately and corrected as MI355X_MICROARCH.md prescribes: profiles/r01_pmc_mlp.json for the default launch
-    forms k_mlp_fwd / k_linear_bwd, profiles/r01_pmc_gemm.json for the per-product k_gemm launches), weighted by how often
-    each kernel was launched in this run.  PMC collection needs the profiler, so bench.py reports the committed measurement."""
-    import json
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    try:
-        mlp = json.load(open(os.path.join(root, "r01_pmc_mlp.json")))["kernels"]
-        gem = json.load(open(os.path.join(root, "r01_pmc_gemm.json")))["kernels"]
-    except (OSError, KeyError, ValueError):
-        return None
-    g_avg = sum(k["traffic_bytes_per_launch"] for k in gem.values()) / max(len(gem), 1)
-    tot, n = 0.0, 0
-    for label, (launches, _ms, _fl) in (per or {}).items():
-        if "k_mlp_fwd" in label and "k_mlp_fwd" in mlp:
-            t = mlp["k_mlp_fwd"]["traffic_bytes_per_launch"]
-        elif "(one)" in label and "k_linear_bwd" in mlp:
-            t = mlp["k_linear_bwd"]["traffic_bytes_per_launch"]
-        else:
-            t = g_avg
-        tot += t * launches
-        n += launches
-    return round(tot / n) if n else None
-
-
-def _roofline_dict(achieved, peak, traffic, n_launches, tot_ms, tot_fl, per):
-    return {"bound": "mfma", "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_fwd (rgbnet + refnet forward, "
-                                       "one launch), k_linear_bwd (data + weight gradient of a layer, one launch) / k_gemm",
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_mlp.json / r01_pmc_gemm.json)",
-            "launches": n_launches, "avg_launch_us": round(tot_ms * 1e3 / n_launches, 2),
-            "algorithmic_gflop_per_launch": round(tot_fl / n_launches / 1e9, 3),
-            "timing": "HIP events on the launch stream around each uninterrupted k_gemm chain in the timed region",
-            "chains": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
-                             "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()}}
+    traffic, detail = None, None
+    if pmc and pmc.get("kernels"):
+        K = pmc["kernels"]
+        # launches of one step, from what this run timed: label prefix -> launches
+        per_step = {}
+        for label, (n, _ms, _fl) in per.items():
+            key = next((k for k in K if label.startswith(k) or k in label), None)
+            if key is not None:
+                per_step[key] = per_step.get(key, 0) + n
+        if per_step:
+            traffic = round(sum(K[k]["bytes_per_launch"] * n for k, n in per_step.items()) / sum(per_step.values()))
+        detail = {"by_kernel": K, "method": pmc.get("method")}
+    elif pmc and pmc.get("error"):
+        detail = {"error": pmc["error"]}
+    out = {"bound": "mfma",
+           "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_rc (forward chain / backward data-gradient "
+                     "chain, activations resident in registers, one launch each), k_mlp_wgrad (all weight and bias gradients, "
+                     "one launch), k_gemm (the two first-layer data gradients)",
+           "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+           "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the MLP launches of a step",
+           "traffic_detail": detail,
+           "launches": tot_n, "avg_launch_us": round(tot_ms * 1e3 / tot_n, 2),
+           "algorithmic_gflop_per_launch": round(tot_fl / tot_n / 1e9, 3),
+           "timing": "HIP events on the launch stream around each uninterrupted MLP chain in the timed region",
+           "chains": {k: {"launches": v[0], "avg_us": round(v[1] * 1e3 / v[0], 2),
+                            "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()}}
+    return out

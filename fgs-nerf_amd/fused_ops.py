@@ -100,13 +100,28 @@ def transpose_multi(mats) -> list:
 
 _RC_IMAGES = {}   # (device index, stream handle, backward) -> packed-weight scratch of the register-resident chains
 
+# bench.py's roofline timing: while enabled, HIP events are recorded on the launch stream IMMEDIATELY around the C call that
+# launches a matrix-core kernel (no Python between the events and the launch), with the launch's algorithmic FLOP count.
+TIMING = {"enabled": False, "events": []}
+
+
+def _timed(label: str, flop: float, launch) -> None:
+    if not TIMING["enabled"]:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TIMING["events"].append((e0, e1, None, label, 1, float(flop)))
+
 
 def rc_mask_bits(M: int, device) -> torch.Tensor:
     """Buffer for the ReLU sign bits of one layer of `rc_chain` (16 bytes per lane of every 32-sample group)."""
     return torch.empty(((M + 31) // 32 + 4) * 64 * 4, dtype=torch.int32, device=device)
 
 
-def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers) -> None:
+def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0) -> None:
     """Register-resident MLP chain (include/fgs_hip.h fgs_mlp_rc_chain).  `layers`: list of dicts with W (the nn.Linear
     weight [n_out, >= n_in], any leading dimension) and optional n_in (default W.shape[1]), bias, relu, mask_bits (int32
     buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext ([M, >= ext_cols] view) / ext_cols."""
@@ -133,11 +148,12 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers) -
     ws = _RC_IMAGES.get(key)
     if ws is None or ws.numel() < need:
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
-    call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0), in0_cols,
-         ptr(ws), ws.numel(), stream())
+    _timed("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)", flop,
+           lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),
+                        in0_cols, ptr(ws), ws.numel(), stream()))
 
 
-def mlp_wgrad(M: int, items) -> None:
+def mlp_wgrad(M: int, items, flop: float = 0.0) -> None:
     """All weight / bias gradients of the MLPs in one launch (include/fgs_hip.h fgs_mlp_wgrad).  `items`: list of
     (dY [M, >= n_out], X [M, >= n_in], dW [n_out, >= n_in] zero-initialised, dbias [n_out] or None, n_out, n_in)."""
     import ctypes
@@ -148,4 +164,4 @@ def mlp_wgrad(M: int, items) -> None:
         arr[i].dY, arr[i].ld_dy, arr[i].n_out = ptr(dY), dY.stride(0), int(n_out)
         arr[i].X, arr[i].ld_x, arr[i].n_in = ptr(X), X.stride(0), int(n_in)
         arr[i].dW, arr[i].ld_dw, arr[i].dbias = ptr(dW), dW.stride(0), ptr(db)
-    call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), stream())
+    _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), stream()))
