@@ -4,7 +4,7 @@
         SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/pmc_sq -- \\
         python3 bench.py --no-cpu-baseline --no-pmc --mode eager --steps 6 --warmup 2
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pmc_sq_trace -- python3 bench.py (same arguments)
-    python scripts/pmc_sq_summary.py gpurun_out/pmc_sq gpurun_out/pmc_sq_trace profiles/r02_pmc_sq.json
+    python scripts/pmc_sq_summary.py gpurun_out/pmc_sq gpurun_out/r_fine profiles/r02_pmc_sq.json   (durations: the default run)
 
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles (summed over SIMDs) in which the matrix pipe is busy; its share of the kernel's time is
 busy / (4 SIMDs x CUs in use x kernel cycles).  Kernel cycles come from the UN-profiled kernel trace of the same command
@@ -25,14 +25,14 @@ def label_of(name):
     return None
 
 
-f = sorted(glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True))[-1]
+f = max(glob.glob(sys.argv[1] + "/**/*_counter_collection.csv", recursive=True), key=__import__("os").path.getmtime)
 acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))      # label -> counter -> dispatch -> value
 for r in csv.DictReader(open(f)):
     lab = label_of(r["Kernel_Name"])
     if lab:
         acc[lab][r["Counter_Name"]][r.get("Dispatch_Id", "0")] += float(r["Counter_Value"])
 dur = defaultdict(list)
-t = sorted(glob.glob(sys.argv[2] + "/**/*_kernel_trace.csv", recursive=True))[-1]
+t = max(glob.glob(sys.argv[2] + "/**/*_kernel_trace.csv", recursive=True), key=__import__("os").path.getmtime)
 for r in csv.DictReader(open(t)):
     lab = label_of(r["Kernel_Name"])
     if lab:

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def per_kernel(d, counter):
-    f = sorted(glob.glob(d + "/*/*_counter_collection.csv"))[-1]
+    f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=__import__("os").path.getmtime)
     acc = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:

@@ -9,7 +9,7 @@ import sys
 d = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 22
-f = sorted(glob.glob(d + "/*/*_kernel_stats.csv"))[-1]
+f = max(glob.glob(d + "/*/*_kernel_stats.csv"), key=__import__("os").path.getmtime)
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time per step: {tot / steps / 1e6:.3f} ms   ({f})")

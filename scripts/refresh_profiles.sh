@@ -28,4 +28,4 @@ SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $ROOT/gpurun_out/pmc_sq -- python3 $ROOT/bench.py --no-cpu-baseline --no-pmc --mode eager --steps 6 --warmup 2 > $ROOT/gpurun_out/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/pmc_sq_trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-pmc --mode eager --steps 6 --warmup 2 > $ROOT/gpurun_out/pmc_sq_trace.log 2>&1
 cd $ROOT
-python3 scripts/pmc_sq_summary.py gpurun_out/pmc_sq gpurun_out/pmc_sq_trace gpurun_out/r_pmc_sq.json > gpurun_out/r_pmc_sq.txt 2>&1 || true
+python3 scripts/pmc_sq_summary.py gpurun_out/pmc_sq gpurun_out/r_fine gpurun_out/r_pmc_sq.json > gpurun_out/r_pmc_sq.txt 2>&1 || true

@@ -3,7 +3,7 @@
     python scripts/trace_step.py gpurun_out/prof_x [step_index]
 """
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"))[-1]
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

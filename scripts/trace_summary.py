@@ -16,7 +16,7 @@ from collections import defaultdict
 d, steps = sys.argv[1], int(sys.argv[2])
 mode = sys.argv[3] if len(sys.argv) > 3 else "graph"
 top = int(sys.argv[4]) if len(sys.argv) > 4 else 40
-f = sorted(glob.glob(d + "/*/*_kernel_trace.csv"))[-1]
+f = max(glob.glob(d + "/*/*_kernel_trace.csv"), key=__import__("os").path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 if mode == "graph":
