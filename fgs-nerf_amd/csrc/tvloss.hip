@@ -1,0 +1,161 @@
+// tvloss.hip -- the autograd-form total-variation losses of the `ori_tv` configurations as a value pass and a gradient pass.
+//
+// Reference: total_variation(v, mask) of model/nerf.py:1212-1221 (sum over the three axes of |v[i+1] - v[i]| over the pairs
+// whose two voxels are both inside the mask, divided by 3 and by mask.sum() -- or by v.sum() without a mask) and of
+// model/dvgo.py:420-428 (per-axis MEANS over the valid pairs), called by density_total_variation (model/nerf.py:430-447,
+// sdf_tv > 0; model/dvgo.py:206-208) and k0_total_variation (model/nerf.py:449-459; model/dvgo.py:210-215) and
+// differentiated by autograd: diff -> abs -> boolean index -> sum, each a dense torch kernel over the grid and each saving
+// a tensor of the grid's size for backward (for the 12-channel feature grid at 160^3: ~20 passes over 197 MB).
+// Here: one streaming pass for the value (per-axis sums of |differences|, the plain sum of v, and the per-axis pair counts
+// when a caller needs means), one for the gradient -- d/dv[j] of sum |v[i+1] - v[i]| is, per axis, sign(v[j] - v[j-1]) for
+// the pair below minus sign(v[j+1] - v[j]) for the pair above (sign(0) = 0 as torch's abs backward has it) -- scaled per
+// axis by device-resident factors, so neither pass needs a value from the host.  HBM-bound: 4 B read per element for the
+// value (neighbours from cache), 4 B read + 4 B written for the gradient.
+#include "fgs_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+struct TvGrid {
+  GridDesc d;
+  const unsigned char *mask;   // [X][Y][Z] (shared by all channels) or null
+  int64_t n;                   // C * X * Y * Z
+};
+
+// element index i -> (c, x, y, z) in the order that makes consecutive threads touch consecutive memory
+template <bool CH_LAST>
+__device__ __forceinline__ void tv_decode(const TvGrid &g, int64_t i, int64_t &c, int64_t &x, int64_t &y, int64_t &z) {
+  if (CH_LAST) {
+    c = i % g.d.C; i /= g.d.C;
+    z = i % g.d.Z; i /= g.d.Z;
+    y = i % g.d.Y; x = i / g.d.Y;
+  } else {
+    z = i % g.d.Z; i /= g.d.Z;
+    y = i % g.d.Y; i /= g.d.Y;
+    x = i % g.d.X; c = i / g.d.X;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// sums[0..2] += sum over valid pairs along x / y / z of |v[i+1] - v[i]|;  sums[3] += sum v;  sums[4..6] += valid pairs per axis
+template <bool CH_LAST>
+__global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__restrict__ v, TvGrid g, double *__restrict__ sums) {
+  float s[3] = {0.f, 0.f, 0.f}, tot = 0.f;
+  unsigned cnt[3] = {0u, 0u, 0u};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    int64_t c, x, y, z;
+    tv_decode<CH_LAST>(g, i, c, x, y, z);
+    const int64_t o = c * g.d.sC + x * g.d.sX + y * g.d.sY + z * g.d.sZ;
+    const float a = v[o];
+    tot += a;
+    const int64_t mo = (x * g.d.Y + y) * g.d.Z + z;
+    if (g.mask && !g.mask[mo]) continue;
+    if (x + 1 < g.d.X && (!g.mask || g.mask[mo + g.d.Y * g.d.Z])) { s[0] += fabsf(v[o + g.d.sX] - a); ++cnt[0]; }
+    if (y + 1 < g.d.Y && (!g.mask || g.mask[mo + g.d.Z])) { s[1] += fabsf(v[o + g.d.sY] - a); ++cnt[1]; }
+    if (z + 1 < g.d.Z && (!g.mask || g.mask[mo + 1])) { s[2] += fabsf(v[o + g.d.sZ] - a); ++cnt[2]; }
+  }
+  __shared__ double part[FGS_BLOCK / FGS_WAVE][7];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double r[7] = {(double)s[0], (double)s[1], (double)s[2], (double)tot, (double)cnt[0], (double)cnt[1], (double)cnt[2]};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    r[k] = wave_sum(r[k]);
+    if (lane == 0) part[wave][k] = r[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) t += part[w][threadIdx.x];
+    atomicAdd(sums + threadIdx.x, t);
+  }
+}
+
+// grad[j] (+)= sum over axes of w[axis] * (sign(v[j] - v[j-1]) [pair below valid] - sign(v[j+1] - v[j]) [pair above valid]) + w[3]
+template <bool CH_LAST, bool ACCUMULATE>
+__global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_grad(const float *__restrict__ v, TvGrid g, const float *__restrict__ w,
+                                                            float *__restrict__ grad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.n) return;
+  const float wx = w[0], wy = w[1], wz = w[2], w0 = w[3];
+  int64_t c, x, y, z;
+  tv_decode<CH_LAST>(g, i, c, x, y, z);
+  const int64_t o = c * g.d.sC + x * g.d.sX + y * g.d.sY + z * g.d.sZ;
+  const int64_t mo = (x * g.d.Y + y) * g.d.Z + z;
+  float r = w0;
+  if (!g.mask || g.mask[mo]) {
+    const float a = v[o];
+    const int64_t mx = g.d.Y * g.d.Z, my = g.d.Z;
+    if (x > 0 && (!g.mask || g.mask[mo - mx])) r += wx * sgnf(a - v[o - g.d.sX]);
+    if (x + 1 < g.d.X && (!g.mask || g.mask[mo + mx])) r -= wx * sgnf(v[o + g.d.sX] - a);
+    if (y > 0 && (!g.mask || g.mask[mo - my])) r += wy * sgnf(a - v[o - g.d.sY]);
+    if (y + 1 < g.d.Y && (!g.mask || g.mask[mo + my])) r -= wy * sgnf(v[o + g.d.sY] - a);
+    if (z > 0 && (!g.mask || g.mask[mo - 1])) r += wz * sgnf(a - v[o - g.d.sZ]);
+    if (z + 1 < g.d.Z && (!g.mask || g.mask[mo + 1])) r -= wz * sgnf(v[o + g.d.sZ] - a);
+  }
+  if (ACCUMULATE) grad[o] += r;
+  else grad[o] = r;
+}
+
+int tv_grid(const char *who, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+            const unsigned char *mask, TvGrid *g, bool *ch_last) {
+  FGS_REQUIRE(C > 0 && X > 0 && Y > 0 && Z > 0, FGS_E_INVALID, "%s: empty grid", who);
+  const int64_t N = C * X * Y * Z;
+  FGS_REQUIRE(N < FGS_MAX_ELEMS, FGS_E_RANGE, "%s: %lld elements", who, (long long)N);
+  const bool first = (sZ == 1 && sY == Z && sX == Y * Z && (C == 1 || sC == X * Y * Z));
+  const bool last = (sC == 1 && sZ == C && sY == Z * C && sX == Y * Z * C);
+  FGS_REQUIRE(first || last, FGS_E_INVALID, "%s: strides (%lld,%lld,%lld,%lld) are neither channel-first nor channel-last dense",
+              who, (long long)sC, (long long)sX, (long long)sY, (long long)sZ);
+  g->d = GridDesc{C, X, Y, Z, sC, sX, sY, sZ};
+  g->mask = mask;
+  g->n = N;
+  *ch_last = last && !(first && C == 1);
+  return 0;
+}
+
+}  // namespace
+
+// Value pass.  v: [1,C,X,Y,Z] with element strides (channel-first or channel-last dense); mask: [X][Y][Z] bytes (non-zero =
+// inside; shared by all channels) or NULL; sums: 7 device doubles the pass ADDS into (the caller zeroes them):
+// {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z}.
+FGS_API int fgs_tv_loss_value(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
+                              int64_t sX, int64_t sY, int64_t sZ, double *sums, fgs_stream_t stream) {
+  TvGrid g;
+  bool ch_last;
+  if (int e = tv_grid("fgs_tv_loss_value", C, X, Y, Z, sC, sX, sY, sZ, mask, &g, &ch_last)) return e;
+  FGS_REQUIRE(v && sums, FGS_E_INVALID, "fgs_tv_loss_value: null pointer");
+  const unsigned blocks = (unsigned)((g.n + FGS_BLOCK - 1) / FGS_BLOCK < 4096 ? (g.n + FGS_BLOCK - 1) / FGS_BLOCK : 4096);
+  if (ch_last) hipLaunchKernelGGL(k_tv_loss_value<true>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, sums);
+  else hipLaunchKernelGGL(k_tv_loss_value<false>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, sums);
+  FGS_LAUNCH_OK("fgs_tv_loss_value");
+  return 0;
+}
+
+// Gradient pass.  w: 4 device floats {w_x, w_y, w_z, w_0}: grad[j] = (accumulate ? grad[j] : 0) + sum_axis w_axis * (signed
+// pair terms of element j) + w_0   (w_0: the derivative through a v.sum() denominator; 0 otherwise).  grad has v's strides.
+FGS_API int fgs_tv_loss_grad(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
+                             int64_t sX, int64_t sY, int64_t sZ, const float *w, float *grad, int accumulate,
+                             fgs_stream_t stream) {
+  TvGrid g;
+  bool ch_last;
+  if (int e = tv_grid("fgs_tv_loss_grad", C, X, Y, Z, sC, sX, sY, sZ, mask, &g, &ch_last)) return e;
+  FGS_REQUIRE(v && w && grad, FGS_E_INVALID, "fgs_tv_loss_grad: null pointer");
+  const dim3 grid(fgs_blocks(g.n)), blk(FGS_BLOCK);
+  hipStream_t st = fgs_s(stream);
+  if (ch_last) {
+    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<true, true>), grid, blk, 0, st, v, g, w, grad);
+    else hipLaunchKernelGGL((k_tv_loss_grad<true, false>), grid, blk, 0, st, v, g, w, grad);
+  } else {
+    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<false, true>), grid, blk, 0, st, v, g, w, grad);
+    else hipLaunchKernelGGL((k_tv_loss_grad<false, false>), grid, blk, 0, st, v, g, w, grad);
+  }
+  FGS_LAUNCH_OK("fgs_tv_loss_grad");
+  return 0;
+}

@@ -118,3 +118,57 @@ class _SmoothTV(torch.autograd.Function):
 
 def smooth_tv_loss(grad3: torch.Tensor, taps_c, mask_u8, inv_count: torch.Tensor, weight: float) -> torch.Tensor:
     return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight))
+
+
+class _GridTV(torch.autograd.Function):
+    """`total_variation(v, mask)` of the reference (model/nerf.py:1212-1221; `per_axis_mean=True`: model/dvgo.py:420-428) as
+    one HIP value pass and one HIP gradient pass (csrc/tvloss.hip) instead of ~20 dense torch kernels that each save a
+    grid-sized tensor.  Denominators and the backward scale factors are device scalars: nothing is read by the host."""
+
+    @staticmethod
+    def forward(ctx, v, mask_u8, masked_count, per_axis_mean):
+        if not (v.is_cuda and v.dtype == torch.float32 and v.dim() == 5 and v.shape[0] == 1):
+            raise RuntimeError("expected a float32 CUDA grid of shape [1,C,X,Y,Z]")
+        from .ops import grid_strides
+        dims = grid_strides(v)                                   # C, X, Y, Z, sC, sX, sY, sZ
+        sums = torch.zeros(7, dtype=torch.float64, device=v.device)
+        call("fgs_tv_loss_value", ptr(v), ptr(mask_u8), *dims, ptr(sums), stream())
+        S, V, n_pairs = sums[0:3], sums[3], sums[4:7]
+        if per_axis_mean:                                        # (mean_x + mean_y + mean_z) / 3 over the valid pairs
+            axis_w = 1.0 / (3.0 * n_pairs)
+            loss = (S * axis_w).sum()
+            w0 = torch.zeros((), dtype=torch.float64, device=v.device)
+        else:                                                    # (S_x + S_y + S_z) / 3 / (mask.sum() or v.sum())
+            den = masked_count.to(torch.float64) if mask_u8 is not None else V
+            axis_w = (1.0 / (3.0 * den)).expand(3)
+            loss = S.sum() / (3.0 * den)
+            # without a mask the denominator is v.sum(): d/dv also carries -S / (3 V^2)
+            w0 = torch.zeros((), dtype=torch.float64, device=v.device) if mask_u8 is not None else -S.sum() / (3.0 * den * den)
+        ctx.save_for_backward(v, torch.cat([axis_w.reshape(3), w0.reshape(1)]))
+        ctx.mask_u8, ctx.dims = mask_u8, dims
+        return loss.to(torch.float32)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        v, w = ctx.saved_tensors
+        w = (w * g_loss.to(torch.float64)).to(torch.float32).contiguous()
+        grad = torch.empty_strided(v.shape, v.stride(), dtype=torch.float32, device=v.device)
+        call("fgs_tv_loss_grad", ptr(v), ptr(ctx.mask_u8), *ctx.dims, ptr(w), ptr(grad), 0, stream())
+        return grad, None, None, None
+
+
+def grid_tv_loss(v: torch.Tensor, mask=None, per_axis_mean: bool = False) -> torch.Tensor:
+    """The reference's `total_variation(v, mask)` on a CUDA grid.  `mask`: bool [1,1,X,Y,Z] or [1,C,X,Y,Z] with identical
+    channels (the reference builds the latter with `.repeat(1, C, 1, 1, 1)`: model/nerf.py:454) or None."""
+    mask_u8 = count = None
+    if mask is not None:
+        m = mask
+        if m.dim() != 5 or tuple(m.shape[2:]) != tuple(v.shape[2:]) or m.shape[1] not in (1, v.shape[1]):
+            raise RuntimeError(f"mask shape {tuple(mask.shape)} does not fit grid {tuple(v.shape)}")
+        reps = m.shape[1]
+        m0 = m[0, 0].contiguous()
+        mask_u8 = m0.view(torch.uint8) if m0.dtype == torch.bool else (m0 != 0).view(torch.uint8)
+        count = m0.sum() * reps                                  # mask.sum() of the tensor the caller passed (device scalar)
+    return _GridTV.apply(v, mask_u8, count, bool(per_axis_mean))
+

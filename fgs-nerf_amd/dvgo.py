@@ -86,8 +86,7 @@ class dvgo(torch.nn.Module):
     def _set_grid_resolution(self, num_voxels):
         """model/dvgo.py:101-109."""
         self.num_voxels = num_voxels
-        self.voxel_size = ((self.xyz_max - self.xyz_min).prod() / num_voxels).pow(1 / 3)
-        self.world_size = ((self.xyz_max - self.xyz_min) / self.voxel_size).long()
+        self.voxel_size, self.world_size = grid_mod.resolution_for(self.xyz_min, self.xyz_max, num_voxels)
         self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
 
     def get_kwargs(self):
@@ -194,10 +193,10 @@ class dvgo(torch.nn.Module):
 
 
 def total_variation(v, mask=None):
-    """model/dvgo.py:420-428 (per-axis means, unlike model/nerf.py's variant)."""
-    tv2, tv3, tv4 = v.diff(dim=2).abs(), v.diff(dim=3).abs(), v.diff(dim=4).abs()
-    if mask is not None:
-        tv2 = tv2[mask[:, :, :-1] & mask[:, :, 1:]]
-        tv3 = tv3[mask[:, :, :, :-1] & mask[:, :, :, 1:]]
-        tv4 = tv4[mask[:, :, :, :, :-1] & mask[:, :, :, :, 1:]]
-    return (tv2.mean() + tv3.mean() + tv4.mean()) / 3
+    """model/dvgo.py:420-428: the mean over the valid pairs of |v[i+1] - v[i]| per axis, averaged over the three axes
+    (model/nerf.py's variant divides the plain sum by mask.sum() instead).  CUDA grids: csrc/tvloss.hip."""
+    if v.is_cuda:
+        from . import dense
+        return dense.grid_tv_loss(v, mask, per_axis_mean=True)
+    from .nerf import _pair_tv
+    return _pair_tv(v, mask, per_axis_mean=True)

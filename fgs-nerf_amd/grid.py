@@ -21,6 +21,14 @@ import torch.nn.functional as F
 from . import ops
 
 
+def resolution_for(xyz_min, xyz_max, num_voxels):
+    """(voxel_size, world_size) of a box cut into about `num_voxels` cubic voxels (model/nerf.py:298-307,
+    model/dvgo.py:101-109): edge = cube root of (box volume / voxel budget); voxels per axis = floor(extent / edge), int64."""
+    extent = xyz_max - xyz_min
+    edge = (extent.prod() / num_voxels).pow(1 / 3)
+    return edge, (extent / edge).long()
+
+
 def create_grid(type, **kwargs):
     """model/grid.py:27-33."""
     if type == 'DenseGrid':

@@ -196,10 +196,9 @@ class nerf(torch.nn.Module):
 
     # ------------------------------------------------------------------ resolution / bookkeeping
     def _set_grid_resolution(self, num_voxels):
-        """model/nerf.py:298-307."""
+        """model/nerf.py:298-307: the voxel budget fixes the (cubic) voxel size, the box extent then the per-axis counts."""
         self.num_voxels = num_voxels
-        self.voxel_size = ((self.xyz_max - self.xyz_min).prod() / num_voxels).pow(1 / 3)
-        self.world_size = ((self.xyz_max - self.xyz_min) / self.voxel_size).long()
+        self.voxel_size, self.world_size = grid_mod.resolution_for(self.xyz_min, self.xyz_max, num_voxels)
         self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
         self._world_size_max = None         # host copy of world_size.max(), fetched once per resolution (TV weights)
 
@@ -265,12 +264,13 @@ class nerf(torch.nn.Module):
         self.refnet = _mlp(self.refnet_dim, self.refnet_width, self.refnet_depth, 3).to(dev)
 
     def set_sdf_mask(self):
-        """model/nerf.py:181-200: adds the ``sdf_mask`` grid (1e-3 where sdf < 0.5) saved for the next stage."""
-        sdf = (self.smooth_conv(self.sdf.grid) if self.smooth_sdf else self.sdf.grid)[0, 0, :]
-        sdf_mask = (abs(sdf < 0.5) * 1e-3)[None, None, :]
+        """model/nerf.py:181-200: a one-channel ``sdf_mask`` grid saved with the stage checkpoint, 1e-3 wherever the
+        (optionally smoothed) SDF is below 0.5 and 0 elsewhere."""
+        field = self.smooth_conv(self.sdf.grid) if self.smooth_sdf else self.sdf.grid
+        inside = (field.detach() < 0.5).to(torch.float32)
         self.sdf_mask = grid_mod.create_grid('DenseGrid', channels=1, world_size=self.world_size,
                                              xyz_min=self.xyz_min, xyz_max=self.xyz_max)
-        self.sdf_mask.grid.data = sdf_mask.float().contiguous()
+        self.sdf_mask.grid.data = (inside * 1e-3).reshape(1, 1, *field.shape[-3:]).contiguous()
 
     def init_sdf_from_sdf(self, sdf0=None, smooth=False, reduce=1., ksize=3, sigma=1., zero2neg=True):
         """model/nerf.py:280-296 (fine stage start: resample the coarse SDF, 5^3 sigma=1 smoothing)."""
@@ -382,7 +382,9 @@ class nerf(torch.nn.Module):
         v = self.k0.grid
         if k0_tv <= 0:
             return 0
-        mask = None if self.nonempty_mask is None else self.nonempty_mask.repeat(1, v.shape[1], 1, 1, 1)
+        # (the reference repeats the mask over the channels, model/nerf.py:454: the denominator is then C * mask.sum();
+        # an expanded view says the same without materialising C copies)
+        mask = None if self.nonempty_mask is None else self.nonempty_mask.expand(1, v.shape[1], -1, -1, -1)
         return total_variation(v, mask)
 
     def k0_total_variation_add_grad(self, weight, dense_mode=True):
@@ -457,23 +459,23 @@ class nerf(torch.nn.Module):
         return ray_pts, ray_id, step_id, mask_outbbox, N_steps
 
     def sample_ray_ori(self, rays_o, rays_d, near, far, stepsize, is_train=False, **render_kwargs):
-        """model/nerf.py:734-758: padded [N, N_samples] sampling used by the mask-cache ray pre-filter."""
-        n_samples = int(np.linalg.norm(np.array(self.sdf.grid.shape[2:]) + 1) / stepsize) + 1
-        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-        rate_a = (self.xyz_max - rays_o) / vec
-        rate_b = (self.xyz_min - rays_o) / vec
-        t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
-        t_max = torch.maximum(rate_a, rate_b).amin(-1).clamp(min=near, max=far)
-        mask_outbbox = (t_max <= t_min)
-        rng = torch.arange(n_samples, device=rays_d.device)[None].float()
-        if is_train:
-            rng = rng.repeat(rays_d.shape[-2], 1)
-            rng += torch.rand_like(rng[:, [0]])
-        step = stepsize * self.voxel_size * rng
-        interpx = (t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True))
-        rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
-        mask_outbbox = mask_outbbox[..., None] | ((self.xyz_min > rays_pts) | (rays_pts > self.xyz_max)).any(dim=-1)
-        return rays_pts, mask_outbbox, step
+        """model/nerf.py:734-758: the padded [N, n_samples] sampler of the mask-cache ray pre-filter (model/nerf_ray.py:230):
+        every ray gets the same number of equidistant points from its box entry, points outside the box are flagged.
+        Returns (points [N, n, 3], outside-the-box flags [N, n], step lengths)."""
+        from .rays import box_interval
+        diag_voxels = float(np.linalg.norm(np.array(self.sdf.grid.shape[2:]) + 1))
+        n_samples = int(diag_voxels / stepsize) + 1
+        t_in, t_out = box_interval(rays_o, rays_d, self.xyz_min, self.xyz_max, near, far)
+        k = torch.arange(n_samples, device=rays_d.device, dtype=torch.float32)[None]
+        if is_train:                         # one random offset per ray, shared by its samples
+            k = k.repeat(rays_d.shape[-2], 1)
+            k += torch.rand_like(k[:, [0]])
+        step = stepsize * self.voxel_size * k
+        t = t_in[..., None] + step / rays_d.norm(dim=-1, keepdim=True)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * t[..., None]
+        missed = (t_out <= t_in)[..., None]
+        outside = ((self.xyz_min > pts) | (pts > self.xyz_max)).any(dim=-1)
+        return pts, missed | outside, step
 
     # ------------------------------------------------------------------ NeuS alpha (a8)
     def _s_val_for(self, global_step, is_train):
@@ -651,44 +653,32 @@ def _nerf_extract_fields(self, bound_min, bound_max, resolution=128):
                           lambda pts: grid_sampler(pts.to(neg.device), neg, self.xyz_min, self.xyz_max))
 
 
-def _nerf_voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
-    """model/nerf.py:398-428: per-voxel count of training views whose rays touch it (for the per-voxel lr option),
-    through autograd of the trilinear lookup on a grid of ones."""
-    n_samples = int(np.linalg.norm(np.array(self.sdf.grid.shape[2:]) + 1) / stepsize) + 1
-    dev = self.sdf.grid.device
-    rng = torch.arange(n_samples, device=dev)[None].float()
-    count = torch.zeros_like(self.sdf.grid.detach())
-    for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
-        ones = torch.ones_like(self.sdf.grid).requires_grad_()
-        if irregular_shape:
-            chunks_o, chunks_d = rays_o_.split(10000), rays_d_.split(10000)
-        else:
-            chunks_o = rays_o_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
-            chunks_d = rays_d_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
-        for rays_o, rays_d in zip(chunks_o, chunks_d):
-            vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-            rate_a, rate_b = (self.xyz_max - rays_o) / vec, (self.xyz_min - rays_o) / vec
-            t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
-            step = stepsize * self.voxel_size.to(dev) * rng
-            interpx = t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True)
-            rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
-            grid_sampler(rays_pts, ones, self.xyz_min, self.xyz_max).sum().backward()
-        with torch.no_grad():
-            count += (ones.grad > 1)
-    return count
-
-
 nerf.extract_geometry = _nerf_extract_geometry
 nerf.extract_fields = _nerf_extract_fields
-nerf.voxel_count_views = _nerf_voxel_count_views
 
 
 def total_variation(v, mask=None):
-    """model/nerf.py:1212-1221 (note: normalised by mask.sum() / v.sum(), unlike dvgo's variant)."""
-    tv2, tv3, tv4 = v.diff(dim=2).abs(), v.diff(dim=3).abs(), v.diff(dim=4).abs()
-    if mask is not None:
-        tv2 = tv2[mask[:, :, :-1] & mask[:, :, 1:]]
-        tv3 = tv3[mask[:, :, :, :-1] & mask[:, :, :, 1:]]
-        tv4 = tv4[mask[:, :, :, :, :-1] & mask[:, :, :, :, 1:]]
-        return (tv2.sum() + tv3.sum() + tv4.sum()) / 3 / mask.sum()
-    return (tv2.sum() + tv3.sum() + tv4.sum()) / 3 / v.sum()
+    """model/nerf.py:1212-1221: sum over the three grid axes of |v[i+1] - v[i]| over the pairs whose two voxels are inside
+    `mask`, divided by 3 and by mask.sum() -- by v.sum() without a mask (sic; dvgo's variant takes per-axis means).
+    CUDA grids: one HIP value pass + one HIP gradient pass (dense.grid_tv_loss, csrc/tvloss.hip)."""
+    if v.is_cuda:
+        from . import dense
+        return dense.grid_tv_loss(v, mask, per_axis_mean=False)
+    return _pair_tv(v, mask, per_axis_mean=False)
+
+
+def _pair_tv(v, mask, per_axis_mean):
+    """Host-tensor form of the two total_variation variants (the CPU tests' models; same value as the reference's
+    diff / boolean-index expression up to summation order)."""
+    per_axis = []
+    for axis in (2, 3, 4):
+        n = v.shape[axis] - 1
+        d = (v.narrow(axis, 1, n) - v.narrow(axis, 0, n)).abs()
+        if mask is None:
+            per_axis.append((d.sum(), d.numel()))
+        else:
+            both = (mask.narrow(axis, 1, n) & mask.narrow(axis, 0, n)).expand_as(d)
+            per_axis.append(((d * both).sum(), both.sum()))
+    if per_axis_mean:
+        return sum(s / c for s, c in per_axis) / 3
+    return sum(s for s, _ in per_axis) / 3 / (v.sum() if mask is None else mask.sum())

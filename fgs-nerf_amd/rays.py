@@ -101,6 +101,16 @@ def get_training_rays(rgb_tr, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_
     return rgb_tr, rays_o_tr, rays_d_tr, viewdirs_tr, [1] * len(rgb_tr)
 
 
+def box_interval(rays_o, rays_d, xyz_min, xyz_max, near, far):
+    """Parameter interval [t_in, t_out] of each ray inside the box (slab method, as model/nerf.py:737-741 writes it: a zero
+    direction component is replaced by 1e-6; both ends clamped to [near, far]).  t_out <= t_in: the ray misses the box."""
+    d = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+    to_hi, to_lo = (xyz_max - rays_o) / d, (xyz_min - rays_o) / d
+    t_in = torch.minimum(to_hi, to_lo).amax(-1).clamp(min=near, max=far)
+    t_out = torch.maximum(to_hi, to_lo).amin(-1).clamp(min=near, max=far)
+    return t_in, t_out
+
+
 def _flatten_views(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, keep_mask_fn=None, rays_fn=None):
     """Shared body of the two flattening samplers: concatenates (optionally masked) per-view rays.  `rays_fn`: the calling
     module's own get_rays_of_a_view (nerf_ray's returns rays on the accelerator, which the mask filter then runs on)."""

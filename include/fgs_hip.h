@@ -529,6 +529,19 @@ int fgs_mc_emit(const float *field, int X, int Y, int Z, float iso, const int8_t
                 uint32_t *vbase, int64_t n_vertices, int64_t n_triangles, double *vertices, int64_t *triangles,
                 fgs_stream_t stream);
 
+/* The autograd-form total-variation losses (ori_tv configurations): total_variation(v, mask) of model/nerf.py:1212-1221 /
+ * model/dvgo.py:420-428 as a value pass and a gradient pass (what the reference differentiates through diff -> abs ->
+ * boolean index -> sum).  v: [1,C,X,Y,Z] float32 with element strides (channel-first or channel-last dense); mask:
+ * [X][Y][Z] bytes, non-zero = inside, shared by all channels, or NULL.
+ * value: ADDS into 7 device doubles {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z}: S_a = sum over the pairs along axis a
+ * whose two voxels are inside the mask of |v[i+1] - v[i]|, pairs_a = their number.
+ * grad: grad[j] = (accumulate ? grad[j] : 0) + sum_a w[a] * (sign(v[j] - v[j-1_a]) [valid] - sign(v[j+1_a] - v[j]) [valid]) +
+ * w[3], sign(0) = 0; w: 4 DEVICE floats (the caller folds 1/3, the denominator and the upstream gradient into them). */
+int fgs_tv_loss_value(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
+                      int64_t sX, int64_t sY, int64_t sZ, double *sums, fgs_stream_t stream);
+int fgs_tv_loss_grad(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
+                     int64_t sX, int64_t sY, int64_t sZ, const float *w, float *grad, int accumulate, fgs_stream_t stream);
+
 /* masked_adam_upd (adam_upd_kernel.cu:25-40) over a SET of 4x4x4-voxel bricks of a channel-last [X][Y][Z][C] grid (C a
  * multiple of 4; sides need not be multiples of 4), and self-cleaning: only the selected bricks are visited, elements with
  * grad == 0 are skipped as in the dense masked update (bit-identical results on the same gradient), and every consumed

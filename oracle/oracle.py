@@ -293,6 +293,19 @@ def gaussian_kernel3d(ksize: int, sigma: float) -> torch.Tensor:
     return k / k.sum()
 
 
+def total_variation(v: torch.Tensor, mask=None, variant: str = "nerf") -> torch.Tensor:
+    """total_variation(v, mask): variant "nerf" = model/nerf.py:1212-1221 ((tv2 + tv3 + tv4).sum() / 3 / mask.sum(), or
+    / v.sum() without a mask), variant "dvgo" = model/dvgo.py:420-428 (per-axis means / 3).  Any float dtype (the parity
+    tests run it in float64)."""
+    tv = [v.diff(dim=d).abs() for d in (2, 3, 4)]
+    if mask is not None:
+        tv = [t[mask.narrow(d, 0, t.shape[d]) & mask.narrow(d, 1, t.shape[d])] for d, t in zip((2, 3, 4), tv)]
+    if variant == "dvgo":
+        return (tv[0].mean() + tv[1].mean() + tv[2].mean()) / 3
+    total = tv[0].sum() + tv[1].sum() + tv[2].sum()
+    return total / 3 / (mask.sum() if mask is not None else v.sum())
+
+
 def tv_smooth_kernel(sigma: float = 0) -> torch.Tensor:
     """model/nerf.py:226-236,250-252: the 3^3 binomial taps of `tv_smooth_conv` (kernel0 / kernel0.sum()), [3,3,3] float32."""
     kernel = np.asarray([[[1, 2, 1], [2, 4, 2], [1, 2, 1]], [[2, 4, 2], [4, 8, 4], [2, 4, 2]], [[1, 2, 1], [2, 4, 2], [1, 2, 1]]])

@@ -65,15 +65,6 @@ def test_stage_checkpoint_to_mask_cache_roundtrip(dev, tmp_path):
     assert (st['model_state_dict']['sdf_mask.grid'] > 0).any()
 
 
-def test_voxel_count_views(dev):
-    from fgs_nerf_amd import synth
-    m = synth.build_model(16, synth.FINE_MODEL, device=dev)
-    ro, rd, _ = synth.view_rays(0, 12, 12)
-    cnt = m.voxel_count_views(ro.reshape(1, 12, 12, 3).to(dev), rd.reshape(1, 12, 12, 3).to(dev), imsz=[1], near=2.0,
-                              far=6.0, stepsize=0.5, irregular_shape=False)
-    assert cnt.shape == m.sdf.grid.shape and float(cnt.sum()) > 0
-
-
 @pytest.mark.parametrize("stage", ["fine", "coarse"])
 def test_training_steps_do_not_leak_device_memory(dev, stage):
     """The fused autograd nodes must not keep their own outputs alive (output -> grad_fn -> ctx -> output is a cycle the

@@ -267,7 +267,8 @@ def test_early_update_of_the_feature_grid_matches_a_plain_step(dev):
         outs.append((model.k0.grid.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone(), st['step'],
                      model.sdf.grid.detach().clone()))
         assert not opt._early
-    # the scatter kernels' float atomics are order dependent: compare in norm (Adam's first steps amplify tiny gradients)
+    # the scatter kernels' float atomics are order dependent: compare in norm (Adam's first steps amplify tiny gradients;
+    # exp_avg_sq carries the gradient's relative noise twice: seen up to 1.2e-3 between two identical runs)
     assert outs[0][3] == outs[1][3] == 3
     for a, b in zip(outs[0][:3] + outs[0][4:], outs[1][:3] + outs[1][4:]):
-        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-3
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 3e-3
