@@ -153,16 +153,23 @@ void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int sh
 }
 
 // g[0] = (s[x+1] - s[x-1]) / 2 / vs on 1 <= x <= X-2 (zero on the two faces), likewise g[1] along y, g[2] along z
+// vol4 (optional): the voxel-interleaved copy [X][Y][Z][4] = {pack_s[v], g_x[v], g_y[v], g_z[v]} the coarse march samples
+// with ONE 16-byte load per trilinear corner instead of four 4-byte gathers from four arrays (pack_s = the smoothed SDF).
 __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_fwd(const float *__restrict__ s, int X, int Y, int Z, float vs,
-                                                           float *__restrict__ g) {
+                                                           float *__restrict__ g, const float *__restrict__ pack_s,
+                                                           float4 *__restrict__ vol4) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t N = (int64_t)X * Y * Z;
   if (idx >= N) return;
   const int z = (int)(idx % Z), y = (int)((idx / Z) % Y), x = (int)(idx / ((int64_t)Z * Y));
   const int64_t sx = (int64_t)Y * Z, sy = Z;
-  g[idx] = (x >= 1 && x <= X - 2) ? (s[idx + sx] - s[idx - sx]) / 2.f / vs : 0.f;
-  g[N + idx] = (y >= 1 && y <= Y - 2) ? (s[idx + sy] - s[idx - sy]) / 2.f / vs : 0.f;
-  g[2 * N + idx] = (z >= 1 && z <= Z - 2) ? (s[idx + 1] - s[idx - 1]) / 2.f / vs : 0.f;
+  const float gx = (x >= 1 && x <= X - 2) ? (s[idx + sx] - s[idx - sx]) / 2.f / vs : 0.f;
+  const float gy = (y >= 1 && y <= Y - 2) ? (s[idx + sy] - s[idx - sy]) / 2.f / vs : 0.f;
+  const float gz = (z >= 1 && z <= Z - 2) ? (s[idx + 1] - s[idx - 1]) / 2.f / vs : 0.f;
+  g[idx] = gx;
+  g[N + idx] = gy;
+  g[2 * N + idx] = gz;
+  if (vol4) vol4[idx] = make_float4(pack_s[idx], gx, gy, gz);
 }
 
 // d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v-1 interior] - dg_axis[v+1] * [v+1 interior] ) / 2 / vs
@@ -227,11 +234,13 @@ FGS_API int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int 
   return 0;
 }
 
-FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, fgs_stream_t stream) {
+FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, const float *pack_sdf,
+                                float *vol4, fgs_stream_t stream) {
   FGS_REQUIRE(X > 0 && Y > 0 && Z > 0 && (int64_t)X * Y * Z < ((int64_t)1 << 38), FGS_E_RANGE, "fgs_sdf_gradvol_fwd: size");
-  FGS_REQUIRE(sdf && grad3, FGS_E_INVALID, "fgs_sdf_gradvol_fwd: null pointer");
+  FGS_REQUIRE(sdf && grad3 && (!vol4 || (pack_sdf && (reinterpret_cast<uintptr_t>(vol4) & 15) == 0)), FGS_E_INVALID,
+              "fgs_sdf_gradvol_fwd: null pointer (vol4 needs pack_sdf and 16-byte alignment)");
   hipLaunchKernelGGL(k_gradvol_fwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), sdf, X, Y, Z,
-                     voxel_size, grad3);
+                     voxel_size, grad3, pack_sdf, reinterpret_cast<float4 *>(vol4));
   FGS_LAUNCH_OK("fgs_sdf_gradvol_fwd");
   return 0;
 }

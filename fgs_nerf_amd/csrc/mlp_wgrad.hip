@@ -11,7 +11,9 @@
 // gathered by LDS-DMA (global_load_lds_dwordx4: every lane names its own 16 source bytes, the data lands lane-linear) into
 // COMPACT panels with compile-time pitch -- A [16][256], B [16][64 | 128 | 256] holding only the block's columns -- so every
 // operand read is a ds_read_b32 with an immediate offset: no address arithmetic in the loop.  Four slots in rotation, one
-// barrier per 16 samples, the DMA of a chunk issued three chunks ahead.
+// barrier per 16 samples, the DMA of a chunk issued three chunks ahead.  (Each LDS-DMA instruction blocks the wave's issue
+// for ~60 cycles -- scripts/diag/rc_step_probe.hip -- but the alternative, global_load_dwordx4 into staging registers and
+// ds_write_b128 a chunk later, measured 1.5 % SLOWER here: 9 123 vs 8 980 cycles per chunk.)
 // Every k-step is 16 MFMAs per wave whatever the block's width -- the wave arrangement adapts:
 //   mode A (129..256 columns): waves 2 x 2 over (rows, columns), 4 x 4 tiles each, all 8 k-steps of a chunk;
 //   mode B ( 65..128 columns): waves 2 (rows) x 2 (k-steps: even / odd), 4 x 4 tiles each;

@@ -67,11 +67,19 @@ def smooth3d(grid: torch.Tensor, taps: torch.Tensor, taps_c=None) -> torch.Tenso
 
 class _GradVol(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grid, voxel_size):
+    def forward(ctx, grid, voxel_size, pack):
         X, Y, Z = _check_grid(grid)
         g = grid.contiguous()
         out = torch.empty(1, 3, X, Y, Z, dtype=torch.float32, device=g.device)
-        call("fgs_sdf_gradvol_fwd", ptr(g), X, Y, Z, float(voxel_size), ptr(out), stream())
+        vol4 = None
+        if pack is not None:       # (pack_sdf [1,1,X,Y,Z], holder): also write the interleaved [X,Y,Z,4] copy
+            pack_sdf, holder = pack
+            _check_grid(pack_sdf)
+            vol4 = torch.empty(X, Y, Z, 4, dtype=torch.float32, device=g.device)
+            holder['vol4'] = vol4
+            pack_sdf = pack_sdf.detach().contiguous()
+        call("fgs_sdf_gradvol_fwd", ptr(g), X, Y, Z, float(voxel_size), ptr(out), ptr(pack_sdf) if pack is not None else None,
+             ptr(vol4), stream())
         ctx.meta = (X, Y, Z, float(voxel_size))
         return out
 
@@ -85,11 +93,15 @@ class _GradVol(torch.autograd.Function):
         sc = d_out.stride(1)
         d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
         call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, ptr(d_in), 0, stream())
-        return d_in, None
+        return d_in, None, None
 
 
-def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float) -> torch.Tensor:
-    return _GradVol.apply(grid, float(voxel_size))
+def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, holder=None) -> torch.Tensor:
+    """[1,3,X,Y,Z] central-difference gradient volume (model/nerf.py:485-494).  With `pack_sdf` (the smoothed SDF grid) and a
+    dict `holder`, the same pass also leaves the voxel-interleaved volume {pack_sdf, g_x, g_y, g_z} in holder['vol4'] for
+    the coarse march (a plain by-product: no gradient flows through it)."""
+    pack = None if pack_sdf is None else (pack_sdf, holder)
+    return _GradVol.apply(grid, float(voxel_size), pack)
 
 
 class _SmoothTV(torch.autograd.Function):

@@ -448,6 +448,7 @@ def _zeros_like_strided(t):
 # bricks" invariant (a dense TV term, an autograd accumulation into the same tensor, a dense gradient exchange) is detected
 # or declared (`_fgs_touched['valid']`, tensor version, storage use count) and falls back to dense update + zero fill.
 _BRICK_ADAM = os.environ.get("FGS_BRICK_ADAM", "1") != "0"
+_COARSE_VOL4 = os.environ.get("FGS_COARSE_VOL4", "1") != "0"
 
 
 def _storage_users(t) -> int:
@@ -939,8 +940,8 @@ class _FusedCoarse(torch.autograd.Function):
         inc = run.inc
         alphainv_last = torch.empty(N, dtype=F32, device=dev)   # an output of the march: a fresh tensor per step
         call("fgs_march_coarse_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
-             run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), run.dist, run.inv_s, run.thres,
-             ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
+             run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), ptr(getattr(run, 'vol4', None)), run.dist, run.inv_s,
+             run.thres, ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
              g.mask[3] if use_mc else 0.0, ptr(inc[0]) if inc else None, *(inc[1] if inc else (0, 0, 0)),
              inc[2] if inc else None, inc[3] if inc else None, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
@@ -1282,7 +1283,11 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
         sdf_smooth = dense.smooth3d(model.sdf.grid, model.smooth_conv.weight, taps[1])
     else:
         sdf_smooth = model.sdf.grid
-    model.gradient = dense.sdf_gradient_volume(model.sdf.grid, g.voxel_size)
+    # (the gradient-volume pass also leaves the voxel-interleaved copy {smoothed sdf, g_x, g_y, g_z} the march samples with
+    # one 16-byte load per trilinear corner: FGS_COARSE_VOL4=0 switches it off)
+    holder = {}
+    model.gradient = dense.sdf_gradient_volume(model.sdf.grid, g.voxel_size, sdf_smooth if _COARSE_VOL4 else None, holder)
+    run.vol4 = holder.get('vol4')
     mlp = []
     for layer in fl:
         mlp += [layer.weight, layer.bias]

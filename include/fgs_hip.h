@@ -456,7 +456,10 @@ int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const float *t
  *   d_grad3(c,x,y,z) = d_grad3[c * chan_stride + ((x*Y + y)*Z + z) * voxel_stride]  (dense: XYZ, 1; interleaved: 1, 4) */
 int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int Y, int Z, int k, const float *taps_host,
                      float *scratch, float *d_in, fgs_stream_t stream);
-int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, fgs_stream_t stream);
+/* vol4 (optional, with pack_sdf [X,Y,Z]): also writes the voxel-interleaved volume [X,Y,Z,4] = {pack_sdf, g_x, g_y, g_z}
+ * that fgs_march_coarse_fwd samples with one 16-byte load per trilinear corner (pack_sdf = the smoothed SDF). */
+int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, const float *pack_sdf,
+                        float *vol4, fgs_stream_t stream);
 int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
                         float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream);
 
@@ -474,11 +477,13 @@ int fgs_smooth_tv_loss(const float *g3, int X, int Y, int Z, const float *taps_h
  * the gradient volume [3,X,Y,Z], NeuS alpha, Alphas2Weights over every sample, `weights > thres` (thres > 0 required),
  * Alphas2Weights again over the kept list.  Record arrays as in fgs_march_fine_fwd, but holding the KEPT samples only
  * (n_surv[ray] of them, a_surv[rec] = its index); n_alive[ray] = how many of them the second chain reached (the rest
- * carry weight 0, T 1).  fgs_surv_compact then builds the flat result lists exactly as for the fine stage. */
+ * carry weight 0, T 1).  fgs_surv_compact then builds the flat result lists exactly as for the fine stage.
+ * vol4 (optional, fgs_sdf_gradvol_fwd): the same four channels voxel-interleaved; used for the lookups when non-NULL
+ * (bit-identical results, a quarter of the gather instructions). */
 int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const float *viewdirs, int64_t n_rays,
                          const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near, float far,
-                         float stepdist, const float *sdf_smooth, const float *gradvol, float dist, float inv_s, float thres,
-                         const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
+                         float stepdist, const float *sdf_smooth, const float *gradvol, const float *vol4, float dist,
+                         float inv_s, float thres, const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
                          int mZ, float mask_thres, const uint8_t *inc_world, int iX, int iY, int iZ,
                          const float *inc_scale_host, const float *inc_shift_host, int max_steps, int *a_step,
                          float *a_alpha, float *a_T, float *a_weight, float *a_sdf, float *a_grad, int *a_surv,

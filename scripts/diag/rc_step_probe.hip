@@ -4,6 +4,10 @@
 //   mode 1: + one ds_read_b128 per step (hand-issued, lgkmcnt(1)), operands rotate through 3 registers
 //   mode 2: + 8 LDS-DMA pieces (global_load_lds_dwordx4) per 32 steps, vmcnt(0) + s_barrier once per 32 steps
 //   mode 3: mode 2 without the barrier
+//   mode 10: mode 3 with the ds_read between MFMA 1 and 2 of a step and the piece between MFMA 2 and 3;  mode 11: mode 10
+//            without any pieces
+//   mode 12: a plain global_load_dwordx4 (to registers, never used) in place of each LDS-DMA piece of mode 3;  mode 13: a
+//            global_store_dwordx4 in their place
 //   mode 4 / 5: 4 / 16 pieces per 32 steps (no barrier);  mode 6: 8 pieces, never waited for
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -42,9 +46,23 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
       const floatx4 a = A[(MODE >= 1) ? (i + 2 * 0) % 3 : 0];
       __builtin_amdgcn_sched_barrier(0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * q + 0], acc[t], 0, 0, 0);
+      if (MODE == 10 || MODE == 11) {
+        __builtin_amdgcn_sched_barrier(0);
+        switch ((i + 2) % 8) {
+          case 0: rd<0 * 4096>(A[(i + 2) % 3], sa); break;
+          case 1: rd<1 * 4096>(A[(i + 2) % 3], sa); break;
+          case 2: rd<2 * 4096>(A[(i + 2) % 3], sa); break;
+          case 3: rd<3 * 4096>(A[(i + 2) % 3], sa); break;
+          case 4: rd<4 * 4096>(A[(i + 2) % 3], sa); break;
+          case 5: rd<5 * 4096>(A[(i + 2) % 3], sa); break;
+          case 6: rd<6 * 4096>(A[(i + 2) % 3], sa); break;
+          default: rd<7 * 4096>(A[(i + 2) % 3], sa); break;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, B[4 * q + 1], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE >= 1) {
+      if (MODE >= 1 && MODE != 10 && MODE != 11) {
         switch ((i + 2) % 8) {
           case 0: rd<0 * 4096>(A[(i + 2) % 3], sa); break;
           case 1: rd<1 * 4096>(A[(i + 2) % 3], sa); break;
@@ -60,12 +78,23 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
         // pieces issued at this step: modes 2/3/6: one at every even step of the second half; 4: every 4th; 5: every step;
         // 7: two at every 4th step; 8: eight at step 16; 9: four at steps 16 and 24
         int n_here = 0, first = 0;
-        if (MODE == 2 || MODE == 3 || MODE == 6) { n_here = (i >= 16 && (i & 1) == 0) ? 1 : 0; first = (i - 16) >> 1; }
+        if (MODE == 2 || MODE == 3 || MODE == 6 || MODE == 10) { n_here = (i >= 16 && (i & 1) == 0) ? 1 : 0; first = (i - 16) >> 1; }
         if (MODE == 4) { n_here = (i >= 16 && (i & 3) == 0) ? 1 : 0; first = (i - 16) >> 2; }
         if (MODE == 5) { n_here = i >= 16 ? 1 : 0; first = i - 16; }
         if (MODE == 7) { n_here = (i >= 16 && (i & 3) == 0) ? 2 : 0; first = ((i - 16) >> 2) * 2; }
         if (MODE == 8) { n_here = i == 16 ? 8 : 0; first = 0; }
         if (MODE == 9) { n_here = (i == 16 || i == 24) ? 4 : 0; first = i == 16 ? 0 : 4; }
+        if (MODE == 12 || MODE == 13) { n_here = 0; }
+        if ((MODE == 12 || MODE == 13) && i >= 16 && (i & 1) == 0) {
+          const int p = (wave + 4 * ((i - 16) >> 1)) & 31;
+          const float *gp = src + p * 256;
+          if (MODE == 12) {
+            floatx4 tmp;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tmp) : "v"(gp) : "memory");
+          } else {
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(gp), "v"(A[0]) : "memory");
+          }
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k < n_here) {
@@ -78,7 +107,8 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, B[4 * q + 2], acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, B[4 * q + 3], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE >= 2 && i == 15) {
+      if (MODE >= 2 && MODE != 11 && i == 15) {
+        if (MODE == 12) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE != 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (MODE == 2) __builtin_amdgcn_s_barrier();
       }
@@ -94,9 +124,10 @@ int main() {
   float *out, *img; unsigned long long *cyc;
   (void)hipMalloc(&out, 256 * 256 * 4); (void)hipMalloc(&cyc, 256 * 8); (void)hipMalloc(&img, 256 * 8192 * 4 + 65536);
   (void)hipMemset(img, 0, 256 * 8192 * 4 + 65536);
+  float *wbuf; (void)hipMalloc(&wbuf, 256 * 8192 * 4 + 65536);
   const int iters = 540;
   unsigned long long h[256];
-  for (int mode = 0; mode < 10; ++mode) {
+  for (int mode = 0; mode < 14; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
@@ -108,6 +139,10 @@ int main() {
       if (mode == 7) hipLaunchKernelGGL(probe<7>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 8) hipLaunchKernelGGL(probe<8>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 9) hipLaunchKernelGGL(probe<9>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 10) hipLaunchKernelGGL(probe<10>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 11) hipLaunchKernelGGL(probe<11>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 12) hipLaunchKernelGGL(probe<12>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 13) hipLaunchKernelGGL(probe<13>, dim3(256), dim3(256), 0, 0, out, (const float *)wbuf, cyc, iters);
       (void)hipDeviceSynchronize();
     }
     (void)hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost);

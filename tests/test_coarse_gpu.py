@@ -178,3 +178,33 @@ def test_fused_coarse_full_size_vs_oracle_forward(dev, oracle):
     w_sum = torch.zeros(4096, device=dev).index_add_(0, res["ray_id"], res["weights"])
     assert float((w_sum + res["alphainv_cum"]).max()) <= 1.0 + 1e-5
     assert bool((res["ray_id"][1:] >= res["ray_id"][:-1]).all())
+
+
+def test_interleaved_volume_lookups_are_bit_identical(dev):
+    """The coarse march samples the smoothed SDF and the gradient volume either from four arrays (32 four-byte gathers per
+    point) or from the voxel-interleaved [X,Y,Z,4] copy the gradient-volume pass leaves behind (8 sixteen-byte loads): same
+    corner order, same fmaf chain -> every output of the render must be bit-identical, forward and backward."""
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    rays = tuple(t.to(dev) for t in synth.random_rays(700, seed=21))
+    target = torch.rand(700, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = {}
+    old = fused._COARSE_VOL4
+    try:
+        for flag in (True, False):
+            fused._COARSE_VOL4 = flag
+            model = synth.build_model(40, synth.COARSE_MODEL, device=dev)
+            res = model(*rays, global_step=300, **synth.RENDER_KWARGS)
+            loss = fused_render_losses(res, target, synth.COARSE_LOSS, model)
+            loss.backward()
+            outs[flag] = ({k: res[k].detach().clone() for k in ('rgb_marched', 'weights', 'ray_id', 'step_id', 'raw_alpha',
+                                                                 'gradient', 'alphainv_cum')},
+                          model.sdf.grid.grad.clone(), float(loss))
+    finally:
+        fused._COARSE_VOL4 = old
+    for k in outs[True][0]:
+        assert torch.equal(outs[True][0][k], outs[False][0][k]), k
+    assert outs[True][2] == outs[False][2]
+    # (sdf.grad goes through float atomics in both runs: equal up to their order)
+    a, b = outs[True][1], outs[False][1]
+    assert float((a - b).norm() / b.norm()) < 1e-5

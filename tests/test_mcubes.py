@@ -115,6 +115,34 @@ def test_extract_geometry_on_the_sdf_model(dev):
 
 
 @pytest.mark.gpu
+def test_extract_geometry_at_the_mesh_resolution_of_configs2(dev):
+    """BASELINE configs[2]'s mesh size (G_mesh = 512; validate_mesh(cfg, model, 512, threshold=0.0),
+    model/nerf_training.py:534): field sampling of -sdf on a 512^3 lattice over a 160^3 model + device marching cubes.
+    No PyMCubes / fixture at this size (parity unpinned, see DESIGN): pinned by what the surface must be -- a closed oriented
+    2-manifold of genus 0 (Euler characteristic 2), every vertex on the sphere the grid's trilinear field describes, area and
+    enclosed volume of that sphere, outward orientation, every vertex referenced, deterministic output."""
+    from fgs_nerf_amd import synth
+    from oracle import mcubes_ref as R
+    G, RES, RAD = 160, 512, 0.6
+    model = synth.build_model(G, synth.COARSE_MODEL, device=dev)
+    with torch.no_grad():
+        ax = torch.linspace(-1, 1, G, device=dev)
+        x, y, z = torch.meshgrid(ax, ax, ax, indexing='ij')
+        model.sdf.grid.data[0, 0] = torch.sqrt(x * x + y * y + z * z) - RAD
+    lo, hi = model.xyz_min.clone().float(), model.xyz_max.clone().float()
+    verts, tris = model.extract_geometry(lo, hi, resolution=RES, threshold=0.0)
+    verts2, tris2 = model.extract_geometry(lo, hi, resolution=RES, threshold=0.0)
+    assert np.array_equal(verts, verts2) and np.array_equal(tris, tris2)
+    assert verts.dtype == np.float64 and tris.shape[1] == 3 and len(tris) > 800_000
+    # trilinear interpolation of a distance field sampled at h = 2/159 flattens the sphere by O(h^2 / R)
+    assert np.abs(np.linalg.norm(verts, axis=1) - RAD).max() < 2.5e-4
+    rep = R.mesh_report(verts, tris)
+    assert rep['closed_oriented'] and rep['euler'] == 2 and rep['used_vertices'] == len(verts)
+    assert abs(rep['area'] / (4 * np.pi * RAD ** 2) - 1) < 1e-3
+    assert rep['signed_volume'] > 0 and abs(rep['signed_volume'] / (4 / 3 * np.pi * RAD ** 3) - 1) < 1e-3
+
+
+@pytest.mark.gpu
 def test_device_marching_cubes_matches_committed_fixture(dev, golden):
     """tests/golden/mcubes.npz (oracle/make_golden.py extras): vertices and triangles bit for bit."""
     from fgs_nerf_amd.extract_geometry import marching_cubes
