@@ -139,6 +139,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
                                                              const float *__restrict__ tot_grad,
                                                              float *__restrict__ sdf_grad_grid) {
   S.M = fgs_rows(S.M, S.m_dev);
+  // (launched for a CAPACITY of rows under a device-side count: workgroups wholly beyond the count leave before they clear,
+  // walk and flush their bricks -- 14 us of a 110 us launch at capacity = 1.5 x count)
+  if ((int64_t)blockIdx.x * (FGS_BLOCK / 32) * TAPS_GROUP >= S.M) return;
   __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
   const int64_t m_first = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5) * TAPS_GROUP;
   const int j = threadIdx.x & 31;

@@ -307,11 +307,15 @@ FGS_API float fgs_adam_step_size(int step, float beta1, float beta2, float lr) {
 
 namespace {
 __global__ void k_scalars_tick(const float *__restrict__ table, int n_rows, int n_cols, int64_t *__restrict__ counter,
-                               float *__restrict__ out) {
+                               float *__restrict__ out, int mirror_col, float *__restrict__ mirror_dst) {
   int64_t row = *counter;
   if (row > n_rows - 1) row = n_rows - 1;
   if (row < 0) row = 0;
-  for (int c = threadIdx.x; c < n_cols; c += blockDim.x) out[c] = table[row * n_cols + c];
+  for (int c = threadIdx.x; c < n_cols; c += blockDim.x) {
+    const float v = table[row * n_cols + c];
+    out[c] = v;
+    if (mirror_dst && c == mirror_col) *mirror_dst = v;     // e.g. the model's s_val parameter (model/nerf.py:520)
+  }
   __syncthreads();
   if (threadIdx.x == 0) *counter = *counter + 1;
 }
@@ -334,10 +338,12 @@ __global__ void k_count_guard(int64_t *__restrict__ offsets, int64_t n, int64_t 
 }
 }  // namespace
 
-FGS_API int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out,
-                                  fgs_stream_t stream) {
-  FGS_REQUIRE(table && counter && out && n_rows > 0 && n_cols > 0, FGS_E_INVALID, "fgs_step_scalars_tick: bad argument");
-  hipLaunchKernelGGL(k_scalars_tick, dim3(1), dim3(64), 0, fgs_s(stream), table, n_rows, n_cols, counter, out);
+FGS_API int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
+                                  float *mirror_dst, fgs_stream_t stream) {
+  FGS_REQUIRE(table && counter && out && n_rows > 0 && n_cols > 0 && (!mirror_dst || (mirror_col >= 0 && mirror_col < n_cols)),
+              FGS_E_INVALID, "fgs_step_scalars_tick: bad argument");
+  hipLaunchKernelGGL(k_scalars_tick, dim3(1), dim3(64), 0, fgs_s(stream), table, n_rows, n_cols, counter, out, mirror_col,
+                     mirror_dst);
   FGS_LAUNCH_OK("fgs_step_scalars_tick");
   return 0;
 }

@@ -11,7 +11,7 @@ step's data ever reaches the host:
   a one-wave kernel copies this iteration's row into device scalars and advances a device counter (fgs_step_scalars_tick);
 * with no host-visible value left in the step, forward + losses + backward + TV + MaskedAdam are captured in a hipGraph
   (torch.cuda.CUDAGraph: PyTorch provides the capture plumbing and the private memory pool; every node is one of this
-  library's kernels or a memset) and an iteration is: four small device copies of the ray batch + one graph launch.
+  library's kernels or a memset) and an iteration is: one device copy of the (packed) ray batch + one graph launch.
 * a survivor count above the capacity cannot corrupt anything: a guard kernel flags it, the optimizer kernels skip the update
   of that step, and the host learns about it at its next `check()` (one read, at a logging interval) and can redo the batch
   eagerly or re-capture with a larger capacity.
@@ -52,15 +52,16 @@ class CapturedFineStep:
         self.n_rays, self.capacity = int(n_rays), int(capacity)
         dev = model.sdf.grid.device
         self.dev = dev
-        # ---- schedule table: column 0 = inv_s, column 1 + g = Adam step size of param group g
+        # ---- schedule table: column 0 = inv_s, column 1 + g = Adam step size of param group g, last column = s_val itself
         groups = optimizer.param_groups
         optimizer.ensure_state()
         base_step = [max([optimizer.state[p]['step'] for p in g['params'] if p in optimizer.state] or [0]) for g in groups]
         step_size = lib().fgs_adam_step_size
-        table = np.zeros((n_iters, 1 + len(groups)), dtype=np.float32)
+        table = np.zeros((n_iters, 2 + len(groups)), dtype=np.float32)
         for it in range(n_iters):
             s_val = model._s_val_for(global_step_of(it), True)
             table[it, 0] = np.float32(1.0) / np.float32(s_val)          # model/nerf.py:522: ones(1) / s_val in float32
+            table[it, -1] = np.float32(s_val)                           # model/nerf.py:520: the s_val parameter's new value
             for gi, g in enumerate(groups):
                 b1, b2 = g['betas']
                 table[it, 1 + gi] = step_size(base_step[gi] + it + 1, float(b1), float(b2), float(lr_of(it, g)))
@@ -69,8 +70,9 @@ class CapturedFineStep:
         self.scalars = torch.zeros(self.n_cols, dtype=torch.float32, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.iteration = 0
-        # ---- static inputs
-        self.rays_o, self.rays_d, self.viewdirs, self.target = (torch.zeros(n_rays, 3, device=dev) for _ in range(4))
+        # ---- static inputs: one buffer, so that a batch that arrives packed as [4, n_rays, 3] is ONE copy
+        self.inputs = torch.zeros(4, n_rays, 3, device=dev)
+        self.rays_o, self.rays_d, self.viewdirs, self.target = self.inputs.unbind(0)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss = None
 
@@ -86,13 +88,12 @@ class CapturedFineStep:
         self.opt.use_device_schedule(None)
 
     def _body(self, update: bool):
-        if True:     # (the warm-up pass ticks too, so that it renders with a real 1/s; capture() rewinds the counter)
-            call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
-                 stream())
+        # (the warm-up pass ticks too, so that it renders with a real 1/s; capture() rewinds the counter.)  The tick also
+        # writes this iteration's s_val into the model's parameter (model/nerf.py:520 refreshes it in every forward).
+        call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
+             self.n_cols - 1, ptr(self.model.s_val.data), stream())
         # (global_step only selects the training branch here: 1/s comes from the device scalars)
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
-        # model.s_val mirrors the schedule (model/nerf.py:520 refreshes it in every forward): 1 / (1/s) from the device scalar
-        torch.reciprocal(self.scalars[0:1], out=self.model.s_val.data)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -126,7 +127,11 @@ class CapturedFineStep:
         self.clear_counters()
 
     # ------------------------------------------------------------------------------------------------ per iteration
-    def load(self, batch: Sequence[torch.Tensor]) -> None:
+    def load(self, batch) -> None:
+        """batch: (rays_o, rays_d, viewdirs, target), each [n_rays, 3] -- or the four stacked as one [4, n_rays, 3] tensor."""
+        if torch.is_tensor(batch):
+            self.inputs.copy_(batch, non_blocking=True)
+            return
         ro, rd, vd, target = batch
         self.rays_o.copy_(ro, non_blocking=True)
         self.rays_d.copy_(rd, non_blocking=True)

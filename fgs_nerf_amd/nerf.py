@@ -484,6 +484,9 @@ class nerf(torch.nn.Module):
         if self.s_learn:
             return self.s_val.item()
         s_val = 1. / (global_step + self.s_ratio / self.s_start - self.step_start) * self.s_ratio
+        sf = self.__dict__.get('_fused_cache', {}).get('sync_free')
+        if sf is not None and sf.get('inv_s_dev') is not None:
+            return s_val                  # a device-resident schedule owns s_val and 1/s (graph_step.CapturedFineStep)
         self.s_val.data.fill_(s_val)      # model/nerf.py:520 `torch.ones_like(self.s_val) * s_val`: same value, one launch
         return s_val
 

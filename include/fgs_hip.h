@@ -57,7 +57,8 @@ int fgs_set_inv_s_ptr(const float *inv_s_dev);
  * The optimizer entry points below skip their update while *skip_dev != 0: a step whose survivor list did not fit changes
  * nothing and the host can redo it (it learns about it from flags[0] whenever it next looks). */
 float fgs_adam_step_size(int step, float beta1, float beta2, float lr);      /* adam_upd_kernel.cu:72, all-float */
-int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, fgs_stream_t stream);
+int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
+                          float *mirror_dst, fgs_stream_t stream);
 int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream);
 /* fgs_adam_upd / fgs_adam_upd_multi with the step size read from device memory (one float per call / per tensor) and an
  * optional skip flag; everything else as in the host-scalar forms. */
