@@ -30,6 +30,7 @@ bounds = marks[-steps:] if mode == "graph" else marks[-(steps + 1):]
 n = len(bounds) - 1
 per = defaultdict(lambda: [0, 0.0])
 busy_tot = span_tot = idle_tot = 0.0
+spans = []
 for s in range(n):
     seg = rows[bounds[s]:bounds[s + 1]]
     t0 = int(seg[0]["Start_Timestamp"])
@@ -46,10 +47,12 @@ for s in range(n):
         end_prev = max(end_prev, b)
     idle_tot += idle
     span_tot += t1 - t0
+    spans.append(t1 - t0)
 print(f"# {f}")
 print(f"timed steps found: {n} ({mode} mode)")
 print(f"kernel time per step (sum over kernels): {busy_tot / n / 1e6:.4f} ms")
-print(f"step span (marker to marker):            {span_tot / n / 1e6:.4f} ms")
+print(f"step span (marker to marker):            {span_tot / n / 1e6:.4f} ms   (median {sorted(spans)[len(spans) // 2] / 1e6:.4f}; "
+      f"a host hiccup under the profiler shows up as one long step)")
 print(f"GPU idle inside a step:                  {idle_tot / n / 1e3:.1f} us")
 for name, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / n / 1e3:8.1f} us/step {c / n:6.2f} calls {t / c / 1e3:8.1f} us  {name}")
