@@ -42,6 +42,7 @@ _SIGNATURES = {
     "fgs_mlp_fwd_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P],
     "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
+    "fgs_pad_cols_multi": [I32, P, P, P, P, P, P, P],
     "fgs_set_row_count_ptr": [P],
     "fgs_set_inv_s_ptr": [P],
     "fgs_step_scalars_tick": [P, I32, I32, P, P, I32, P, P],

@@ -368,10 +368,12 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         layers.append(dict(W=rgb_w[i], mask_bits=bits[i - 1], out=out, n_store=rw))
         dY_rgb[i - 1] = out
     fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1)))
-    # narrow products
+    # narrow products: the reflection-encoding columns of dZ (dY_ref[0] . V0[:, rw:]) and dX0 (dY_rgb[0] . W0).  (As one-layer
+    # register-resident chains of 4 row tiles they measured 63 us each against 47 for the tiled GEMM: with 64 MFMAs per chunk
+    # the chain's per-chunk barrier / DMA and its uncoalesced input load dominate.)
     z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
-    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
     dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
     _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw))
     # all weight / bias gradients (the bias gradient of the top refnet layer came out of the head kernel)
     items = []
@@ -577,8 +579,8 @@ class _FusedFine(torch.autograd.Function):
         ldx0, ldz = run.ldx0, run.ldz
         sf = run.sync_free
         token = None if sf else _count_begin(run, ws['surv_off'], N)
-        W0p = torch.nn.functional.pad(rgb_w[0].detach(), (0, ldx0 - rgb_w[0].shape[1]))   # one fill + one copy launch each
-        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldz - ref_w[0].shape[1]))
+        # K-padded first-layer weights of both MLPs, one launch (F.pad: a fill + a copy launch per matrix)
+        W0p, V0p = fo.pad_cols_multi([rgb_w[0].detach(), ref_w[0].detach()], [ldx0, ldz])
         pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         if sf:
@@ -952,7 +954,7 @@ class _FusedCoarse(torch.autograd.Function):
         ref_w = [mlp[2 * i] for i in range(n_ref)]
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
         fw, ldx0 = ref_w[0].shape[0], run.ldx0
-        V0p = torch.nn.functional.pad(ref_w[0].detach(), (0, ldx0 - ref_w[0].shape[1]))
+        (V0p,) = fo.pad_cols_multi([ref_w[0].detach()], [ldx0])
         pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         M = _count_end(token)                      # the one host read of the step

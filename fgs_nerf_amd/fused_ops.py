@@ -98,6 +98,19 @@ def transpose_multi(mats) -> list:
     return outs
 
 
+def pad_cols_multi(mats, widths) -> list:
+    """[F.pad(W, (0, width - W.shape[1])) for W, width in zip(mats, widths)] in ONE launch (include/fgs_hip.h
+    fgs_pad_cols_multi; W: 2-D float32 CUDA with unit column stride, at most 8 of them)."""
+    import ctypes
+    n = len(mats)
+    outs = [torch.empty(w.shape[0], int(width), dtype=torch.float32, device=w.device) for w, width in zip(mats, widths)]
+    PtrArr, I64Arr, IntArr = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    call("fgs_pad_cols_multi", n, PtrArr(*[ptr(w) for w in mats]), IntArr(*[w.shape[0] for w in mats]),
+         IntArr(*[w.shape[1] for w in mats]), I64Arr(*[w.stride(0) for w in mats]), PtrArr(*[ptr(o) for o in outs]),
+         I64Arr(*[o.stride(0) for o in outs]), stream())
+    return outs
+
+
 _RC_IMAGES = {}   # (device index, stream handle, backward) -> packed-weight scratch of the register-resident chains
 
 # bench.py's roofline timing: while enabled, HIP events are recorded on the launch stream IMMEDIATELY around the C call that
@@ -121,7 +134,7 @@ def rc_mask_bits(M: int, device) -> torch.Tensor:
     return torch.empty(((M + 31) // 32 + 4) * 64 * 4, dtype=torch.int32, device=device)
 
 
-def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0) -> None:
+def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None) -> None:
     """Register-resident MLP chain (include/fgs_hip.h fgs_mlp_rc_chain).  `layers`: list of dicts with W (the nn.Linear
     weight [n_out, >= n_in], any leading dimension) and optional n_in (default W.shape[1]), bias, relu, mask_bits (int32
     buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext ([M, >= ext_cols] view) / ext_cols."""
@@ -148,7 +161,7 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, f
     ws = _RC_IMAGES.get(key)
     if ws is None or ws.numel() < need:
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
-    _timed("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)", flop,
+    _timed(label or ("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)"), flop,
            lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),
                         in0_cols, ptr(ws), ws.numel(), stream()))
 

@@ -331,6 +331,10 @@ int fgs_mlp_chain_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, in
 /* dst[i] [cols[i], ld_dst[i]] = transpose of src[i] [rows[i], ld_src[i]], i < n <= 8, one launch (HOST arrays). */
 int fgs_transpose_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
                         float *const *dst, const int64_t *ld_dst, fgs_stream_t stream);
+/* dst[i] [rows[i], ld_dst[i]] = src[i] [rows[i], >= cols[i]] with columns cols[i] .. ld_dst[i]-1 zero-filled, i < n <= 8, one
+ * launch (HOST arrays): the K-padded copies of the first-layer weights the narrow data-gradient products multiply by. */
+int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
+                       float *const *dst, const int64_t *ld_dst, fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,
