@@ -264,6 +264,73 @@ class TrainStepper:
             model.init_smooth_conv(**smu[g_])
         return loss
 
+    # ------------------------------------------------------------------------------------------------ captured windows
+    def run_captured(self, first_step: int, n_steps: int, capacity: Optional[int] = None):
+        """Iterations first_step .. first_step + n_steps - 1 of the fine stage as hipGraph replays
+        (graph_step.CapturedFineStep): one capture, then per iteration a batch gather + one graph launch, nothing read by the
+        host.  Equivalent to calling `step()` for each of them, for windows in which the iteration's SHAPE does not change:
+        no grid rescale, no voxel increment, no autograd TV terms (`ori_tv`, smooth-gradient TV), the TV add-grad either on
+        in every iteration of the window or in none, no `decay_step_module` / `tv_updates` / `s_updates` / `smooth_updates`
+        entry inside it, one GPU.  The learning-rate decay (model/nerf_training.py:389-436) and the NeuS s_val schedule
+        become rows of the device-resident table.  Returns (losses [n_steps] device tensor, overflowed: bool); on overflow
+        (more survivors than `capacity` in some iteration: that iteration's update was skipped) the caller re-runs with a
+        larger capacity or falls back to `step()`.  Per-iteration statistics are not collected in a captured window."""
+        from . import fused
+        from .graph_step import CapturedFineStep
+        model, ct, opt = self.model, self.cfg_train, self.optimizer
+        steps = range(first_step, first_step + n_steps)
+        if self.stage != 'fine' or not fused.supports(model) or self.averager is not None:
+            raise RuntimeError("run_captured covers the fused fine stage on one GPU")
+        if ct.get('voxel_inc', False) or ct.get('ori_tv', False):
+            raise RuntimeError("run_captured: voxel_inc / ori_tv iterations change shape from step to step; use step()")
+        for key, cfg in (('pg_scale', ct), ('reset_iter', ct)):
+            if any(g in cfg.get(key, []) for g in steps):
+                raise RuntimeError(f"run_captured: {key} inside the window")
+        for key, cfg in (('decay_step_module', ct), ('tv_updates', ct), ('s_updates', self.cfg_model),
+                         ('smooth_updates', self.cfg_model)):
+            if any((g - 1) in cfg.get(key, {}) for g in steps):
+                raise RuntimeError(f"run_captured: a {key} entry falls inside the window")
+        tv_on = {self._tv_active(g) for g in steps}
+        tv_terms = Cfg(ct.get('tv_terms', {}))
+        if len(tv_on) != 1:
+            raise RuntimeError("run_captured: the TV schedule switches inside the window")
+        tv_on = tv_on.pop()
+        if tv_on and (tv_terms.get('smooth_grad_tv', 0) > 0 and ct.get('weight_tv_density', 0) > 0):
+            raise RuntimeError("run_captured: the smooth-gradient TV term is an autograd loss; use step()")
+        if tv_on and ct.get('weight_tv_k0', 0) > 0:
+            raise RuntimeError("run_captured: TV add-grad on k0 is not part of the captured iteration; use step()")
+        dense = {g < ct.get('tv_dense_before', 0) for g in steps}
+        if tv_on and len(dense) != 1:
+            raise RuntimeError("run_captured: tv_dense_before falls inside the window")
+        tv = None
+        if tv_on and ct.get('weight_tv_density', 0) > 0 and tv_terms.get('sdf_tv', 0) > 0:
+            tv = (ct.weight_tv_density * tv_terms.sdf_tv / ct.N_rand, dense.pop())
+        # learning rates: iteration i runs with lr_now * prod_{j < i} decay(first_step + j)   (step() decays AFTER its update)
+        factors = [1.0]
+        for g in steps:
+            factors.append(factors[-1] * lr_decay_factor(ct, g))
+        base_lr = {id(g): g['lr'] for g in opt.param_groups}
+        first = self._select_rays()
+        if capacity is None:
+            with torch.no_grad():
+                probe = model(first[1], first[2], first[3], global_step=first_step, **self.render_kwargs)
+            capacity = (int(probe['weights'].shape[0] * 1.5) + 4095) // 4096 * 4096
+        cap = CapturedFineStep(model, opt, ct, self.render_kwargs, ct.N_rand, n_iters=n_steps,
+                               global_step_of=lambda it: first_step + it,
+                               lr_of=lambda it, g: base_lr[id(g)] * factors[it], tv=tv, capacity=capacity)
+        batch = (first[1], first[2], first[3], first[0])           # (rays_o, rays_d, viewdirs, target)
+        cap.capture(batch)
+        losses = torch.empty(n_steps, dtype=torch.float32, device=self.rgb_tr.device)
+        for i in range(n_steps):
+            if i:
+                t, ro, rd, vd = self._select_rays()
+                batch = (ro, rd, vd, t)
+            losses[i:i + 1].copy_(cap.replay(batch).detach().reshape(1))
+        for g in opt.param_groups:                                  # the host's copy of the schedule catches up
+            g['lr'] = base_lr[id(g)] * factors[-1]
+        overflow, _ = cap.check()
+        return losses, overflow
+
     def stats(self, reset: bool = True) -> Dict[str, float]:
         """Means of the per-iteration statistics since the last call (one device->host transfer)."""
         if not self._stats['psnr']:
