@@ -116,7 +116,7 @@ PMC_KERNELS = (("k_mlp_rc<false", "k_mlp_rc forward chain"), ("k_mlp_rc<true", "
                ("k_mlp_wgrad", "k_mlp_wgrad"), ("k_mlp_fwd", "k_mlp_fwd"), ("k_linear_bwd", "k_linear_bwd"), ("k_gemm", "k_gemm"))
 
 
-def pmc_traffic_live(args, timeout_s=300):
+def pmc_traffic_live(args, timeout_s=180):
     import csv
     import glob
     import shutil
