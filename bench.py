@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
-                    help="graph (default, 1 GPU, fused fine stage): the whole step is one hipGraph replay, nothing of it reaches "
+                    help="graph (default, 1 GPU, fused path): the whole step is one hipGraph replay, nothing of it reaches "
                          "the host; eager: Python enqueues every launch and reads the survivor count back once per step")
     ap.add_argument("--grid", type=int, default=GRID,
                     help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
@@ -305,7 +305,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         del res
     torch.cuda.synchronize()
-    use_graph = (args.mode == "graph" and world == 1 and not force_dist and not args.composed and args.stage == "fine"
+    use_graph = (args.mode == "graph" and world == 1 and not force_dist and not args.composed
                  and os.environ.get("FGS_MLP", "rc") == "rc")
     STEP_STATS["max_survivors"] = 0
     for i in range(args.warmup):
@@ -317,7 +317,8 @@ def main():
         # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
         seen = max(STEP_STATS["max_survivors"], 16384)
         capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
-        captured = CapturedFineStep(model, opt, synth.FINE_LOSS, synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
+        captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
+                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
                                     global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
                                     tv=(0.01 * 0.1 / n_global, True), capacity=capacity)
         captured.capture(batches[0])

@@ -205,9 +205,14 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A)
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (ray >= A.n_rays) return;
-  const int n_active = (int)fgs_uniform(A.n_alive[ray]), n_kept = (int)fgs_uniform(A.n_surv[ray]);
-  if (n_kept == 0) return;
+  const int n_active = (int)fgs_uniform(A.n_alive[ray]);
+  int n_kept = (int)fgs_uniform(A.n_surv[ray]);
   const int64_t rec0 = ray * A.max_steps, s_off = fgs_uniform(A.surv_off[ray]);
+  // (fgs_count_guard cuts the offsets at the buffers' capacity when a step's survivor list did not fit: never walk past
+  // this ray's slots -- that step's update is skipped anyway)
+  const int64_t n_slots = fgs_uniform(A.surv_off[ray + 1]) - s_off;
+  if ((int64_t)n_kept > n_slots) n_kept = (int)n_slots;
+  if (n_kept <= 0) return;
   const float o[3] = {A.rays_o[3 * ray], A.rays_o[3 * ray + 1], A.rays_o[3 * ray + 2]};
   const float d[3] = {A.rays_d[3 * ray], A.rays_d[3 * ray + 1], A.rays_d[3 * ray + 2]};
   const float vx = A.viewdirs[3 * ray], vy = A.viewdirs[3 * ray + 1], vz = A.viewdirs[3 * ray + 2];

@@ -146,7 +146,7 @@ class _DeviceScalars:
 
 
 def set_sync_free(model, capacity=None, inv_s_dev=None) -> None:
-    """Switch the fused fine-stage path of `model` to the sync-free form (or back, with capacity=None): the survivor count
+    """Switch the fused path of `model` (fine or coarse stage) to the sync-free form (or back, with capacity=None): the survivor count
     is never read by the host; result tensors, activations and gradients of the survivors are allocated for `capacity` rows
     and every kernel clamps to the device-side count; a device-side guard records a count above the capacity (see
     `sync_free_state`) and makes the optimizer skip that step.  `inv_s_dev`: optional 1-element float32 device tensor the
@@ -941,6 +941,9 @@ class _FusedCoarse(torch.autograd.Function):
         use_mc = run.mask_grid is not None
         inc = run.inc
         alphainv_last = torch.empty(N, dtype=F32, device=dev)   # an output of the march: a fresh tensor per step
+        sf = run.sync_free
+        if sf and sf.get('inv_s_dev') is not None:
+            call("fgs_set_inv_s_ptr", ptr(sf['inv_s_dev']))       # reset by forward_coarse()
         call("fgs_march_coarse_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), ptr(getattr(run, 'vol4', None)), run.dist, run.inv_s,
              run.thres, ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
@@ -949,7 +952,7 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
              ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
         call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
-        token = _count_begin(run, ws['surv_off'], N)
+        token = None if sf else _count_begin(run, ws['surv_off'], N)
         n_ref = run.n_ref                           # queued behind the count copy: K-padded first-layer weights, k0.grad fill
         ref_w = [mlp[2 * i] for i in range(n_ref)]
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
@@ -957,7 +960,13 @@ class _FusedCoarse(torch.autograd.Function):
         (V0p,) = fo.pad_cols_multi([ref_w[0].detach()], [ldx0])
         pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
-        M = _count_end(token)                      # the one host read of the step
+        if sf:       # sync-free (see _FusedFine.forward): the count stays on the device, M is the CAPACITY from here on
+            M = sf['capacity']
+            run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
+            call("fgs_count_guard", ptr(ws['surv_off']), N + 1, M, ptr(sf['flags']), ptr(sf['total']), st)
+            call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_coarse() when this forward returns
+        else:
+            M = _count_end(token)                  # the one host read of the step
         run.M = M
         ray_id = torch.empty(M, dtype=I64, device=dev)
         step_id = torch.empty(M, dtype=I64, device=dev)
@@ -1023,7 +1032,15 @@ class _FusedCoarse(torch.autograd.Function):
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
+    def backward(ctx, *grads):
+        run = ctx.run
+        sf = run.sync_free
+        inv = ptr(sf['inv_s_dev']) if (sf and sf.get('inv_s_dev') is not None) else None
+        with _DeviceScalars(count=run.count_ptr if sf else None, inv_s=inv):    # (the autograd thread has its own setting)
+            return _FusedCoarse._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
         run = ctx.run
         if run.done:
             raise RuntimeError("fused forward_coarse: backward called twice on the same forward (retain_graph is not "
@@ -1293,8 +1310,17 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     mlp = []
     for layer in fl:
         mlp += [layer.weight, layer.bias]
-    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
-        run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
+    fw_ = fl[0].out_features
+    if run.sync_free and not (_MLP_IMPL == "rc" and fw_ % 32 == 0 and fw_ <= 256 and run.ldx0 <= 256 and len(fl) - 1 <= 8):
+        raise RuntimeError("the sync-free coarse-stage path needs the register-resident MLP kernels (FGS_MLP=rc, refnet width "
+                           "a multiple of 32, <= 256)")
+    try:
+        (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
+            run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
+    finally:
+        if run.sync_free:
+            call("fgs_set_row_count_ptr", None)
+            call("fgs_set_inv_s_ptr", None)
     ex = run.extras
     depth = ex['depth']
 
@@ -1319,7 +1345,8 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
-             'survivor_pts': run.saved['pts']}
+             'survivor_pts': run.saved['pts'],
+             'survivor_count_ptr': run.count_ptr}       # sync-free mode: see forward_fine
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox,
                               'viewdirs': lambda: run.viewdirs[ray_id]})     # per-sample gather only when somebody reads it
 

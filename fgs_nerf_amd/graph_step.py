@@ -30,7 +30,7 @@ from .losses import fused_render_losses
 
 
 class CapturedFineStep:
-    """One captured iteration of the fine stage.
+    """One captured iteration (fine stage, or a coarse stage: same kernels behind the same device-side row count).
 
     model, optimizer : a fused-path `nerf` model (stage 'fine') and its MaskedAdam
     loss_cfg         : the loss weights (config keys of model/nerf_training.py:308-327)
@@ -46,8 +46,9 @@ class CapturedFineStep:
     def __init__(self, model, optimizer, loss_cfg: Dict, render_kwargs: Dict, n_rays: int, n_iters: int,
                  global_step_of: Callable[[int], int], lr_of: Callable[[int, Dict], float], tv=None,
                  capacity: int = 131072):
-        if not fused.supports(model):
-            raise RuntimeError("CapturedFineStep needs a model the fused fine-stage path covers")
+        coarse = getattr(model, 'stage', 'fine') in ('coarse', 'geometry_searching')
+        if not (fused.supports_coarse(model) if coarse else fused.supports(model)):
+            raise RuntimeError("CapturedFineStep needs a model the fused path covers")
         self.model, self.opt, self.loss_cfg, self.kw, self.tv = model, optimizer, dict(loss_cfg), dict(render_kwargs), tv
         self.n_rays, self.capacity = int(n_rays), int(capacity)
         dev = model.sdf.grid.device
@@ -103,12 +104,22 @@ class CapturedFineStep:
             self.opt.step()
         return loss
 
+    def _drop_autograd_leftovers(self) -> None:
+        self.model.gradient = None                 # rebuilt by (coarse) or on first read after (fine) the next forward
+        self.loss = None
+
     def capture(self, batch: Sequence[torch.Tensor]) -> None:
         """Warm up (one eager forward + backward in the sync-free form on `batch`, no update: allocator pools, cached host
         copies of the geometry) and capture the step."""
         self.load(batch)
         self._enter()
         try:
+            # A leaf's AccumulateGrad node lives as long as any autograd graph that reaches it, and it remembers the stream it
+            # was created on; backward synchronises with that stream.  The coarse stages keep their gradient volume (a node
+            # over sdf.grid) on the model between iterations: after eager iterations that node sits on the DEFAULT stream,
+            # and a capture whose backward touches the default stream dies inside hipStreamEndCapture.  Drop the old graph
+            # before the warm-up (its nodes are then created on the warm-up's stream) and again before the capture.
+            self._drop_autograd_leftovers()
             side = torch.cuda.Stream(device=self.dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -116,6 +127,7 @@ class CapturedFineStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.opt.zero_grad(set_to_none=True)
+            self._drop_autograd_leftovers()
             fused.reset_grid_grad(self.model)      # the warm-up's k0.grad was not consumed: the captured step starts clean
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -160,3 +172,6 @@ class CapturedFineStep:
     def check(self):
         """(overflowed, survivors processed since the last clear) -- one device->host read; not for every step."""
         return fused.sync_free_state(self.model)
+
+
+CapturedStep = CapturedFineStep       # (the class serves both stages; the fine stage came first)

@@ -319,7 +319,8 @@ class TrainStepper:
                                global_step_of=lambda it: first_step + it,
                                lr_of=lambda it, g: base_lr[id(g)] * factors[it], tv=tv, capacity=capacity)
         batch = (first[1], first[2], first[3], first[0])           # (rays_o, rays_d, viewdirs, target)
-        cap.capture(batch)
+        self.last_result = None          # (an earlier step()'s result would keep its autograd graph -- and the leaves'
+        cap.capture(batch)               # AccumulateGrad nodes, bound to the default stream -- alive across the capture)
         losses = torch.empty(n_steps, dtype=torch.float32, device=self.rgb_tr.device)
         for i in range(n_steps):
             if i:

@@ -124,8 +124,60 @@ def test_stepper_captured_window_matches_step_by_step(dev):
     for a, b in zip(runs["steps"][2], runs["captured"][2]):
         assert abs(a - b) <= 1e-12 * abs(a)                                                  # the host's lr copy caught up
     assert runs["steps"][3] == runs["captured"][3] and set(runs["captured"][3]) == {N}
+    # a captured window after eager steps on the SAME stepper (their autograd leftovers must not reach the capture)
+    model = synth.build_model(32, synth.FINE_MODEL, device=dev)
+    st = nt.TrainStepper(model, cfg, {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=2)
+    for g in range(1, 3):
+        st.step(g)
+    losses, overflow = st.run_captured(3, 3)
+    assert not overflow and bool(torch.isfinite(losses).all())
     # windows the captured form does not cover are refused, not silently mis-run
     model = synth.build_model(32, synth.FINE_MODEL, device=dev)
     st = nt.TrainStepper(model, dict(cfg, tv_every=3), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
     with pytest.raises(RuntimeError):
         st.run_captured(1, 6)
+
+
+def test_captured_coarse_step_matches_eager_steps(dev):
+    """The coarse stage (5^3 smoothing + gradient volume + forward_coarse + losses + backward + TV + MaskedAdam) captured the
+    same way: same survivor totals, first loss equal to an ulp, parameters equal in norm after a few Adam steps."""
+    import bench
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.graph_step import CapturedStep
+    from fgs_nerf_amd.losses import fused_render_losses
+    N, ITERS, TV = 512, 4, (0.01 * 0.1 / 512, True)
+
+    def setup():
+        model = synth.build_model(48, synth.COARSE_MODEL, device=dev)
+        opt = bench.make_optimizer(model)
+        batches = []
+        for b in range(3):
+            ro, rd, vd = synth.random_rays(N, seed=70 + b)
+            target = torch.rand(N, 3, generator=torch.Generator().manual_seed(b))
+            batches.append(tuple(t.to(dev).contiguous() for t in (ro, rd, vd, target)))
+        return model, opt, batches
+
+    model, opt, batches = setup()
+    losses_e, surv_e = [], 0
+    for it in range(ITERS):
+        ro, rd, vd, target = batches[it % 3]
+        res = model(ro, rd, vd, global_step=300 + 50 * it, **synth.RENDER_KWARGS)
+        surv_e += int(res['weights'].shape[0])
+        loss = fused_render_losses(res, target, synth.COARSE_LOSS, model)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        model.sdf_total_variation_add_grad(*TV)
+        opt.step()
+        losses_e.append(float(loss.detach()))
+    model2, opt2, _ = setup()
+    step = CapturedStep(model2, opt2, synth.COARSE_LOSS, synth.RENDER_KWARGS, N, n_iters=ITERS,
+                        global_step_of=lambda it: 300 + 50 * it, lr_of=lambda it, g: g['lr'], tv=TV, capacity=16384)
+    step.capture(batches[0])
+    losses_g = [float(step.replay(batches[it % 3]).clone()) for it in range(ITERS)]
+    overflow, surv_g = step.check()
+    assert not overflow and surv_g == surv_e, (overflow, surv_g, surv_e)
+    assert abs(losses_g[0] - losses_e[0]) < 2e-7 * abs(losses_e[0]) + 1e-9, (losses_g, losses_e)
+    for a, b in zip(losses_g, losses_e):
+        assert abs(a - b) < 5e-4 * abs(b), (losses_g, losses_e)
+    for pa, pb in zip(model.parameters(), model2.parameters()):
+        assert float((pa.detach() - pb.detach()).norm() / pa.detach().norm().clamp_min(1e-30)) < 3e-3

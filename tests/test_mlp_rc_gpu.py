@@ -184,3 +184,16 @@ def test_wgrad_all_layers_one_launch_matches_fp64(dev, M):
     fo.mlp_wgrad(M, [(d0, X0, g0, None, W, 90), (d1, X1, g1, b1, W, W)])
     assert rel_l2(g0[:, :90], 1.0 + d0.double().T @ X0[:, :90].double()) < 2e-6
     assert rel_l2(g1, d1.double().T @ X1.double()) < 2e-6 and rel_l2(b1, d1.double().sum(0)) < 2e-6
+
+
+def test_pad_cols_multi_matches_torch_pad(dev):
+    """fgs_pad_cols_multi: the K-padded first-layer weights of both MLPs in one launch == F.pad per matrix (views with a
+    row pitch larger than their width included)."""
+    from fgs_nerf_amd import fused_ops as fo
+    torch.manual_seed(3)
+    big = torch.randn(256, 400, device=dev)
+    mats = [torch.randn(256, 106, device=dev), big[:, 7:314], torch.randn(3, 5, device=dev)]
+    widths = [108, 308, 8]
+    outs = fo.pad_cols_multi(mats, widths)
+    for w, width, o in zip(mats, widths, outs):
+        assert torch.equal(o, torch.nn.functional.pad(w, (0, width - w.shape[1])))
