@@ -39,7 +39,9 @@ PROFILE = {"enabled": False, "gemm_events": [], "open": None}      # see set_pro
 def supports(model) -> bool:
     """Configurations the fused kernels cover (everything the shipped fine-stage configs use)."""
     from .nerf import mlp_layers
-    if model.stage != 'fine' or model.rgbnet is None or model.smooth_sdf or model.s_learn:
+    if model.stage != 'fine' or model.rgbnet is None or model.s_learn:
+        return False
+    if model.smooth_sdf and int(model.smooth_conv.weight.shape[-1]) > 7:      # dense.smooth3d covers kernel sides <= 7
         return False
     if not (model.fast_color_thres > 0) or not model.use_viewdir:
         return False
@@ -1366,9 +1368,20 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     if run.sync_free and not _rc_eligible(rl[0].out_features, fl[0].out_features, run.ldx0, run.ldz, len(rl), len(fl)):
         raise RuntimeError("the sync-free fine-stage path needs the register-resident MLP kernels (FGS_MLP=rc and equal "
                            "rgbnet / refnet widths that are multiples of 32, <= 256)")
+    # model/nerf.py:791: every lookup of the fine stage samples the smoothed grid when smooth_sdf is set (an autograd node over
+    # sdf.grid, csrc/dense.hip); model.gradient stays the gradient volume of the RAW grid (model/nerf.py:856)
+    sdf_in = model.sdf.grid
+    if model.smooth_sdf:
+        from . import dense
+        taps = getattr(model, '_fused_taps', None)
+        if taps is None or taps[0] is not model.smooth_conv:
+            taps = (model.smooth_conv, dense._taps_c(model.smooth_conv.weight))
+            model._fused_taps = taps
+        sdf_in = dense.smooth3d(model.sdf.grid, model.smooth_conv.weight, taps[1])
+    run.sdf_in = sdf_in.detach()
     try:
         (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
-            run, model.sdf.grid, model.k0.grid, *mlp)
+            run, sdf_in, model.k0.grid, *mlp)
     finally:
         if run.sync_free:
             call("fgs_set_row_count_ptr", None)
@@ -1382,6 +1395,14 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
             _, _, _, mask_outbbox, _ = model.sample_ray(rays_o=rays_o, rays_d=rays_d, **render_kwargs)
         return mask_outbbox
 
+    def _current_sdf_in():
+        """the grid the lookups sample NOW (the training loop reads 'mask' after optimizer.step(): on the updated grid)"""
+        if not model.smooth_sdf:
+            return model.sdf.grid
+        from . import dense
+        with torch.no_grad():
+            return dense.smooth3d(model.sdf.grid.detach(), model.smooth_conv.weight, model._fused_taps[1])
+
     def lazy_mask():
         """`weights > thres` over the reference's alpha-compacted list (model/nerf.py:825): per ray the alive records come
         first (survivors flagged), the samples behind the terminating one follow (all False)."""
@@ -1392,7 +1413,7 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
         n_m1 = torch.empty(N, dtype=I64, device=dev)
         n_in = torch.empty(N, dtype=I64, device=dev)
         call("fgs_march_count", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
-             g.voxel_size, run.near, 1e9, run.stepdist, ptr(model.sdf.grid), run.dist, run.inv_s, run.thres,
+             g.voxel_size, run.near, 1e9, run.stepdist, ptr(_current_sdf_in()), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
              g.mask[3] if g.mask else 0.0, run.max_steps, ptr(n_m1), ptr(n_in), stream())
         # the training loop reads 'mask' after optimizer.step() (nerf_training.py:373-381), i.e. on an updated sdf grid:
