@@ -418,7 +418,8 @@ def main():
                 "rho_survivors_per_inbbox_sample": round(rho, 4),
                 "sampled_path": round(sampled / step_s / 8e12, 4), "whole_step": round((sampled + dense) / step_s / 8e12, 4),
                 "note": "algorithmic bytes / step time / 8 TB/s; the step is bound by fp32 matrix throughput and atomics"}
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine") else cpu_baseline()
+        # (the CPU baseline is timed at N = 1 only: the other ranks of a multi-GPU run would sit in the final barrier meanwhile)
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine" or world > 1) else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
