@@ -70,6 +70,8 @@ _SIGNATURES = {
     "fgs_brick_compact": [P, I64, P, P, P],
     "fgs_tv_loss_value": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P],
     "fgs_tv_loss_grad": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I32, P],
+    "fgs_brick_masks_pts": [P, I64, P, P, I32, I32, I32, P, P],
+    "fgs_adam_upd_voxels": [P, P, P, P, I32, I32, I32, I32, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_bricks": [P, P, P, P, I32, I32, I32, I32, P, P, I64, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_multi": [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P],
     "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -107,10 +107,15 @@ class MaskedAdam(torch.optim.Optimizer):
         from ._lib import ptr
         b1, b2 = group['betas']
         idx, n = t['idx'], t['n']
-        call("fgs_adam_upd_bricks", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'],
-             ptr(idx) if idx is not None else None, None, int(n) if idx is not None else 0, ptr(t['flags']),
-             int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']),
-             ss_ptr if dev is not None else None, dev['skip'] if dev is not None else None, stream())
+        tail = (int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']),
+                ss_ptr if dev is not None else None, dev['skip'] if dev is not None else None, stream())
+        if idx is None:       # this rank's own scatter: the voxels recorded in the 64-bit brick masks
+            call("fgs_adam_upd_voxels", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'], ptr(t['flags']),
+                 *tail)
+        else:                 # after a brick-sparse exchange: the union's bricks, whole (other ranks' voxels are not in the masks)
+            call("fgs_adam_upd_bricks", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'], ptr(idx), None,
+                 int(n), None, *tail)
+            t['flags'].zero_()
         gb['clean'] = True
         return True
 

@@ -446,9 +446,10 @@ def _zeros_like_strided(t):
 # ---- the feature grid's gradient: one persistent, self-cleaning buffer instead of a fresh zero-filled one per step ----------
 # Rays touch a thin shell of the feature grid, yet a step used to zero-fill all of k0.grad (197 MB at 160^3, 1.57 GB at
 # 320^3) and MaskedAdam then read all of it back to find the few non-zero elements (model/adam.py:205-221 has no other way to
-# know).  Here the backward pass scatters into a buffer that is all-zero by construction, records the 4x4x4-voxel bricks the
-# survivors' trilinear corners fall into (fgs_brick_flags_pts), and MaskedAdam's update of this tensor visits those bricks
-# only and zeroes what it consumed (fgs_adam_upd_bricks).  Anything that breaks the "non-zero only inside the recorded
+# know).  Here the backward pass scatters into a buffer that is all-zero by construction, records the voxels the survivors'
+# trilinear corners fall on (fgs_brick_masks_pts: a 64-bit mask per 4x4x4-voxel brick), and MaskedAdam's update of this tensor
+# visits those voxels only and zeroes what it consumed (fgs_adam_upd_voxels; after a multi-GPU exchange: the union's bricks,
+# fgs_adam_upd_bricks).  Anything that breaks the "non-zero only inside the recorded
 # bricks" invariant (a dense TV term, an autograd accumulation into the same tensor, a dense gradient exchange) is detected
 # or declared (`_fgs_touched['valid']`, tensor version, storage use count) and falls back to dense update + zero fill.
 _BRICK_ADAM = os.environ.get("FGS_BRICK_ADAM", "1") != "0"
@@ -473,7 +474,8 @@ def _grid_grad_state(cache, k0_grid, create: bool):
     if k0_grid.stride() != (C * X * Y * Z, 1, Y * Z * C, Z * C, C) or C % 4 or k0_grid.dtype != F32 or min(X, Y, Z) < 2:
         return None           # not channel-last / channel count not float4-able: the plain path
     buf = _zeros_like_strided(k0_grid)
-    flags = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4), dtype=torch.int32, device=k0_grid.device)
+    # 64 bytes per 4x4x4-voxel brick: which of its voxels hold a trilinear corner of a survivor (fgs_brick_masks_pts)
+    flags = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4) * 64, dtype=torch.uint8, device=k0_grid.device)
     gb = cache['k0_grad'] = dict(key=key, buf=buf, flags=flags, clean=True, dims=(C, X, Y, Z), base_users=None)
     gb['base_users'] = _storage_users(buf)
     return gb
@@ -512,7 +514,7 @@ def _publish_touched(gb, k0_grid, grad_k0, pts, M, g, st, exchange: bool):
         k0_grid._fgs_touched = None
         return
     C, X, Y, Z = gb['dims']
-    call("fgs_brick_flags_pts", ptr(pts), M, g.lo_c, g.hi_c, X, Y, Z, ptr(gb['flags']), st)
+    call("fgs_brick_masks_pts", ptr(pts), M, g.lo_c, g.hi_c, X, Y, Z, ptr(gb['flags']), st)
     k0_grid._fgs_touched = dict(state=gb, grad_ptr=grad_k0.data_ptr(), version=gb['buf']._version, dims=gb['dims'],
                                 flags=gb['flags'], idx=None, n=None, valid=True, exchange=exchange)
 

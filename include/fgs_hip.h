@@ -565,6 +565,16 @@ int fgs_adam_upd_bricks(float *param, float *grad, float *exp_avg, float *exp_av
                         float beta2, float lr, float eps, const float *step_size_dev, const int *skip_dev,
                         fgs_stream_t stream);
 
+/* The same at voxel granularity: masks holds 64 bytes per 4x4x4-voxel brick, byte 16 x' + 4 y' + z' != 0 = "voxel (x', y', z')
+ * of the brick holds a trilinear corner of a survivor point" (fgs_brick_masks_pts sets them; the caller zeroes the 16-byte
+ * aligned buffer once); fgs_adam_upd_voxels walks the recorded voxels only, applies the masked update to their C floats,
+ * zeroes the consumed gradient and clears the bytes.  C a multiple of 4, <= 64. */
+int fgs_brick_masks_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
+                        int Z, unsigned char *masks, fgs_stream_t stream);
+int fgs_adam_upd_voxels(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int C, int X, int Y, int Z,
+                        unsigned char *masks, int step, float beta1, float beta2, float lr, float eps,
+                        const float *step_size_dev, const int *skip_dev, fgs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Integrated directional encoding -- generate_ide_fn / integrated_dir_enc_fn (model/utils.py:515-574; built at
  * model/nerf.py:179, never evaluated by the reference's forward passes).  mat: [n_pow][n] coefficient matrix

@@ -76,6 +76,69 @@ def test_brick_adam_is_bit_exact_and_consumes_the_gradient(dev, oracle, dims, se
         assert not bool(g.any()) and not bool(flags.any())          # gradient consumed, occupancy cleared
 
 
+def _masks_for(pts, lo, hi, dims, dev):
+    from fgs_nerf_amd._lib import call, ptr, stream
+    C, X, Y, Z = dims
+    masks = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4) * 64, dtype=torch.uint8, device=dev)
+    call("fgs_brick_masks_pts", ptr(pts), pts.shape[0], (ctypes.c_float * 3)(*lo), (ctypes.c_float * 3)(*hi), X, Y, Z,
+         ptr(masks), stream())
+    return masks
+
+
+def _voxels_of(masks, dims):
+    """bool [1,C,X,Y,Z]: the voxels whose byte (16 x' + 4 y' + z' of their brick's 64) is set"""
+    C, X, Y, Z = dims
+    nb = ((X + 3) // 4, (Y + 3) // 4, (Z + 3) // 4)
+    m = masks.reshape(*nb, 4, 4, 4).cpu().numpy() != 0                    # [bx, by, bz, x', y', z']
+    out = np.ascontiguousarray(m.transpose(0, 3, 1, 4, 2, 5)).reshape(nb[0] * 4, nb[1] * 4, nb[2] * 4)
+    return torch.from_numpy(out[:X, :Y, :Z].copy())[None, None].expand(1, C, X, Y, Z)
+
+
+@pytest.mark.parametrize("dims", [(12, 20, 24, 28), (8, 18, 21, 23), (4, 5, 6, 7), (16, 32, 32, 32), (64, 8, 8, 8)])
+def test_voxel_adam_is_bit_exact_and_consumes_the_gradient(dev, oracle, dims):
+    """fgs_brick_masks_pts + fgs_adam_upd_voxels: the recorded voxels are exactly the in-volume trilinear corners of the
+    points (checked against a torch restatement of the index arithmetic), the update over them is bit-identical to the
+    oracle's masked Adam, gradient and masks are zero afterwards.  With a device step size and the skip flag, too."""
+    from fgs_nerf_amd._lib import call, lib, ptr, stream
+    C, X, Y, Z = dims
+    shape = (1, C, X, Y, Z)
+    rng = np.random.RandomState(X + C)
+    lo, hi = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
+    pts = torch.from_numpy((rng.rand(90, 3) * 2.2 - 1.1).astype(np.float32)).to(dev)       # some outside the box
+    p, m, v = _cl(shape, dev, rng=rng), _cl(shape, dev), _cl(shape, dev)
+    ref_p, ref_m, ref_v = _storage(p), _storage(m), _storage(v)
+    ss = torch.zeros(1, dtype=torch.float32, device=dev)
+    skip = torch.zeros(1, dtype=torch.int32, device=dev)
+    for step, (dev_sched, skipped) in enumerate([(False, False), (True, False), (True, True), (False, False)], start=1):
+        masks = _masks_for(pts[(step - 1) * 20:step * 20 + 10], lo, hi, dims, dev)
+        vox = _voxels_of(masks, dims).to(dev)
+        if step == 1:       # the corners, restated: index = (p - lo) / (hi - lo) * (n - 1), floor and floor + 1 per axis
+            q = pts[0:30].double().cpu()
+            want = torch.zeros(X, Y, Z, dtype=torch.bool)
+            f = (q + 1.0) / 2.0 * torch.tensor([X - 1, Y - 1, Z - 1], dtype=torch.float64)
+            f0 = torch.floor(f.float()).long()      # the kernels compute the index in float32
+            f32 = ((pts[0:30].cpu() - torch.tensor(lo)) / (torch.tensor(hi) - torch.tensor(lo))).float()
+            for dx in (0, 1):
+                for dy in (0, 1):
+                    for dz in (0, 1):
+                        c = f0 + torch.tensor([dx, dy, dz])
+                        ok = ((c >= 0) & (c < torch.tensor([X, Y, Z]))).all(1)
+                        want[c[ok, 0], c[ok, 1], c[ok, 2]] = True
+            got = vox[0, 0].cpu()
+            assert int((got ^ want).sum()) <= 2, int((got ^ want).sum())      # (a point within an ulp of a lattice plane)
+        g = _cl(shape, dev, rng=rng)
+        g.mul_(vox).mul_(torch.from_numpy((rng.rand(*shape) > 0.3).astype(np.float32)).to(dev))
+        g_ref = _storage(g)
+        skip.fill_(int(skipped))
+        ss.fill_(lib().fgs_adam_step_size(step, 0.9, 0.99, 0.05))
+        call("fgs_adam_upd_voxels", ptr(p), ptr(g), ptr(m), ptr(v), C, X, Y, Z, ptr(masks), step, 0.9, 0.99, 0.05, 1e-8,
+             ptr(ss) if dev_sched else None, ptr(skip) if dev_sched else None, stream())
+        if not skipped:
+            oracle.K.adam_upd(ref_p, g_ref, ref_m, ref_v, step, 0.9, 0.99, 0.05, 1e-8, mode=1)
+        assert np.array_equal(_storage(p), ref_p) and np.array_equal(_storage(m), ref_m) and np.array_equal(_storage(v), ref_v)
+        assert not bool(g.any()) and not bool(masks.any())
+
+
 def test_brick_adam_device_step_size_and_skip_flag(dev, oracle):
     from fgs_nerf_amd._lib import call, lib, ptr, stream
     dims = (12, 16, 16, 16)
