@@ -19,7 +19,7 @@ cd $ROOT
 python3 bench.py > gpurun_out/r_bench.json 2> gpurun_out/r_bench.err
 python3 scripts/trace_summary.py gpurun_out/r_fine 30 graph > gpurun_out/r_sum_fine.txt
 python3 scripts/trace_summary.py gpurun_out/r_eager 30 eager > gpurun_out/r_sum_eager.txt
-python3 scripts/trace_summary.py gpurun_out/r_coarse 30 eager > gpurun_out/r_sum_coarse.txt
+python3 scripts/trace_summary.py gpurun_out/r_coarse 30 graph > gpurun_out/r_sum_coarse.txt
 python3 scripts/trace_summary.py gpurun_out/r_320 20 graph > gpurun_out/r_sum_320.txt
 tail -1 gpurun_out/r_bench.json | cut -c1-400
 # SQ counters of the MLP kernels (one --pmc pass; durations from an un-profiled trace of the same command)
