@@ -81,11 +81,9 @@ struct RcArgs {
   int n_layers, total_chunks;
   unsigned long long *stamps;              // diagnostics (fgs_mlp_rc_debug_stamps): per workgroup {s_memtime, s_memrealtime} x 2
   const float *img;
-  int chunk_piece0[RC_MAXCH];              // first 1 KB piece of chunk j in the image
-  int chunk_pieces[RC_MAXCH];              // 1 KB pieces of chunk j (= rows_pad / 8).  (int, not a byte array: hipcc (ROCm 7.2)
-                                           // folded the byte index of a uint8 table into the SGPR BASE of the neighbouring
-                                           // s_load_dword -- base = kernarg + j, soffset = 3 j -- and the scalar unit drops
-                                           // the base's two low bits before adding: chunk_piece0[1] read back chunk_piece0[0])
+  // (chunk j of the stream starts at 1 KB piece j * 4 NTT of the image and has 4 NTT pieces: every layer of a launch has the
+  // same padded row count, so no per-chunk table is needed -- a table lookup per chunk was two scalar loads and an exposed
+  // s_waitcnt in front of every DMA issue)
   RcLayer L[RC_MAXL];
 };
 
@@ -135,7 +133,7 @@ struct RcState {
   const RcArgs *a;
   float *ring;
   int64_t issued, done, total_steps;
-  int issue_j, issue_slot, slot;
+  int issue_j, issue_slot, slot, total_chunks;
   int wave, lane;
   // the chunk whose DMA is being issued piece by piece between the MFMAs of the running chunk
   const float *dma_src;
@@ -150,14 +148,15 @@ struct RcState {
 };
 
 // start the DMA of the next chunk of the stream (nothing is issued yet: rc_dma_piece does that)
+template <int NTT>
 __device__ __forceinline__ void rc_dma_begin(RcState &s) {
   const RcArgs &a = *s.a;
-  s.dma_pieces = a.chunk_pieces[s.issue_j];
-  s.dma_src = a.img + (int64_t)a.chunk_piece0[s.issue_j] * 256 + s.lane * 4;
+  s.dma_pieces = 4 * NTT;
+  s.dma_src = a.img + (int64_t)s.issue_j * (4 * NTT * 256) + s.lane * 4;
   s.dma_dst = s.ring + s.issue_slot * RC_SLOT_FLOATS;
   s.dma_p = s.wave;
   ++s.issued;
-  s.issue_j = (s.issue_j + 1 == a.total_chunks) ? 0 : s.issue_j + 1;
+  s.issue_j = (s.issue_j + 1 == s.total_chunks) ? 0 : s.issue_j + 1;
   s.issue_slot = (s.issue_slot + 1 == RC_SLOTS) ? 0 : s.issue_slot + 1;
 }
 
@@ -174,8 +173,9 @@ __device__ __forceinline__ void rc_dma_piece(RcState &s) {
   s.dma_p += 4;
 }
 
+template <int NTT>
 __device__ __forceinline__ void rc_dma(RcState &s) {     // a whole chunk at once (prologue)
-  rc_dma_begin(s);
+  rc_dma_begin<NTT>(s);
   while (s.dma_p < s.dma_pieces) rc_dma_piece(s);
 }
 
@@ -252,7 +252,7 @@ __device__ __forceinline__ void rc_chunk(RcState &s, const float *__restrict__ S
     if (i == STEPS / 2 - 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (s.issued < s.total_steps) rc_dma_begin(s);
+      if (s.issued < s.total_steps) rc_dma_begin<NTT>(s);
       else s.dma_pieces = 0;                      // end of the stream: the issue slots only touch the dump area
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -281,10 +281,12 @@ __device__ __forceinline__ void rc_load_ext(const RcLayer &L, int c, int64_t row
 // dead once chunk 0 has run, tile 1 after chunk 1, so the appended columns are loaded into THOSE registers right there --
 // seven chunks (~25 us) before chunks 8 and 9 multiply by them.
 template <int NTT, bool BWD, int C>
-__device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
-                                          floatx16 (&acc)[NTT], floatx4 (&A)[3], int64_t rowc, int h) {
+__device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, int nch, bool has_ext, const int (&rdoff)[4],
+                                          floatx16 (&prev)[8], floatx16 (&acc)[NTT], floatx4 (&A)[3], int64_t rowc, int h) {
+  // (nch / has_ext are read once per layer by the caller: behind the `memory` clobbers of the hand-issued instructions the
+  // compiler re-read L.nch and L.ext from the kernel-argument segment at every chunk -- a scalar load and an exposed wait each)
   if constexpr (C < 10) {
-    if (C < L.nch) {
+    if (C < nch) {
       const float *S = s.ring + s.slot * RC_SLOT_FLOATS;
       s.slot = (s.slot + 1 == RC_SLOTS) ? 0 : s.slot + 1;
       ++s.done;
@@ -294,9 +296,9 @@ __device__ __forceinline__ void rc_chunks(RcState &s, const RcLayer &L, const in
       // chunk C < 8 multiplies by input tile C = output tile C of the previous layer: its HBM copy goes out from here
       rc_chunk<NTT, PH, NS, (C < 8 ? C : -1)>(s, S, S_next, rdoff, prev[C < 8 ? C : C - 8], acc, A, h);
       if constexpr (!BWD && C < 2) {
-        if (L.ext) rc_load_ext(L, C, rowc, h, prev[C]);
+        if (has_ext) rc_load_ext(L, C, rowc, h, prev[C]);
       }
-      rc_chunks<NTT, BWD, C + 1>(s, L, rdoff, prev, acc, A, rowc, h);
+      rc_chunks<NTT, BWD, C + 1>(s, L, nch, has_ext, rdoff, prev, acc, A, rowc, h);
     }
   }
 }
@@ -314,7 +316,9 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
   uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
   if (BWD && L.mask_r) mbits = L.mask_r[group * 64 + s.lane];
   if (s.timed) t1 = __builtin_amdgcn_s_memtime();
-  rc_chunks<NTT, BWD, 0>(s, L, rdoff, prev, acc, A, rowc, h);
+  const int nch = __builtin_amdgcn_readfirstlane(L.nch);
+  const bool has_ext = L.ext != nullptr;
+  rc_chunks<NTT, BWD, 0>(s, L, nch, has_ext, rdoff, prev, acc, A, rowc, h);
   if (s.timed) t2 = __builtin_amdgcn_s_memtime();
   {   // the two operands prefetched for the next layer's first steps sit at rotation index (nch * 4 NTT) % 3: make that 0
     const int ph = (L.nch * 4 * NTT) % 3;
@@ -384,12 +388,12 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   }
   RcState s;
   s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = my_blocks * a.total_chunks;
-  s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane; s.done = 0;
+  s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane; s.done = 0; s.total_chunks = a.total_chunks;
   s.dma_p = 0; s.dma_pieces = 0; s.dma_src = a.img + lane * 4; s.dma_dst = ring;
   s.pend_row = nullptr; s.pend_nstore = 0;
   s.timed = a.stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
-  rc_dma(s);
-  if (s.total_steps > 1) rc_dma(s);
+  rc_dma<NTT>(s);
+  if (s.total_steps > 1) rc_dma<NTT>(s);
   {   // bias table -> LDS, once (a layer's epilogue then reads 16 bytes per output group instead of waiting on HBM)
     float *bt = ring + RC_SLOTS * RC_SLOT_FLOATS + 4 * 256;
     for (int i = tid; i < (RC_MAXL + 1) * 256; i += RC_THREADS) {
@@ -541,11 +545,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     PackLayer &P = p.L[l];
     P.W = U.W; P.ldw = U.ldw; P.n_out = U.n_out; P.n_in = U.n_in; P.rows_pad = L.nt * 32; P.nch = L.nch; P.base = base;
     P.f4_begin = f4;
-    for (int c = 0; c < L.nch; ++c) {
-      a.chunk_piece0[chunk] = (int)((base + (int64_t)c * P.rows_pad * 32) / 256);
-      a.chunk_pieces[chunk] = P.rows_pad / 8;
-      ++chunk;
-    }
+    chunk += L.nch;
     base += (int64_t)P.rows_pad * 32 * L.nch;
     f4 += (int64_t)P.rows_pad * 8 * L.nch;
     carried = rows < 256 ? rows : 256;      // what the next layer finds in the registers
