@@ -54,15 +54,22 @@ def train_step(model, opt, averager, batch, n_rays_global):
     loss = fused_render_losses(res, target, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model)
     pts = res.get('survivor_pts') if hasattr(res, 'get') else None
     if pts is not None:   # every k0 gradient of this step comes from trilinear lookups at the survivors
-        averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
+        count_ptr = res.get('survivor_count_ptr')
+        if count_ptr is None:
+            averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
+        else:             # sync-free: `pts` has CAPACITY rows, the rows that count are behind a device-side counter
+            from fgs_nerf_amd.fused import _DeviceScalars
+            with _DeviceScalars(count=count_ptr):
+                averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     averager.average()
     # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)
     model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)
     opt.step()
-    STEP_STATS["survivors"] += int(res['weights'].shape[0])     # a host number already (the forward read it)
-    STEP_STATS["max_survivors"] = max(STEP_STATS.get("max_survivors", 0), int(res['weights'].shape[0]))
+    if res.get('survivor_count_ptr') is None if hasattr(res, 'get') else True:
+        STEP_STATS["survivors"] += int(res['weights'].shape[0])     # a host number already (the forward read it)
+        STEP_STATS["max_survivors"] = max(STEP_STATS.get("max_survivors", 0), int(res['weights'].shape[0]))
     return loss
 
 
@@ -218,7 +225,7 @@ def main():
     ap.add_argument("--composed", action="store_true", help="operator-at-a-time HIP path instead of the fused kernels")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine = the headline workload (configs[1]); coarse = configs[2]'s forward_coarse step at the same size")
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+    ap.add_argument("--mode", choices=["graph", "eager", "eager-sync"], default="graph",
                     help="graph (default, 1 GPU, fused path): the whole step is one hipGraph replay, nothing of it reaches "
                          "the host; eager: Python enqueues every launch and reads the survivor count back once per step")
     ap.add_argument("--grid", type=int, default=GRID,
@@ -234,6 +241,13 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if os.environ.get("FGS_BENCH_DRY"):
         sys.exit(dry_rank(args))
+
+    # stdout carries ONE JSON line.  Libraries write there too (RCCL prints its version banner and warnings with printf at
+    # communicator creation, whatever NCCL_DEBUG_FILE says): from here on file descriptor 1 points at stderr, and the line
+    # is written to the saved original descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     pmc = None
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.pmc_child or args.no_pmc or args.composed)
@@ -311,6 +325,21 @@ def main():
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
     torch.cuda.synchronize()
+    # Eager runs (several GPUs, --mode eager on request): the same launches, but with the survivor count left on the device
+    # (fused.set_sync_free: fixed-capacity buffers, kernels clamp to the device-side count), so that the host never waits
+    # for the GPU inside a step and its ~2 ms of Python per step overlap the previous step's kernels.  --mode eager-sync
+    # keeps the reference-shaped form (result tensors sized by a survivor count read back once per step).
+    sync_free_eager = (not use_graph and not args.composed and args.mode != "eager-sync"
+                       and os.environ.get("FGS_MLP", "rc") == "rc")
+    if sync_free_eager:
+        from fgs_nerf_amd import fused as _fused
+        seen = max(STEP_STATS["max_survivors"], 16384)
+        _fused.set_sync_free(model, (int(1.5 * seen) + 4095) // 4096 * 4096)
+        for i in range(2):                       # allocator warm-up of the capacity-sized buffers
+            train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+        torch.cuda.synchronize()
+        st_ = model._fused_cache['sync_free_buffers']
+        st_['flags'].zero_(); st_['total'].zero_()
     captured = None
     if use_graph:
         from fgs_nerf_amd.graph_step import CapturedFineStep
@@ -359,6 +388,12 @@ def main():
         gc.enable()
     fused.set_profiling(False)
     roofline_note = "HIP events on the launch stream immediately around every MLP matrix-core launch in the timed region"
+    if sync_free_eager:
+        from fgs_nerf_amd import fused as _fused
+        overflow, total = _fused.sync_free_state(model)
+        if overflow:
+            raise SystemExit("survivor capacity overflowed during the timed region: rerun with --mode eager-sync")
+        STEP_STATS["survivors"] = total
     if captured is not None:
         overflow, total = captured.check()
         if overflow:
@@ -401,8 +436,15 @@ def main():
                        "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
         }
         line["config"]["step_mode"] = ("one hipGraph replay per step, no device->host read" if captured is not None
+                                       else "eager launches, no device->host read (device-side survivor count)" if sync_free_eager
                                        else "eager launches, one survivor-count read per step")
-        line["roofline"] = fused.roofline_report(pmc)
+        # (sync-free eager launches are issued for the buffers' CAPACITY; their algorithmic work is the rows behind the
+        # device-side count: scale the FLOP the launch sites booked by rows processed / rows launched)
+        flop_scale = 1.0
+        if sync_free_eager:
+            cap_rows = model._fused_cache['sync_free']['capacity'] * max(args.steps, 1)
+            flop_scale = STEP_STATS["survivors"] / max(cap_rows, 1)
+        line["roofline"] = fused.roofline_report(pmc, flop_scale)
         if line["roofline"] is not None:
             line["roofline"]["timing"] = roofline_note
         if line["roofline"] is not None and args.stage == "fine":
@@ -420,7 +462,8 @@ def main():
                 "note": "algorithmic bytes / step time / 8 TB/s; the step is bound by fp32 matrix throughput and atomics"}
         # (the CPU baseline is timed at N = 1 only: the other ranks of a multi-GPU run would sit in the final barrier meanwhile)
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine" or world > 1) else cpu_baseline()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

@@ -1438,7 +1438,7 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks, 'viewdirs': lambda: run.viewdirs[ray_id]})
 
 
-def roofline_report(pmc=None):
+def roofline_report(pmc=None, flop_scale: float = 1.0):
     """Achieved fp32 FLOP/s of the dominant kernels -- the MLP matrix-core kernels: k_mlp_rc (register-resident forward chain
     and backward data-gradient chain, one launch each), k_mlp_wgrad (all weight / bias gradients, one launch), k_gemm (the two
     first-layer data gradients) -- from the HIP events recorded around every uninterrupted run of them, against the gfx950
@@ -1451,6 +1451,7 @@ def roofline_report(pmc=None):
     per = {}
     tot_ms, tot_fl, tot_n = 0.0, 0.0, 0
     for e0, e1, e1s, label, n, fl in ev:
+        fl = fl * flop_scale
         ms = e0.elapsed_time(e1)
         if e1s is not None:
             ms = max(ms, e0.elapsed_time(e1s))
