@@ -391,9 +391,12 @@ def main():
     if sync_free_eager:
         from fgs_nerf_amd import fused as _fused
         overflow, total = _fused.sync_free_state(model)
-        if overflow:
+        if overflow and world == 1:
             raise SystemExit("survivor capacity overflowed during the timed region: rerun with --mode eager-sync")
+        if overflow:          # (several ranks: leaving here would strand the others in the collectives below; flag the line)
+            print(f"[bench] rank {rank}: survivor capacity overflowed during the timed region", file=sys.stderr, flush=True)
         STEP_STATS["survivors"] = total
+        STEP_STATS["overflow"] = bool(overflow)
     if captured is not None:
         overflow, total = captured.check()
         if overflow:
@@ -435,6 +438,8 @@ def main():
                        "mlp_survivors_per_step_per_gpu": int(STEP_STATS["survivors"] / max(args.steps, 1)),
                        "path": "composed" if args.composed else "fused", "parallelism": f"dp{world} rays"},
         }
+        if STEP_STATS.get("overflow"):
+            line["config"]["capacity_overflow_on_rank0"] = True
         line["config"]["step_mode"] = ("one hipGraph replay per step, no device->host read" if captured is not None
                                        else "eager launches, no device->host read (device-side survivor count)" if sync_free_eager
                                        else "eager launches, one survivor-count read per step")
