@@ -278,3 +278,49 @@ def test_rank_asymmetric_steps_keep_the_collectives_matched(dev, mode):
     else:
         assert all(r[3] == 0 for r in results), results            # the hint never armed anything on the small grid
         assert results[0][2] != results[1][2]                      # different survivor histories on the two ranks
+
+
+def test_sync_free_eager_steps_with_the_exchange_match_plain_steps(dev):
+    """What `bench.py` runs on several GPUs: eager launches with the survivor count left on the device (fused.set_sync_free)
+    and the in-backward gradient exchange (a real RCCL group of one) -- against the same steps with host-sized tensors.
+    Same survivor totals, parameters equal in norm; the hinted brick occupancy is computed under the device-side count."""
+    import bench
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.dist import GradAverager
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        N, STEPS = 1024, 4
+        batches = []
+        for b in range(2):
+            ro, rd, vd = synth.random_rays(N, seed=40 + b)
+            batches.append(tuple(t.to(dev).contiguous() for t in (ro, rd, vd, torch.rand(N, 3, generator=torch.Generator().manual_seed(b)))))
+        outs = {}
+        for mode in ("plain", "sync_free"):
+            model = synth.build_model(64, synth.FINE_MODEL, device=dev)
+            opt = bench.make_optimizer(model)
+            avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16)
+            avg.attach(model)
+            avg.attach_optimizer(opt)
+            bench.STEP_STATS.update(survivors=0, max_survivors=0)
+            if mode == "sync_free":
+                fused.set_sync_free(model, 32768)
+            for i in range(STEPS):
+                bench.train_step(model, opt, avg, batches[i % 2], N)
+            torch.cuda.synchronize()
+            if mode == "sync_free":
+                overflow, total = fused.sync_free_state(model)
+                assert not overflow
+                fused.set_sync_free(model, None)
+            else:
+                total = bench.STEP_STATS["survivors"]
+            assert avg.last_sparse_fill is not None and 0 < avg.last_sparse_fill < 0.6      # the sparse exchange ran
+            outs[mode] = (total, [p.detach().clone() for p in model.parameters()])
+        assert outs["plain"][0] == outs["sync_free"][0] > 0
+        for pa, pb in zip(outs["plain"][1], outs["sync_free"][1]):
+            assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 3e-3
+    finally:
+        dist.destroy_process_group()
