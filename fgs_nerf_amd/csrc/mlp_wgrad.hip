@@ -45,7 +45,7 @@ struct WgBlock {
   float *dbias;          // null unless this is column block 0 of a layer with a bias gradient
   int64_t ld_dy, ld_x, ld_dw;
   int n_out, n_in;       // valid rows / columns of dW
-  int col0, mode;        // first column of the block; wave arrangement (0 = A, 1 = B, 2 = C)
+  int col0, cols, mode;  // first column and width of the block; wave arrangement (WgMode)
   int wg0, n_wg;         // workgroups [wg0, wg0 + n_wg) split the samples of this block
 };
 
@@ -62,10 +62,22 @@ constexpr int WG_NS = 4;                          // ring slots
 constexpr int WG_PA = WG_ROWS * 256;              // floats of the A panel
 constexpr int WG_LDS_FLOATS = WG_NS * 2 * WG_PA + 4 * 256;     // mode A slots (the largest) + 1 KB dump area per wave
 
+// Wave arrangements: RT x CT MFMA tiles per wave, KS = how many waves share a tile position and split a chunk's k-steps,
+// PWB = floats per row of the compact B panel.  Waves = (4 / KS) positions x KS; positions are NWR row parts x NWC column
+// parts (NWC = 2 only for KS = 1).  Rows covered = NWR * RT * 32, columns = NWC * CT * 32.
+//   n_out <= 256:  0: 2x2 pos, 4x4 tiles (cols <= 256)   1: 2x1 pos x 2 k, 4x4 (cols <= 128)   2: 1 pos x 4 k, 8x2 (cols <= 64)
+//   n_out <= 192:  3: 2x2 pos, 3x3 tiles (cols <= 192)   4: 2x1 pos x 2 k, 3x4 (cols <= 128)   5: 1 pos x 4 k, 6x2 (cols <= 64)
+//   n_out <= 128:  6: 1 pos x 4 k, 4x4 tiles (cols <= 128)
+// (the coarse stages' 192- and 128-wide layers ran as mode 0 / 1 before: 56 % / 25 % of their MFMAs on rows and columns
+// that exist)
 template <int MODE> struct WgMode;
 template <> struct WgMode<0> { static constexpr int RT = 4, CT = 4, KS = 1, PWB = 256; };
 template <> struct WgMode<1> { static constexpr int RT = 4, CT = 4, KS = 2, PWB = 128; };
 template <> struct WgMode<2> { static constexpr int RT = 8, CT = 2, KS = 4, PWB = 64; };
+template <> struct WgMode<3> { static constexpr int RT = 3, CT = 3, KS = 1, PWB = 192; };
+template <> struct WgMode<4> { static constexpr int RT = 3, CT = 4, KS = 2, PWB = 128; };
+template <> struct WgMode<5> { static constexpr int RT = 6, CT = 2, KS = 4, PWB = 64; };
+template <> struct WgMode<6> { static constexpr int RT = 4, CT = 4, KS = 4, PWB = 128; };
 
 // The chunk whose panels are being fetched: uniform base pointers + per-lane byte offsets, clamped per lane to the tensor's
 // last 16 bytes (lanes of a row that straddles the end re-read the last float4 into places nobody uses or that get zeroed).
@@ -76,10 +88,11 @@ struct WgDma {
 };
 
 template <int MODE, int I>
-__device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsigned vb0, unsigned step_a, unsigned step_b,
-                                             int wave, float *dump) {
+__device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsigned col0_4, unsigned step_a, unsigned ld_b4,
+                                             int wave, int lane, float *dump) {
   using Md = WgMode<MODE>;
-  constexpr int NB = Md::PWB / 64;            // B pieces per wave (A: 4 -- one sample row of 256 floats each)
+  constexpr int PWB = Md::PWB;
+  constexpr int NB = PWB / 64;                // B pieces per wave (A: 4 -- one sample row of 256 floats each)
   static_assert(I < 4 + NB, "piece index");
   const char *src;
   float *dst;
@@ -89,7 +102,11 @@ __device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsig
     src = d.base_a + off;
     dst = d.dst + (wave + 4 * I) * 256;
   } else {
-    unsigned off = vb0 + (I - 4) * step_b;
+    // B piece p = wave + 4 (I - 4): floats [256 p, 256 p + 256) of the compact [16][PWB] panel; this lane's float4 starts at
+    // flat index f -> panel row f / PWB, panel column f % PWB (PWB is a compile-time constant: a multiply and a shift)
+    const unsigned f = (unsigned)(wave + 4 * (I - 4)) * 256u + (unsigned)lane * 4u;
+    const unsigned r = f / (unsigned)PWB, c = f - r * (unsigned)PWB;
+    unsigned off = r * ld_b4 + col0_4 + c * 4u;
     off = off < d.lim_b ? off : d.lim_b;
     src = d.base_b + off;
     dst = d.dst + WG_PA + (wave + 4 * (I - 4)) * 256;
@@ -101,15 +118,15 @@ __device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsig
 
 template <int MODE, int I, int N>
 struct WgPieces {       // pieces [I, N) of the pending chunk, back to back (prologue)
-  static __device__ __forceinline__ void run(const WgDma &d, unsigned va0, unsigned vb0, unsigned sa, unsigned sb, int wave,
-                                             float *dump) {
-    wg_dma_piece<MODE, I>(d, va0, vb0, sa, sb, wave, dump);
-    WgPieces<MODE, I + 1, N>::run(d, va0, vb0, sa, sb, wave, dump);
+  static __device__ __forceinline__ void run(const WgDma &d, unsigned va0, unsigned col0_4, unsigned sa, unsigned ldb4, int wave,
+                                             int lane, float *dump) {
+    wg_dma_piece<MODE, I>(d, va0, col0_4, sa, ldb4, wave, lane, dump);
+    WgPieces<MODE, I + 1, N>::run(d, va0, col0_4, sa, ldb4, wave, lane, dump);
   }
 };
 template <int MODE, int N>
 struct WgPieces<MODE, N, N> {
-  static __device__ __forceinline__ void run(const WgDma &, unsigned, unsigned, unsigned, unsigned, int, float *) {}
+  static __device__ __forceinline__ void run(const WgDma &, unsigned, unsigned, unsigned, unsigned, int, int, float *) {}
 };
 
 template <int MODE>
@@ -125,9 +142,9 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   // position of the wave: row half wr, column half wc, k-step residue kg
-  const int wr = MODE == 0 ? wave >> 1 : MODE == 1 ? (wave & 1) : 0;
-  const int wc = MODE == 0 ? (wave & 1) : 0;
-  const int kg = MODE == 0 ? 0 : MODE == 1 ? wave >> 1 : wave;
+  constexpr int NWC = KS == 1 ? 2 : 1, NPOS = 4 / KS, NM = RT * CT;      // column parts, tile positions, MFMAs per k-step
+  const int pos = wave % NPOS, kg = wave / NPOS;
+  const int wr = pos / NWC, wc = pos % NWC;
   const int row_base = wr * RT * 32, colp_base = wc * CT * 32;     // first row of the wave / first panel column
   // chunk range of this workgroup
   const int64_t NC = (M + WG_ROWS - 1) / WG_ROWS;
@@ -137,12 +154,11 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
   // ---- DMA: per-lane source offsets inside a chunk (bytes)
-  //   A piece i: sample row wave + 4 i, 256 floats from its start:                      lane * 16
-  //   B piece i: sample rows (wave + 4 i) * rpp ..+rpp, PWB floats from column col0:    rpp = 256 / PWB rows per 1 KB piece
-  constexpr int RPP = 256 / PWB, LPR = PWB / 4;      // rows per B piece, lanes per row
+  //   A piece i: sample row wave + 4 i, 256 floats from its start:   lane * 16
+  //   B piece i: 256 consecutive floats of the compact [16][PWB] panel (wg_dma_piece works out row and column per lane)
   const unsigned va0 = wave * ld_a4 + lane * 16;
-  const unsigned vb0 = (wave * RPP + lane / LPR) * ld_b4 + (b.col0 + (lane % LPR) * 4) * 4;
-  const unsigned step_a = 4 * ld_a4, step_b = 4 * RPP * ld_b4;
+  const unsigned col0_4 = (unsigned)b.col0 * 4u;
+  const unsigned step_a = 4 * ld_a4;
   const int64_t bytes_a = M * (int64_t)ld_a4, bytes_b = M * (int64_t)ld_b4;
   WgDma d;
   int64_t issue_c = c0;
@@ -188,7 +204,7 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
 #pragma unroll
   for (int k = 0; k < WG_NS - 1; ++k) {
     dma_begin();
-    WgPieces<MODE, 0, NP>::run(d, va0, vb0, step_a, step_b, wave, dump);
+    WgPieces<MODE, 0, NP>::run(d, va0, col0_4, step_a, ld_b4, wave, lane, dump);
   }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   __builtin_amdgcn_s_barrier();
@@ -227,17 +243,17 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
           if (i < RT) fa[nxt][i] = Sn[offA + 32 * i];
           else if (i < RT + CT) fb[nxt][i - RT] = SnB[offB + 32 * (i - RT)];
           if (tb == CT - 1) bsum[ta] += fa[cur][ta];
-          if (sl >= KPC / 2 && i >= 16 - PPK) {     // second half of the chunk: the pieces of the chunk three ahead
-            const int piece = (sl - KPC / 2) * PPK + (i - (16 - PPK));
+          if (sl >= KPC / 2 && i >= NM - PPK) {     // second half of the chunk: the pieces of the chunk three ahead
+            const int piece = (sl - KPC / 2) * PPK + (i - (NM - PPK));
             switch (piece) {      // (compile-time after unrolling)
-              case 0: wg_dma_piece<MODE, 0>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 1: wg_dma_piece<MODE, 1>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 2: wg_dma_piece<MODE, 2>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 3: wg_dma_piece<MODE, 3>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 4: wg_dma_piece<MODE, 4>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 5: if (NP > 5) wg_dma_piece<MODE, (NP > 5 ? 5 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 6: if (NP > 6) wg_dma_piece<MODE, (NP > 6 ? 6 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
-              case 7: if (NP > 7) wg_dma_piece<MODE, (NP > 7 ? 7 : 0)>(d, va0, vb0, step_a, step_b, wave, dump); break;
+              case 0: wg_dma_piece<MODE, 0>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 1: wg_dma_piece<MODE, 1>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 2: wg_dma_piece<MODE, 2>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 3: wg_dma_piece<MODE, 3>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 4: wg_dma_piece<MODE, 4>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 5: if (NP > 5) wg_dma_piece<MODE, (NP > 5 ? 5 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 6: if (NP > 6) wg_dma_piece<MODE, (NP > 6 ? 6 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 7: if (NP > 7) wg_dma_piece<MODE, (NP > 7 ? 7 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
               default: break;
             }
           }
@@ -292,6 +308,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
     stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)blk;
   }
   switch (b.mode) {
+    case 6: wgrad_block<6>(b, M, j, lds, stamps); break;
+    case 5: wgrad_block<5>(b, M, j, lds, stamps); break;
+    case 4: wgrad_block<4>(b, M, j, lds, stamps); break;
+    case 3: wgrad_block<3>(b, M, j, lds, stamps); break;
     case 2: wgrad_block<2>(b, M, j, lds, stamps); break;
     case 1: wgrad_block<1>(b, M, j, lds, stamps); break;
     default: wgrad_block<0>(b, M, j, lds, stamps); break;
@@ -306,7 +326,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_wgrad_small(WgArgs a) {
   const int64_t M = fgs_rows(a.M, a.m_dev);
   const WgBlock &b = a.B[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cols = b.n_in - b.col0 < 256 ? b.n_in - b.col0 : 256;
+  const int cols = b.cols;
   if (i >= b.n_out * cols) return;
   const int n = i / cols, k = b.col0 + i % cols;
   float s = 0.f, sb = 0.f;
@@ -350,16 +370,25 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
                     U.ld_dw >= U.n_in && U.ld_dy <= 320 && U.ld_x <= 320 && (U.ld_dy % 4) == 0 && (U.ld_x % 4) == 0,
                 FGS_E_INVALID, "fgs_mlp_wgrad: item %d: bad pointer or shape (n_out <= 256, n_in <= 320, leading dimensions "
                                "of dY / X multiples of 4 and <= 320, 16-byte aligned)", i);
-    for (int col0 = 0; col0 < U.n_in; col0 += 256) {
+    // column blocks: 256 wide for layers of more than 192 rows, 192 wide for the others (their waves hold 3 x 3 tiles)
+    const int blk_cols = U.n_out > 192 ? 256 : (U.n_out > 128 ? 192 : 128);
+    for (int col0 = 0; col0 < U.n_in; col0 += blk_cols) {
       FGS_REQUIRE(nb < WG_MAXBLK, FGS_E_RANGE, "fgs_mlp_wgrad: more than %d column blocks", WG_MAXBLK);
-      const int cols = U.n_in - col0 < 256 ? U.n_in - col0 : 256;
-      const int tiles = (cols + 31) / 32;                   // column tiles of the block
+      const int cols = U.n_in - col0 < blk_cols ? U.n_in - col0 : blk_cols;
       WgBlock &b = a.B[nb];
       b.dY = U.dY; b.X = U.X; b.dW = U.dW; b.dbias = col0 == 0 ? U.dbias : nullptr;
-      b.ld_dy = U.ld_dy; b.ld_x = U.ld_x; b.ld_dw = U.ld_dw; b.n_out = U.n_out; b.n_in = U.n_in; b.col0 = col0;
-      b.mode = tiles <= 2 ? 2 : tiles <= 4 ? 1 : 0;
-      // time per chunk of 16 samples: 8 / 4 / 2 k-steps of 16 MFMAs per wave, plus the chunk's fixed work (barrier, DMA issue)
-      cost[nb] = b.mode == 0 ? 33 : b.mode == 1 ? 18 : 10;
+      b.ld_dy = U.ld_dy; b.ld_x = U.ld_x; b.ld_dw = U.ld_dw; b.n_out = U.n_out; b.n_in = U.n_in; b.col0 = col0; b.cols = cols;
+      // cost = time per chunk of 16 samples: k-steps of the wave x MFMAs per k-step x 64 cycles + the chunk's fixed work
+      if (U.n_out > 192) {
+        b.mode = cols <= 64 ? 2 : cols <= 128 ? 1 : 0;
+        cost[nb] = b.mode == 0 ? 33 : b.mode == 1 ? 18 : 10;
+      } else if (U.n_out > 128) {
+        b.mode = cols <= 64 ? 5 : cols <= 128 ? 4 : 3;
+        cost[nb] = b.mode == 3 ? 20 : b.mode == 4 ? 14 : 8;
+      } else {
+        b.mode = 6;
+        cost[nb] = 10;
+      }
       cost_total += cost[nb];
       ++nb;
     }

@@ -184,6 +184,17 @@ def test_wgrad_all_layers_one_launch_matches_fp64(dev, M):
     fo.mlp_wgrad(M, [(d0, X0, g0, None, W, 90), (d1, X1, g1, b1, W, W)])
     assert rel_l2(g0[:, :90], 1.0 + d0.double().T @ X0[:, :90].double()) < 2e-6
     assert rel_l2(g1, d1.double().T @ X1.double()) < 2e-6 and rel_l2(b1, d1.double().sum(0)) < 2e-6
+    # every wave arrangement of the narrow layers: n_out 192 with 307 columns (blocks of 192 + 115), n_out 128 with 200
+    # columns (128 + 72) and with 39 columns (geometry_searching's first layer), n_out 160 with 64 columns, n_out 100
+    for n_out, n_in in [(192, 307), (128, 200), (128, 39), (160, 64), (100, 128)]:
+        ld = (n_in + 3) // 4 * 4
+        X = torch.randn(M, ld, generator=g).to(dev)
+        dY = torch.randn(M, n_out, generator=g).to(dev)
+        dW, db = torch.zeros(n_out, ld, device=dev), torch.zeros(n_out, device=dev)
+        fo.mlp_wgrad(M, [(dY, X, dW, db, n_out, n_in)])
+        assert rel_l2(dW[:, :n_in], dY.double().T @ X[:, :n_in].double()) < 2e-6, (n_out, n_in)
+        assert float(dW[:, n_in:].abs().max()) == 0.0 if n_in < ld else True
+        assert rel_l2(db, dY.double().sum(0)) < 2e-6, (n_out, n_in)
 
 
 def test_pad_cols_multi_matches_torch_pad(dev):
