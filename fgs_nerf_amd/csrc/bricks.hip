@@ -224,6 +224,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_bricks(float *__restrict__ p
                                                            int *__restrict__ flags, float step_size,
                                                            const float *__restrict__ ss_dev, float beta1, float beta2,
                                                            float eps, const int *__restrict__ skip) {
+  __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
+                                     // the vector pipe: this memory-bound kernel's few vector instructions go first
   const int64_t total = (int64_t)g.nbx * g.nby * g.nbz;
   const int64_t n = idx ? (count_dev ? min(*count_dev, total) : n_host) : total;
   const bool no_update = skip && *skip;           // an overflowed step: consume (zero) the gradient, change nothing else
@@ -295,6 +297,8 @@ namespace {
 __global__ __launch_bounds__(FGS_BLOCK) void k_brick_masks_pts(const float *__restrict__ pts, int64_t M,
                                                                const int64_t *__restrict__ m_dev, SceneGeom sg, BrickGrid g,
                                                                unsigned char *__restrict__ vox) {
+  __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
+                                     // the vector pipe: this memory-bound kernel's few vector instructions go first
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= fgs_rows(M, m_dev)) return;
   const GridDesc d = fgs_sdf_desc(sg);
@@ -318,6 +322,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_voxels(float *__restrict__ p
                                                            BrickGrid g, unsigned char *__restrict__ vox,
                                                            float step_size, const float *__restrict__ ss_dev, float beta1,
                                                            float beta2, float eps, const int *__restrict__ skip) {
+  __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
+                                     // the vector pipe: this memory-bound kernel's few vector instructions go first
   const int64_t total = (int64_t)g.nbx * g.nby * g.nbz;
   const bool no_update = skip && *skip;
   if (ss_dev) step_size = *ss_dev;

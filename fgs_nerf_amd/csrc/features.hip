@@ -55,6 +55,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const flo
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__restrict__ k0_grad, GridDesc kd,
                                                            const float *__restrict__ dX0) {
+  __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
+                                     // the vector pipe: this memory-bound kernel's few vector instructions go first
   S.M = fgs_rows(S.M, S.m_dev);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
@@ -348,40 +350,32 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X
   }
 }
 
-// 32 lanes per survivor: gradients reaching sdf and the raw gradient vector through the feature columns, the normal
-// (orientation loss, reflection) and the reflection encoding.  The 3 F_ref (sin, cos) column pairs are dealt to the lanes
-// and summed with shuffles; the short tail is computed by every lane and written by lane 0.
+// One thread per survivor: gradients reaching sdf and the raw gradient vector through the feature columns, the normal
+// (orientation loss, reflection) and the reflection encoding.  (The first form dealt the 3 F_ref (sin, cos) column pairs to 32
+// lanes per survivor, summed them with shuffles and left the divisions and square roots of the tail to lane 0: 2 of 64 lanes
+// busy through ~400 instructions, VALU-bound at 27 us -- and the fp32 matrix instructions of k_mlp_wgrad, which this kernel
+// runs beside, execute on the same vector pipe.)  A thread reads its row's 6 F_ref + 3 columns of Z and dZ itself: four cache
+// lines per survivor.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const float *__restrict__ Z,
                                                             const float *__restrict__ dX0, const float *__restrict__ dZ,
                                                             const float *__restrict__ g_normal, float *__restrict__ g_sdf,
                                                             float *__restrict__ g_gradient) {
+  __builtin_amdgcn_s_setprio(2);             // beside the matrix kernel: first pick of the shared vector pipe (a few us)
   S.M = fgs_rows(S.M, S.m_dev);
-  const int64_t m_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  const int j = threadIdx.x & 31;
-  const bool live = m_raw < S.M;
-  const int64_t m = live ? m_raw : 0;        // every lane takes part in the shuffles
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= S.M) return;
   const FeatLayout &L = S.L;
   const int F = L.n_reffreq;
   const float *z = Z + m * L.ldz + L.off_ref;
   const float *dz = dZ + m * L.ldz + L.off_ref;
   // d reflect_c = dE[c] + sum_f 2^f (cos * dE_sin - sin * dE_cos)
   float part[3] = {0.f, 0.f, 0.f};
-  if (live)
-    for (int p = j; p < 3 * F; p += 32) {
-      const int c = p / F, f = p - c * F;
-      const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
-      const float t = (float)(1 << f) * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
-      part[0] += (c == 0) ? t : 0.f;
-      part[1] += (c == 1) ? t : 0.f;
-      part[2] += (c == 2) ? t : 0.f;
-    }
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    part[0] += __shfl_xor(part[0], off, 32);
-    part[1] += __shfl_xor(part[1], off, 32);
-    part[2] += __shfl_xor(part[2], off, 32);
-  }
-  if (!live || j != 0) return;
+  for (int c = 0; c < 3; ++c)
+    for (int f = 0; f < F; ++f) {
+      const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
+      part[c] += (float)(1 << f) * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
+    }
   const float dr[3] = {dz[0] + part[0], dz[1] + part[1], dz[2] + part[2]};
   const int64_t r = S.ray_id[m];
   const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
@@ -772,7 +766,7 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
                      (float *)nullptr, g_gradient);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/enc");
   return 0;
@@ -823,7 +817,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
+  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
                      g_gradient);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/enc");
   (void)sdf_grad_grid;  // the sdf.grad scatter of the survivors is fgs_sdf_scatter_surv (after fgs_march_fine_bwd)

@@ -60,7 +60,8 @@ struct WgArgs {
 constexpr int WG_ROWS = 16;                       // samples per chunk = 8 k-steps
 constexpr int WG_NS = 4;                          // ring slots
 constexpr int WG_PA = WG_ROWS * 256;              // floats of the A panel
-constexpr int WG_LDS_FLOATS = WG_NS * 2 * WG_PA + 4 * 256;     // mode A slots (the largest) + 1 KB dump area per wave
+constexpr int WG_LDS_FLOATS = WG_NS * 2 * WG_PA;     // mode A slots (the largest): 128 KB -- with the 32 000 bytes of one
+                                                     // k_feat_taps_bwd workgroup (it runs beside this kernel) exactly a CU's 160 KB
 
 // Wave arrangements: RT x CT MFMA tiles per wave, KS = how many waves share a tile position and split a chunk's k-steps,
 // PWB = floats per row of the compact B panel.  Waves = (4 / KS) positions x KS; positions are NWR row parts x NWC column
@@ -84,12 +85,13 @@ template <> struct WgMode<6> { static constexpr int RT = 4, CT = 4, KS = 4, PWB 
 struct WgDma {
   const char *base_a, *base_b;    // dY / X at the chunk's first sample row
   unsigned lim_a, lim_b;          // largest byte offset from base that keeps a 16-byte load inside the tensor
-  float *dst;                     // slot base, or null: no chunk left (the pieces then go to the dump area)
+  float *dst;                     // slot base (no chunk left: the pieces re-read the tensors' first rows into the slot the
+                                  // chunk would have used -- free by the ring's invariant, read by nobody)
 };
 
 template <int MODE, int I>
 __device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsigned col0_4, unsigned step_a, unsigned ld_b4,
-                                             int wave, int lane, float *dump) {
+                                             int wave, int lane) {
   using Md = WgMode<MODE>;
   constexpr int PWB = Md::PWB;
   constexpr int NB = PWB / 64;                // B pieces per wave (A: 4 -- one sample row of 256 floats each)
@@ -111,7 +113,6 @@ __device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsig
     src = d.base_b + off;
     dst = d.dst + WG_PA + (wave + 4 * (I - 4)) * 256;
   }
-  if (!d.dst) dst = dump;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 }
@@ -119,14 +120,14 @@ __device__ __forceinline__ void wg_dma_piece(const WgDma &d, unsigned va0, unsig
 template <int MODE, int I, int N>
 struct WgPieces {       // pieces [I, N) of the pending chunk, back to back (prologue)
   static __device__ __forceinline__ void run(const WgDma &d, unsigned va0, unsigned col0_4, unsigned sa, unsigned ldb4, int wave,
-                                             int lane, float *dump) {
-    wg_dma_piece<MODE, I>(d, va0, col0_4, sa, ldb4, wave, lane, dump);
-    WgPieces<MODE, I + 1, N>::run(d, va0, col0_4, sa, ldb4, wave, lane, dump);
+                                             int lane) {
+    wg_dma_piece<MODE, I>(d, va0, col0_4, sa, ldb4, wave, lane);
+    WgPieces<MODE, I + 1, N>::run(d, va0, col0_4, sa, ldb4, wave, lane);
   }
 };
 template <int MODE, int N>
 struct WgPieces<MODE, N, N> {
-  static __device__ __forceinline__ void run(const WgDma &, unsigned, unsigned, unsigned, unsigned, int, int, float *) {}
+  static __device__ __forceinline__ void run(const WgDma &, unsigned, unsigned, unsigned, unsigned, int, int) {}
 };
 
 template <int MODE>
@@ -150,7 +151,6 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const int64_t NC = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t c0 = NC * j_in_block / b.n_wg, c1 = NC * (j_in_block + 1) / b.n_wg;
   if (c0 >= c1) return;
-  float *dump = lds + WG_LDS_FLOATS - 4 * 256 + wave * 256;
   const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
   // ---- DMA: per-lane source offsets inside a chunk (bytes)
@@ -174,7 +174,7 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
       d.base_a = (const char *)b.dY; d.base_b = (const char *)b.X;
       d.lim_a = (unsigned)(bytes_a - 16 < 0x7fffffff ? bytes_a - 16 : 0x7fffffff);
       d.lim_b = (unsigned)(bytes_b - 16 < 0x7fffffff ? bytes_b - 16 : 0x7fffffff);
-      d.dst = nullptr;
+      d.dst = lds + issue_slot * SLOT;
     }
     ++issue_c;
     issue_slot = issue_slot + 1 == WG_NS ? 0 : issue_slot + 1;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
 #pragma unroll
   for (int k = 0; k < WG_NS - 1; ++k) {
     dma_begin();
-    WgPieces<MODE, 0, NP>::run(d, va0, col0_4, step_a, ld_b4, wave, lane, dump);
+    WgPieces<MODE, 0, NP>::run(d, va0, col0_4, step_a, ld_b4, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
   __builtin_amdgcn_s_barrier();
@@ -246,14 +246,14 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
           if (sl >= KPC / 2 && i >= NM - PPK) {     // second half of the chunk: the pieces of the chunk three ahead
             const int piece = (sl - KPC / 2) * PPK + (i - (NM - PPK));
             switch (piece) {      // (compile-time after unrolling)
-              case 0: wg_dma_piece<MODE, 0>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 1: wg_dma_piece<MODE, 1>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 2: wg_dma_piece<MODE, 2>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 3: wg_dma_piece<MODE, 3>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 4: wg_dma_piece<MODE, 4>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 5: if (NP > 5) wg_dma_piece<MODE, (NP > 5 ? 5 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 6: if (NP > 6) wg_dma_piece<MODE, (NP > 6 ? 6 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
-              case 7: if (NP > 7) wg_dma_piece<MODE, (NP > 7 ? 7 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane, dump); break;
+              case 0: wg_dma_piece<MODE, 0>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 1: wg_dma_piece<MODE, 1>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 2: wg_dma_piece<MODE, 2>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 3: wg_dma_piece<MODE, 3>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 4: wg_dma_piece<MODE, 4>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 5: if (NP > 5) wg_dma_piece<MODE, (NP > 5 ? 5 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 6: if (NP > 6) wg_dma_piece<MODE, (NP > 6 ? 6 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
+              case 7: if (NP > 7) wg_dma_piece<MODE, (NP > 7 ? 7 : 0)>(d, va0, col0_4, step_a, ld_b4, wave, lane); break;
               default: break;
             }
           }

@@ -346,7 +346,7 @@ def _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
 
 
 def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs):
+                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs, fork=False):
     """FGS_MLP=rc: every 256-wide data gradient of the two MLPs in ONE register-resident launch (fgs_mlp_rc_chain on the
     transposed weight images, ReLU masks from the 16-byte-per-lane sign bits the forward chain saved), the two narrow
     products (the reflection-encoding columns of dZ, dX0) as plain NN GEMMs on the dY tensors the chain wrote out, then every
@@ -383,8 +383,33 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         items.append((dY_ref[i], acts_ref[i], gw_ref[i], None if i == n_ref - 2 else gb_ref[i], fw, ref_w[i].shape[1]))
     for i in range(n_rgb):
         items.append((dY_rgb[i], acts_rgb[i], gw_rgb[i], gb_rgb[i], rw, rgb_w[i].shape[1]))
-    fo.mlp_wgrad(M, items, flop=2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w)))
+    _wgrad(dev, M, items, 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w)), fork)
     return dZ, dX0
+
+
+# The weight-gradient launch (k_mlp_wgrad: 57 + 256 registers per lane, one 256-thread workgroup per CU, 132 KB of LDS, matrix
+# pipe busy) needs nothing that the rest of the backward pass produces and nothing after it needs its result before the
+# optimizer: with FGS_WGRAD_FORK=1 (default) it goes to a side stream behind the data-gradient chain and the narrow products,
+# and the gather / scatter / atomics-bound kernels that follow on the main stream (feature backward, march backward, sdf
+# scatter: ~200 us of memory latency, < 192 registers, < 25 KB of LDS) take the free issue slots of the same SIMDs.  In a
+# captured step the fork / join become graph edges.  Not with a gradient exchange attached (the MLP gradients are exchanged
+# from inside the backward pass there).
+_WGRAD_FORK = os.environ.get("FGS_WGRAD_FORK", "1") == "1"
+_SIDE_PENDING = set()
+
+
+def _wgrad(dev, M, items, flop, fork: bool) -> None:
+    if not (fork and _WGRAD_FORK):
+        fo.mlp_wgrad(M, items, flop=flop)
+        return
+    side, keep = _side(dev)
+    ready = torch.cuda.Event()
+    ready.record()                      # dY tensors, layer inputs and the zero-filled gradient buffer exist from here on
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        fo.mlp_wgrad(M, items, flop=flop)
+    keep.append(items)                  # (allocated on the main stream: alive until the join)
+    _SIDE_PENDING.add(dev.index)
 
 
 def _flush_tn(dev) -> None:
@@ -403,8 +428,9 @@ def _flush_tn(dev) -> None:
 
 def _join_side(dev) -> None:
     """Main stream waits for the weight-gradient launches on the side stream (before the gradients are handed back)."""
-    if _LINEAR_BWD_MODE not in ("overlap", "late"):
+    if _LINEAR_BWD_MODE not in ("overlap", "late") and dev.index not in _SIDE_PENDING:
         return
+    _SIDE_PENDING.discard(dev.index)
     side, keep = _side(dev)
     done = torch.cuda.Event()
     done.record(side)
@@ -812,7 +838,7 @@ class _FusedFine(torch.autograd.Function):
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
         if S.get('relu_bits') is not None:
             dZ, dX0 = _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                                   gw_rgb, gb_rgb, gw_ref, gb_ref, cs)
+                                   gw_rgb, gb_rgb, gw_ref, gb_ref, cs, fork=_early_hooks(run)[0] is None)
         elif S.get('WT') is not None and ldx0 <= 256:
             dZ, dX0 = _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
                                       gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs)
@@ -1112,8 +1138,9 @@ class _FusedCoarse(torch.autograd.Function):
                 fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers))
             dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
             _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
-            fo.mlp_wgrad(M, [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
-                             for i in range(n_ref - 1)], flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]))
+            _wgrad(dev, M, [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
+                            for i in range(n_ref - 1)], 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]),
+                   fork=_early_hooks(run)[0] is None)
         else:
             for i in range(n_ref - 2, -1, -1):
                 a_in = acts[i]
