@@ -269,9 +269,11 @@ class GradAverager:
     def early(self, kind: str, params, tensor: Optional[torch.Tensor] = None) -> None:
         """Called from INSIDE the fused backward pass (fused.py) as soon as a group of gradients is final, so that its
         exchange runs on a side stream under the kernels the backward pass still has to launch:
-          early('k0',  [k0 param],  grad)  after the feature-grid scatter; ~175 us of sdf scatter kernels follow;
-          early('mlp', mlp params,  flat)  after the MLP chain; `flat` is the one buffer all MLP gradients are views of,
-                                           so a single in-place all-reduce replaces the bucket pack / unpack;
+          early('k0',  [k0 param],  grad)  after the feature-grid scatter, which the backward pass runs right behind the
+                                           data-gradient chain: the weight-gradient launch (~440 us) and ~175 us of sdf
+                                           scatter kernels follow;
+          early('mlp', mlp params,  flat)  after the weight-gradient launch; `flat` is the one buffer all MLP gradients are
+                                           views of, so a single in-place all-reduce replaces the bucket pack / unpack;
           early('join', ...)               before the backward pass copies anything out of `flat`: waits for the 'mlp'
                                            exchange only.
         `average()` then skips these parameters; the main stream waits for the k0 exchange at the end of `average()`, or,

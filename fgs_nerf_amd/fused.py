@@ -346,11 +346,12 @@ def _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
 
 
 def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs, fork=False):
+                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs):
     """FGS_MLP=rc: every 256-wide data gradient of the two MLPs in ONE register-resident launch (fgs_mlp_rc_chain on the
     transposed weight images, ReLU masks from the 16-byte-per-lane sign bits the forward chain saved), the two narrow
-    products (the reflection-encoding columns of dZ, dX0) as plain NN GEMMs on the dY tensors the chain wrote out, then every
-    weight and bias gradient in ONE fgs_mlp_wgrad launch, written straight into the views of the flat gradient buffer."""
+    products (the reflection-encoding columns of dZ, dX0) as plain NN GEMMs on the dY tensors the chain wrote out.  Returns
+    (dZ, dX0, wgrad): `wgrad(fork)` issues every weight and bias gradient in ONE fgs_mlp_wgrad launch, written straight into
+    the views of the flat gradient buffer -- the caller decides where in the backward pass (see _wgrad)."""
     S = run.saved
     dev = dY.device
     bits = S['relu_bits']
@@ -383,8 +384,8 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         items.append((dY_ref[i], acts_ref[i], gw_ref[i], None if i == n_ref - 2 else gb_ref[i], fw, ref_w[i].shape[1]))
     for i in range(n_rgb):
         items.append((dY_rgb[i], acts_rgb[i], gw_rgb[i], gb_rgb[i], rw, rgb_w[i].shape[1]))
-    _wgrad(dev, M, items, 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w)), fork)
-    return dZ, dX0
+    flop = 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w))
+    return dZ, dX0, lambda fork: _wgrad(dev, M, items, flop, fork)
 
 
 # The weight-gradient launch (k_mlp_wgrad: 57 + 256 registers per lane, one 256-thread workgroup per CU, 132 KB of LDS, matrix
@@ -752,8 +753,8 @@ class _FusedFine(torch.autograd.Function):
         run.pre = None
         hook, opt_hook = _early_hooks(run)
         if hook is not None:
-            hook('mlp', mlp, flat)
             hook('k0', [k0_grid], grad_k0)
+            hook('mlp', mlp, flat)
             hook('join', None)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)
@@ -836,9 +837,10 @@ class _FusedFine(torch.autograd.Function):
         gW0p, gV0p, cs = views[-3], views[-2], views[-1]
         # 3. refnet layers n_ref-2 .. 0   (dY is the gradient w.r.t. the pre-activation output of layer i)
         grp = _gemm_group("backward chain (" + _LINEAR_BWD_MODE + ")").__enter__()
+        wgrad = None
         if S.get('relu_bits') is not None:
-            dZ, dX0 = _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                                   gw_rgb, gb_rgb, gw_ref, gb_ref, cs, fork=_early_hooks(run)[0] is None)
+            dZ, dX0, wgrad = _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
+                                          gw_rgb, gb_rgb, gw_ref, gb_ref, cs)
         elif S.get('WT') is not None and ldx0 <= 256:
             dZ, dX0 = _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
                                       gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs)
@@ -872,8 +874,9 @@ class _FusedFine(torch.autograd.Function):
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
-        if hook is not None:
-            hook('mlp', mlp, flat)               # every MLP gradient is a view of `flat`, final from here on
+        if wgrad is not None and hook is None:
+            wgrad(True)                          # one GPU: on a side stream, beside the scatter kernels below
+            wgrad = None
 
         # 5. features -> grids
         if run.pre is not None:
@@ -892,7 +895,13 @@ class _FusedFine(torch.autograd.Function):
              ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:
-            hook('k0', [k0_grid], grad_k0)       # final: its exchange runs under the sdf scatter kernels below
+            # the exchanges, in the order EVERY path of every rank issues them (k0, mlp, join: _backward_empty too): k0's is
+            # the long one (tens of MB at 8 ranks) and starts first, under the weight-gradient launch and the sdf scatter
+            # kernels; the MLP gradients -- views of `flat`, final after that launch -- follow
+            hook('k0', [k0_grid], grad_k0)
+            if wgrad is not None:
+                wgrad(False)
+            hook('mlp', mlp, flat)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)           # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
@@ -1100,8 +1109,8 @@ class _FusedCoarse(torch.autograd.Function):
             grad_k0 = torch.empty_strided(k0_grid.shape, k0_grid.stride(), dtype=F32, device=dev).zero_()
             hook, opt_hook = _early_hooks(run)
             if hook is not None:
-                hook('mlp', mlp, flat)
                 hook('k0', [k0_grid], grad_k0)
+                hook('mlp', mlp, flat)
                 hook('join', None)
             elif opt_hook is not None:
                 opt_hook(k0_grid, grad_k0)
@@ -1122,6 +1131,7 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
              ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), st)
         dX0 = None
+        wgrad = None
         grp = _gemm_group("backward chain (" + ("rc" if S.get('relu_bits') is not None else _LINEAR_BWD_MODE) + ")").__enter__()
         if S.get('relu_bits') is not None:
             # register-resident data-gradient chain (layers n_ref-2 .. 1), dX0 as one narrow NN product, every weight / bias
@@ -1138,9 +1148,9 @@ class _FusedCoarse(torch.autograd.Function):
                 fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers))
             dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
             _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
-            _wgrad(dev, M, [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
-                            for i in range(n_ref - 1)], 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]),
-                   fork=_early_hooks(run)[0] is None)
+            wg_items = [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
+                        for i in range(n_ref - 1)]
+            wgrad = lambda fork: _wgrad(dev, M, wg_items, 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), fork)
         else:
             for i in range(n_ref - 2, -1, -1):
                 a_in = acts[i]
@@ -1155,8 +1165,9 @@ class _FusedCoarse(torch.autograd.Function):
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
-        if hook is not None:
-            hook('mlp', mlp, flat)
+        if wgrad is not None and hook is None:
+            wgrad(True)
+            wgrad = None
         if run.pre is not None:
             d4, pre_k0 = run.pre
             run.pre = None
@@ -1169,8 +1180,11 @@ class _FusedCoarse(torch.autograd.Function):
              g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
              ptr(g_grad_s), st)
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
-        if hook is not None:
+        if hook is not None:                     # (k0, mlp, join: the order of every path, see _FusedFine)
             hook('k0', [k0_grid], grad_k0)
+            if wgrad is not None:
+                wgrad(False)
+            hook('mlp', mlp, flat)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
