@@ -356,6 +356,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X
 // busy through ~400 instructions, VALU-bound at 27 us -- and the fp32 matrix instructions of k_mlp_wgrad, which this kernel
 // runs beside, execute on the same vector pipe.)  A thread reads its row's 6 F_ref + 3 columns of Z and dZ itself: four cache
 // lines per survivor.
+// (FREF: the number of reflection frequencies as a compile-time constant, 0 = read it from the layout -- with the loops
+// unrolled all 4 * 3 F loads of a thread are in flight together instead of one dependent round trip per frequency)
+template <int FREF>
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const float *__restrict__ Z,
                                                             const float *__restrict__ dX0, const float *__restrict__ dZ,
                                                             const float *__restrict__ g_normal, float *__restrict__ g_sdf,
@@ -365,17 +368,28 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= S.M) return;
   const FeatLayout &L = S.L;
-  const int F = L.n_reffreq;
+  const int F = FREF ? FREF : L.n_reffreq;
   const float *z = Z + m * L.ldz + L.off_ref;
   const float *dz = dZ + m * L.ldz + L.off_ref;
   // d reflect_c = dE[c] + sum_f 2^f (cos * dE_sin - sin * dE_cos)
   float part[3] = {0.f, 0.f, 0.f};
+  if (FREF) {
+    float zs[3 * (FREF ? FREF : 1)], zc[3 * (FREF ? FREF : 1)], ds[3 * (FREF ? FREF : 1)], dc[3 * (FREF ? FREF : 1)];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    for (int f = 0; f < F; ++f) {
-      const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
-      part[c] += (float)(1 << f) * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
-    }
+    for (int i = 0; i < 3 * FREF; ++i) { zs[i] = z[3 + i]; zc[i] = z[3 + 3 * FREF + i]; ds[i] = dz[3 + i]; dc[i] = dz[3 + 3 * FREF + i]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int f = 0; f < FREF; ++f)
+        part[c] += (float)(1 << f) * (zc[c * FREF + f] * ds[c * FREF + f] - zs[c * FREF + f] * dc[c * FREF + f]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      for (int f = 0; f < F; ++f) {
+        const float sn = z[3 + c * F + f], cs = z[3 + 3 * F + c * F + f];
+        part[c] += (float)(1 << f) * (cs * dz[3 + c * F + f] - sn * dz[3 + 3 * F + c * F + f]);
+      }
+  }
   const float dr[3] = {dz[0] + part[0], dz[1] + part[1], dz[2] + part[2]};
   const int64_t r = S.ray_id[m];
   const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
@@ -766,8 +780,14 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal,
-                     (float *)nullptr, g_gradient);
+#define FGS_ENC_BWD(F) hipLaunchKernelGGL(k_feat_enc_bwd<F>, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal, (float *)nullptr, g_gradient)
+  switch (S.L.n_reffreq) {      // the shipped configs' frequency counts (config/shiny_blender.py: 3 / 5 / 8) unrolled
+    case 3: FGS_ENC_BWD(3); break;
+    case 5: FGS_ENC_BWD(5); break;
+    case 8: FGS_ENC_BWD(8); break;
+    default: FGS_ENC_BWD(0); break;
+  }
+#undef FGS_ENC_BWD
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/enc");
   return 0;
 }
@@ -817,8 +837,14 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf,
-                     g_gradient);
+#define FGS_ENC_BWD(F) hipLaunchKernelGGL(k_feat_enc_bwd<F>, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf, g_gradient)
+  switch (S.L.n_reffreq) {      // the shipped configs' frequency counts (config/shiny_blender.py: 3 / 5 / 8) unrolled
+    case 3: FGS_ENC_BWD(3); break;
+    case 5: FGS_ENC_BWD(5); break;
+    case 8: FGS_ENC_BWD(8); break;
+    default: FGS_ENC_BWD(0); break;
+  }
+#undef FGS_ENC_BWD
   FGS_LAUNCH_OK("fgs_feat_fine_bwd/enc");
   (void)sdf_grad_grid;  // the sdf.grad scatter of the survivors is fgs_sdf_scatter_surv (after fgs_march_fine_bwd)
   return 0;

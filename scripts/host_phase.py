@@ -48,6 +48,16 @@ for i in range(5):
     bench.train_step(model, opt, avg, batches[i % 8], N)
 torch.cuda.synchronize()
 
+HOOK_T = {}
+if args.force_dist:          # the exchange hooks run on the autograd thread, inside `backward`
+    _early = avg.early
+
+    def timed_early(kind, params, tensor=None):
+        t = time.perf_counter()
+        _early(kind, params, tensor)
+        HOOK_T[kind] = HOOK_T.get(kind, 0.0) + time.perf_counter() - t
+    model._fused_cache['grad_hook'] = timed_early
+
 T = dict(forward=0.0, loss=0.0, hint=0.0, backward=0.0, average=0.0, tv=0.0, adam=0.0)
 
 
@@ -90,3 +100,5 @@ if args.cprofile:
 print(f"host-bound step: {el / K * 1e3:.3f} ms  (grid {args.grid}, {N} rays, force_dist={args.force_dist})")
 for k, v in T.items():
     print(f"  {k:9s} {v / K * 1e3:.3f} ms")
+for k, v in HOOK_T.items():
+    print(f"    (inside backward) early('{k}') {v / K * 1e3:.3f} ms")

@@ -204,7 +204,8 @@ def test_interleaved_volume_lookups_are_bit_identical(dev):
         fused._COARSE_VOL4 = old
     for k in outs[True][0]:
         assert torch.equal(outs[True][0][k], outs[False][0][k]), k
-    assert outs[True][2] == outs[False][2]
+    # (the loss scalar is a sum of per-workgroup partials added with float atomics: equal up to their order, like sdf.grad)
+    assert abs(outs[True][2] - outs[False][2]) <= 1e-6 * abs(outs[False][2])
     # (sdf.grad goes through float atomics in both runs: equal up to their order)
     a, b = outs[True][1], outs[False][1]
     assert float((a - b).norm() / b.norm()) < 1e-5
