@@ -30,6 +30,7 @@
 // element depends only on its own row of A and column of B, so whatever the panel holds there only reaches accumulators that
 // the flush skips.  Sample rows beyond M (the last chunk) do reach real outputs: they are zeroed in LDS once the chunk landed.
 #include "fgs_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,6 +48,7 @@ struct WgBlock {
   int n_out, n_in;       // valid rows / columns of dW
   int col0, cols, mode;  // first column and width of the block; wave arrangement (WgMode)
   int wg0, n_wg;         // workgroups [wg0, wg0 + n_wg) split the samples of this block
+  float stagger;         // a of the share function (wgrad_block)
 };
 
 struct WgArgs {
@@ -149,7 +151,14 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const int row_base = wr * RT * 32, colp_base = wc * CT * 32;     // first row of the wave / first panel column
   // chunk range of this workgroup
   const int64_t NC = (M + WG_ROWS - 1) / WG_ROWS;
-  const int64_t c0 = NC * j_in_block / b.n_wg, c1 = NC * (j_in_block + 1) / b.n_wg;
+  // Staggered shares: workgroup j of n takes the chunks [NC F(j / n), NC F((j + 1) / n)), F(x) = (1 - a) x + a x^2 -- the
+  // first a few per cent fewer than the last.  With equal shares all 256 workgroups reach the flush together and the memory-
+  // side atomic units, idle until then, become the bottleneck for the last ~40 us (64 MB of fp32 atomics); staggered, the
+  // early finishers' atomics run under the matrix work of the others.
+  const double xa = (double)j_in_block / b.n_wg, xb = (double)(j_in_block + 1) / b.n_wg;
+  const double sa = b.stagger;
+  const int64_t c0 = j_in_block == 0 ? 0 : (int64_t)((double)NC * ((1.0 - sa) * xa + sa * xa * xa));
+  const int64_t c1 = j_in_block + 1 == b.n_wg ? NC : (int64_t)((double)NC * ((1.0 - sa) * xb + sa * xb * xb));
   if (c0 >= c1) return;
   const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
@@ -401,6 +410,8 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
   // one workgroup per CU (256 accumulator registers per lane); blocks get workgroups in proportion to their MFMA count,
   // at least one each, never more than one per 64 samples
   const int64_t max_per_block = (M + 63) / 64;
+  static const float stagger = getenv("FGS_WGRAD_STAGGER") ? (float)atof(getenv("FGS_WGRAD_STAGGER")) : 0.04f;
+  // (measured at M = 58 430: a = 0: 441 us, 0.03: 436, 0.06: 435, 0.10: 444, 0.15: 461 -- scripts/diag/wg_stagger.sh)
   int wg = 0, given = 0, cost_seen = 0;
   for (int i = 0; i < nb; ++i) {
     cost_seen += cost[i];
@@ -408,7 +419,7 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
     if (n < 1) n = 1;
     if (n > max_per_block) n = (int)max_per_block;
     given += n;
-    a.B[i].wg0 = wg; a.B[i].n_wg = n;
+    a.B[i].wg0 = wg; a.B[i].n_wg = n; a.B[i].stagger = stagger;
     wg += n;
   }
   if (M < 64 && !a.m_dev) {      // tiny batches: not worth a 256-register workgroup per block
