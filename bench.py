@@ -62,7 +62,10 @@ def train_step(model, opt, averager, batch, n_rays_global):
             with _DeviceScalars(count=count_ptr):
                 averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
     opt.zero_grad(set_to_none=True)
-    loss.backward()
+    seed = STEP_STATS.get("seed")
+    if seed is None or seed.device != loss.device:
+        seed = STEP_STATS["seed"] = torch.ones((), dtype=torch.float32, device=loss.device)
+    loss.backward(seed)             # (the gradient seed given: one fill launch less than autograd's implicit ones_like)
     averager.average()
     # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)
     model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)

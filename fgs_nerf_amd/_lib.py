@@ -54,6 +54,7 @@ _SIGNATURES = {
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
+    "fgs_exclusive_scan_guard_i64": [P, I64, P, I64, P, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
                            P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_march_count": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,

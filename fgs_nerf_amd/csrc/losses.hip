@@ -1,5 +1,5 @@
 // losses.hip -- the ray-dependent loss terms of one training iteration (model/nerf_training.py:308-327) and their
-// gradients as two small kernels each, instead of ~40 elementwise / reduction launches of the autograd graph.
+// gradients as one small kernel each way, instead of ~40 elementwise / reduction launches of the autograd graph.
 // (training-loop host overhead.)
 //
 //   main      w_main   * mean((rgb_marched - target)^2)                                    :308
@@ -36,9 +36,8 @@ __device__ __forceinline__ float block_sum_to(float v, float *dst) {
   return v;
 }
 
-__global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_fwd(LossArgs L, float *loss) {
-  L.M = fgs_rows(L.M, L.m_dev);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over N*3 elements
+// ray terms of element i (of N*3)
+__device__ __forceinline__ float loss_rays_term(const LossArgs &L, int64_t i) {
   float acc = 0.f;
   if (i < L.N * 3) {
     const float t = L.target[i];
@@ -50,12 +49,11 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_fwd(LossArgs L, float *
     const float p = fminf(fmaxf(L.alphainv_cum[L.N - 1], 1e-6f), 1.f - 1e-6f);
     acc += L.w_ent * (-(p * logf(p) + (1.f - p) * logf(1.f - p)));
   }
-  block_sum_to(acc, loss);
+  return acc;
 }
 
-__global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_fwd(LossArgs L, float *loss) {
-  L.M = fgs_rows(L.M, L.m_dev);
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// survivor terms of survivor m
+__device__ __forceinline__ float loss_surv_term(const LossArgs &L, int64_t m) {
   float acc = 0.f;
   if (m < L.M) {
     const float w = L.weights[m];
@@ -76,16 +74,21 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_fwd(LossArgs L, float *
       acc += L.w_rgbper * s * w / (float)L.N;
     }
   }
+  return acc;
+}
+
+// One launch for both index ranges (thread i: element i of the N*3 ray values AND survivor i): each launch of a captured
+// step costs ~5 us whatever it does.
+__global__ __launch_bounds__(FGS_BLOCK) void k_loss_fwd(LossArgs L, float *loss, int with_surv) {
+  L.M = fgs_rows(L.M, L.m_dev);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = loss_rays_term(L, i);
+  if (with_surv) acc += loss_surv_term(L, i);
   block_sum_to(acc, loss);
 }
 
-__global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_bwd(LossArgs L, const float *__restrict__ grad_out,
-                                                             float *__restrict__ g_rgb_marched,
-                                                             float *__restrict__ g_sigmoid_rgb,
-                                                             float *__restrict__ g_last) {
-  L.M = fgs_rows(L.M, L.m_dev);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float go = grad_out[0];
+__device__ __forceinline__ void loss_rays_bwd(const LossArgs &L, int64_t i, float go, float *__restrict__ g_rgb_marched,
+                                              float *__restrict__ g_sigmoid_rgb, float *__restrict__ g_last) {
   if (i < L.N * 3) {
     const float t = L.target[i];
     const float inv2 = 2.f / (float)(L.N * 3);
@@ -102,13 +105,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_rays_bwd(LossArgs L, const f
   }
 }
 
-__global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_bwd(LossArgs L, const float *__restrict__ grad_out,
-                                                             float *__restrict__ g_normal,
-                                                             float *__restrict__ g_raw_rgb) {
-  L.M = fgs_rows(L.M, L.m_dev);
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void loss_surv_bwd(const LossArgs &L, int64_t m, float go, float *__restrict__ g_normal,
+                                              float *__restrict__ g_raw_rgb) {
   if (m >= L.M) return;
-  const float go = grad_out[0];
   const float w = L.weights[m];
   const int64_t r = L.ray_id[m];
   const float v[3] = {L.viewdirs[3 * r], L.viewdirs[3 * r + 1], L.viewdirs[3 * r + 2]};
@@ -130,6 +129,17 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_surv_bwd(LossArgs L, const f
                                  ? go * L.w_rgbper * w * 2.f * (L.raw_rgb[3 * m + c] - L.target[3 * r + c]) / (float)L.N
                                  : 0.f;
   }
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_loss_bwd(LossArgs L, const float *__restrict__ grad_out,
+                                                        float *__restrict__ g_rgb_marched, float *__restrict__ g_sigmoid_rgb,
+                                                        float *__restrict__ g_last, float *__restrict__ g_normal,
+                                                        float *__restrict__ g_raw_rgb) {
+  L.M = fgs_rows(L.M, L.m_dev);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float go = grad_out[0];
+  loss_rays_bwd(L, i, go, g_rgb_marched, g_sigmoid_rgb, g_last);
+  if (g_normal) loss_surv_bwd(L, i, go, g_normal, g_raw_rgb);
 }
 
 int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
@@ -162,12 +172,10 @@ FGS_API int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, co
   hipStream_t st = fgs_s(stream);
   hipError_t he = hipMemsetAsync(loss_out, 0, sizeof(float), st);
   if (he != hipSuccess) return fgs_set_error((int)he, "fgs_fine_loss_fwd: %s", hipGetErrorString(he));
-  hipLaunchKernelGGL(k_loss_rays_fwd, dim3(fgs_blocks(N * 3)), dim3(FGS_BLOCK), 0, st, L, loss_out);
-  FGS_LAUNCH_OK("fgs_fine_loss_fwd/rays");
-  if (M > 0 && (L.w_ori > 0.f || L.w_rgbper > 0.f)) {
-    hipLaunchKernelGGL(k_loss_surv_fwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, L, loss_out);
-    FGS_LAUNCH_OK("fgs_fine_loss_fwd/surv");
-  }
+  const int with_surv = (M > 0 && (L.w_ori > 0.f || L.w_rgbper > 0.f)) ? 1 : 0;
+  const int64_t n_thr = (with_surv && M > N * 3) ? M : N * 3;
+  hipLaunchKernelGGL(k_loss_fwd, dim3(fgs_blocks(n_thr)), dim3(FGS_BLOCK), 0, st, L, loss_out, with_surv);
+  FGS_LAUNCH_OK("fgs_fine_loss_fwd");
   return 0;
 }
 
@@ -183,12 +191,9 @@ FGS_API int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, co
   FGS_REQUIRE(grad_out && g_rgb_marched && g_sigmoid_rgb && g_last && (M == 0 || g_normal), FGS_E_INVALID,
               "fgs_fine_loss_bwd: null pointer");
   hipStream_t st = fgs_s(stream);
-  hipLaunchKernelGGL(k_loss_rays_bwd, dim3(fgs_blocks(N * 3)), dim3(FGS_BLOCK), 0, st, L, grad_out, g_rgb_marched,
-                     g_sigmoid_rgb, g_last);
-  FGS_LAUNCH_OK("fgs_fine_loss_bwd/rays");
-  if (M > 0) {
-    hipLaunchKernelGGL(k_loss_surv_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, L, grad_out, g_normal, g_raw_rgb);
-    FGS_LAUNCH_OK("fgs_fine_loss_bwd/surv");
-  }
+  const int64_t n_thr = M > N * 3 ? M : N * 3;
+  hipLaunchKernelGGL(k_loss_bwd, dim3(fgs_blocks(n_thr)), dim3(FGS_BLOCK), 0, st, L, grad_out, g_rgb_marched, g_sigmoid_rgb,
+                     g_last, M > 0 ? g_normal : (float *)nullptr, g_raw_rgb);
+  FGS_LAUNCH_OK("fgs_fine_loss_bwd");
   return 0;
 }

@@ -91,9 +91,13 @@ __global__ void k_count(const float *__restrict__ rays_o, const float *__restric
 // Exclusive prefix sum of int64 counts into out[n+1] (out[n] = total).  One 1024-thread workgroup;
 // each thread owns a contiguous slice, slices are combined with a wave-shuffle + LDS scan.
 // Replaces N_steps.cumsum(0) and N_steps.sum().item() of render_utils_kernel.cu:211-212.
+// GUARD (fgs_exclusive_scan_guard_i64): the capacity guard of a sync-free step (fgs_count_guard, gridopt.hip) applied while
+// the offsets are written -- every offset cut at `capacity`, flags / total updated from the uncut total -- one launch less.
 constexpr int SCAN_THREADS = 1024;
+template <bool GUARD>
 __global__ __launch_bounds__(SCAN_THREADS) void k_exclusive_scan_i64(const int64_t *__restrict__ in, int64_t n,
-                                                                      int64_t *__restrict__ out) {
+                                                                      int64_t *__restrict__ out, int64_t capacity,
+                                                                      int *__restrict__ flags, int64_t *__restrict__ total) {
   __shared__ int64_t wave_tot[SCAN_THREADS / FGS_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -113,12 +117,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_exclusive_scan_i64(const int64
   for (int w = 0; w < wv; ++w) wave_base += wave_tot[w];
   int64_t run = wave_base + inc - sum;
   for (int64_t i = lo; i < hi; ++i) {
-    out[i] = run;
+    out[i] = (GUARD && run > capacity) ? capacity : run;
     run += in[i];
   }
   if (tid == SCAN_THREADS - 1) {
     int64_t tot = 0;
     for (int w = 0; w < SCAN_THREADS / FGS_WAVE; ++w) tot += wave_tot[w];
+    if (GUARD) {
+      const int over = tot > capacity ? 1 : 0;
+      flags[1] = over;
+      if (over) flags[0] = 1;
+      if (total) *total += over ? capacity : tot;
+      if (over) tot = capacity;
+    }
     out[n] = tot;
   }
 }
@@ -259,8 +270,8 @@ FGS_API int fgs_sample_count(const float *rays_o, const float *rays_d, const flo
   hipLaunchKernelGGL(k_count, dim3(fgs_blocks(n_rays)), dim3(FGS_BLOCK), 0, fgs_s(stream), rays_o, rays_d, xyz_min,
                      xyz_max, near, far, stepdist, n_rays, n_steps, t_min, t_max);
   FGS_LAUNCH_OK("fgs_sample_count/count");
-  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), (const int64_t *)n_steps,
-                     n_rays, steps_cumsum);
+  hipLaunchKernelGGL(k_exclusive_scan_i64<false>, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), (const int64_t *)n_steps,
+                     n_rays, steps_cumsum, (int64_t)0, (int *)nullptr, (int64_t *)nullptr);
   FGS_LAUNCH_OK("fgs_sample_count/scan");
   return 0;
 }
@@ -321,7 +332,20 @@ FGS_API int fgs_maskcache_lookup(const uint8_t *world, const float *xyz, const f
 FGS_API int fgs_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, fgs_stream_t stream) {
   FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_exclusive_scan_i64: n=%lld", (long long)n);
   FGS_REQUIRE(out && (n == 0 || in), FGS_E_INVALID, "fgs_exclusive_scan_i64: null pointer");
-  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), in, n, out);
+  hipLaunchKernelGGL(k_exclusive_scan_i64<false>, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), in, n, out, (int64_t)0,
+                     (int *)nullptr, (int64_t *)nullptr);
   FGS_LAUNCH_OK("fgs_exclusive_scan_i64");
+  return 0;
+}
+
+// fgs_exclusive_scan_i64 followed by fgs_count_guard(out, n + 1, capacity, flags, total) in one launch.
+FGS_API int fgs_exclusive_scan_guard_i64(const int64_t *in, int64_t n, int64_t *out, int64_t capacity, int *flags,
+                                         int64_t *total, fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS && capacity >= 0, FGS_E_RANGE, "fgs_exclusive_scan_guard_i64: n=%lld capacity=%lld",
+              (long long)n, (long long)capacity);
+  FGS_REQUIRE(out && flags && (n == 0 || in), FGS_E_INVALID, "fgs_exclusive_scan_guard_i64: null pointer");
+  hipLaunchKernelGGL(k_exclusive_scan_i64<true>, dim3(1), dim3(SCAN_THREADS), 0, fgs_s(stream), in, n, out, capacity, flags,
+                     total);
+  FGS_LAUNCH_OK("fgs_exclusive_scan_guard_i64");
   return 0;
 }

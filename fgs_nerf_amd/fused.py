@@ -598,7 +598,12 @@ class _FusedFine(torch.autograd.Function):
              g.mask[3] if g.mask else 0.0, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']),
              ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']), ptr(ws['n_alive']),
              ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
-        call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        sf = run.sync_free
+        if sf:      # sync-free: offsets cut at the capacity and the overflow flags set by the scan launch itself
+            call("fgs_exclusive_scan_guard_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), sf['capacity'], ptr(sf['flags']),
+                 ptr(sf['total']), st)
+        else:
+            call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
         # everything that does not need the survivor count is issued BEFORE the host read, off the post-sync path:
         # first-layer weights are copied into K-padded operands (their row length is not a multiple of 4)
         n_rgb, n_ref = run.n_rgb, run.n_ref
@@ -618,7 +623,6 @@ class _FusedFine(torch.autograd.Function):
             # sync-free: the count stays on the device (last entry of the survivor offsets); M is the CAPACITY from here on
             M = sf['capacity']
             run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
-            call("fgs_count_guard", ptr(ws['surv_off']), N + 1, M, ptr(sf['flags']), ptr(sf['total']), st)
             call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_fine() when this forward returns
         else:
             M = _count_end(token)                  # the one host read of the step
@@ -717,7 +721,11 @@ class _FusedFine(torch.autograd.Function):
         # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
         run.pre = None
         if any(ctx.needs_input_grad) and M > 0:        # all False under torch.no_grad() (rendering)
-            run.pre = (torch.zeros_like(sdf_grid), pre_k0)
+            # sdf.grad and the flat buffer of the MLP gradients (both accumulated into by the backward pass) share ONE zero
+            # fill: [flat | sdf.grad], each 16-byte aligned
+            _, n_flat = _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz)
+            arena = torch.zeros(n_flat + sdf_grid.numel(), dtype=F32, device=dev)
+            run.pre = (arena[n_flat:].view(sdf_grid.shape), pre_k0, arena[:n_flat])
         WT = None
         if run.pre is not None and _LINEAR_BWD_MODE == "chain" and rw == 256 and fw == 256 and n_ref - 1 + n_rgb <= 8:
             # transposed weights in the order the backward chain walks the layers (dX = dY . W as a forward-shaped product)
@@ -816,7 +824,7 @@ class _FusedFine(torch.autograd.Function):
         # them, views of a flat buffer, each 16-byte aligned.  The layout is cached; only the three views the head kernel
         # needs are made before its launch, the rest while it runs (the GPU is idle at the start of a backward pass).
         items, total = _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz)
-        flat = torch.zeros(total, dtype=F32, device=dev)
+        flat = run.pre[2] if run.pre is not None else torch.zeros(total, dtype=F32, device=dev)   # (zero-filled in forward)
 
         def view(i):
             sh, n, off = items[i]
@@ -880,7 +888,7 @@ class _FusedFine(torch.autograd.Function):
 
         # 5. features -> grids
         if run.pre is not None:
-            grad_sdf, pre_k0 = run.pre            # zero-filled at the end of the forward pass
+            grad_sdf, pre_k0 = run.pre[:2]        # zero-filled at the end of the forward pass
             run.pre = None
         else:
             grad_sdf, pre_k0 = torch.zeros_like(sdf_grid), None
@@ -990,7 +998,11 @@ class _FusedCoarse(torch.autograd.Function):
              inc[2] if inc else None, inc[3] if inc else None, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
              ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
-        call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
+        if sf:
+            call("fgs_exclusive_scan_guard_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), sf['capacity'], ptr(sf['flags']),
+                 ptr(sf['total']), st)
+        else:
+            call("fgs_exclusive_scan_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), st)
         token = None if sf else _count_begin(run, ws['surv_off'], N)
         n_ref = run.n_ref                           # queued behind the count copy: K-padded first-layer weights, k0.grad fill
         ref_w = [mlp[2 * i] for i in range(n_ref)]
@@ -1002,7 +1014,6 @@ class _FusedCoarse(torch.autograd.Function):
         if sf:       # sync-free (see _FusedFine.forward): the count stays on the device, M is the CAPACITY from here on
             M = sf['capacity']
             run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
-            call("fgs_count_guard", ptr(ws['surv_off']), N + 1, M, ptr(sf['flags']), ptr(sf['total']), st)
             call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_coarse() when this forward returns
         else:
             M = _count_end(token)                  # the one host read of the step

@@ -74,6 +74,7 @@ class CapturedFineStep:
         # ---- static inputs: one buffer, so that a batch that arrives packed as [4, n_rays, 3] is ONE copy
         self.inputs = torch.zeros(4, n_rays, 3, device=dev)
         self.rays_o, self.rays_d, self.viewdirs, self.target = self.inputs.unbind(0)
+        self._seed = torch.ones((), dtype=torch.float32, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss = None
 
@@ -97,7 +98,7 @@ class CapturedFineStep:
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        loss.backward(self._seed)             # (d loss / d loss given: autograd would launch a ones_like fill per step)
         if update:
             if self.tv is not None:
                 self.model.sdf_total_variation_add_grad(self.tv[0], self.tv[1])

@@ -60,6 +60,10 @@ float fgs_adam_step_size(int step, float beta1, float beta2, float lr);      /* 
 int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
                           float *mirror_dst, fgs_stream_t stream);
 int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream);
+/* fgs_exclusive_scan_i64(in, n, out) + fgs_count_guard(out, n + 1, capacity, flags, total) as ONE launch (the survivor offsets
+ * of a sync-free step: model/nerf.py:802-833's nonzero / cumsum without the host). */
+int fgs_exclusive_scan_guard_i64(const int64_t *in, int64_t n, int64_t *out, int64_t capacity, int *flags, int64_t *total,
+                                 fgs_stream_t stream);
 /* fgs_adam_upd / fgs_adam_upd_multi with the step size read from device memory (one float per call / per tensor) and an
  * optional skip flag; everything else as in the host-scalar forms. */
 int fgs_adam_upd_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,

@@ -319,7 +319,9 @@ def test_sync_free_eager_steps_with_the_exchange_match_plain_steps(dev):
                 total = bench.STEP_STATS["survivors"]
             assert avg.last_sparse_fill is not None and 0 < avg.last_sparse_fill < 0.6      # the sparse exchange ran
             outs[mode] = (total, [p.detach().clone() for p in model.parameters()])
-        assert outs["plain"][0] == outs["sync_free"][0] > 0
+        # (the two trainings see the same batches, but their gradients are summed with float atomics: after a few Adam steps a
+        # sample sitting on the alpha threshold may fall on either side -- 29 644 vs 29 645 survivors has been seen)
+        assert outs["sync_free"][0] > 0 and abs(outs["plain"][0] - outs["sync_free"][0]) <= 8
         for pa, pb in zip(outs["plain"][1], outs["sync_free"][1]):
             assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 3e-3
     finally:
