@@ -54,6 +54,8 @@ print(f"kernel time per step (sum over kernels): {busy_tot / n / 1e6:.4f} ms")
 print(f"step span (marker to marker):            {span_tot / n / 1e6:.4f} ms   (median {sorted(spans)[len(spans) // 2] / 1e6:.4f}; "
       f"a host hiccup under the profiler shows up as one long step)")
 print(f"GPU idle inside a step:                  {idle_tot / n / 1e3:.1f} us")
+print(f"kernel time hidden by overlap:           {(busy_tot - (span_tot - idle_tot)) / n / 1e3:.1f} us   (k_mlp_wgrad runs on a "
+      f"graph branch of its own beside the scatter kernels: their durations below include the time they share the CUs)")
 for name, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t / n / 1e3:8.1f} us/step {c / n:6.2f} calls {t / c / 1e3:8.1f} us  {name}")
 mc = sorted(glob.glob(d + "/*/*_memory_copy_trace.csv"))
