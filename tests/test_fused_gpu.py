@@ -459,3 +459,57 @@ def test_register_resident_mlp_path_matches_the_gemm_path(dev, monkeypatch, G, N
     assert abs(got["rc"][2] - got["lds"][2]) < 1e-6
     for k, v in got["lds"][3].items():
         assert rel_l2(got["rc"][3][k], v) < 1e-4, (k, rel_l2(got["rc"][3][k], v))
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_forked_weight_gradient_launch_matches_one_stream(dev, monkeypatch, stage):
+    """fused._wgrad: the weight-gradient launch on a side stream beside the scatter kernels of the backward pass (default
+    on one GPU) against the same step on ONE stream: identical forward, every gradient within the float-atomics order
+    tolerance -- and two forwards followed by their two backwards (two weight-gradient launches pending on the side stream
+    at once, the tensors they read kept alive until the join) give the same gradients as separate steps."""
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    cfg, lossw = (synth.FINE_MODEL, synth.FINE_LOSS) if stage == "fine" else (synth.COARSE_MODEL, synth.COARSE_LOSS)
+    rays = [tuple(r.to(dev) for r in synth.random_rays(600, seed=s)) for s in (5, 6)]
+    target = torch.rand(600, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    got = {}
+    for fork in (True, False):
+        monkeypatch.setattr(fused, "_WGRAD_FORK", fork)
+        model = synth.build_model(40, cfg, device=dev)
+        res = model(*rays[0], global_step=1000, **synth.RENDER_KWARGS)
+        loss = fused_render_losses(res, target, lossw, model)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert not fused._SIDE_PENDING                      # joined before the backward pass returned
+        got[fork] = (res["rgb_marched"].detach().clone(), {k: v.clone() for k, v in grads_of_any(model).items()})
+    assert torch.equal(got[True][0], got[False][0])
+    for k, v in got[False][1].items():
+        assert rel_l2(got[True][1][k], v) < 2e-5, k
+    # two forwards, then their backwards (sum of the two losses): gradients == sum of the separate steps' gradients
+    monkeypatch.setattr(fused, "_WGRAD_FORK", True)
+    model = synth.build_model(40, cfg, device=dev)
+    sep = []
+    for r in rays:
+        for p in model.parameters():
+            p.grad = None
+        fused_render_losses(model(*r, global_step=1000, **synth.RENDER_KWARGS), target, lossw, model).backward()
+        sep.append({k: v.clone() for k, v in grads_of_any(model).items()})
+    for p in model.parameters():
+        p.grad = None
+    l0 = fused_render_losses(model(*rays[0], global_step=1000, **synth.RENDER_KWARGS), target, lossw, model)
+    l1 = fused_render_losses(model(*rays[1], global_step=1000, **synth.RENDER_KWARGS), target, lossw, model)
+    (l0 + l1).backward()
+    torch.cuda.synchronize()
+    both = grads_of_any(model)
+    for k in both:
+        assert rel_l2(both[k], sep[0][k] + sep[1][k]) < 2e-5, k
+
+
+def grads_of_any(model):
+    from fgs_nerf_amd.nerf import mlp_layers
+    out = {'sdf': model.sdf.grid.grad, 'k0': model.k0.grid.grad}
+    for net in ('rgbnet', 'refnet'):
+        if getattr(model, net, None) is not None:
+            for i, l in enumerate(mlp_layers(getattr(model, net))):
+                out[f'{net}.{i}.weight'], out[f'{net}.{i}.bias'] = l.weight.grad, l.bias.grad
+    return out

@@ -181,3 +181,23 @@ def test_captured_coarse_step_matches_eager_steps(dev):
         assert abs(a - b) < 5e-4 * abs(b), (losses_g, losses_e)
     for pa, pb in zip(model.parameters(), model2.parameters()):
         assert float((pa.detach() - pb.detach()).norm() / pa.detach().norm().clamp_min(1e-30)) < 3e-3
+
+
+@pytest.mark.parametrize("n,cap", [(1, 10), (4096, 10 ** 9), (4096, 30000), (5000, 0), (70001, 123456)])
+def test_scan_with_capacity_guard_equals_scan_then_guard(dev, n, cap):
+    """fgs_exclusive_scan_guard_i64 (one launch) == fgs_exclusive_scan_i64 followed by fgs_count_guard, bit for bit: offsets
+    cut at the capacity, flags[1] = overflow of this call, flags[0] sticky, total += min(count, capacity)."""
+    from fgs_nerf_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(n)
+    counts = torch.randint(0, 30, (n,), generator=g, dtype=torch.int64).to(dev)
+    a, b = torch.empty(n + 1, dtype=torch.int64, device=dev), torch.empty(n + 1, dtype=torch.int64, device=dev)
+    fa = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+    fb = fa.clone()
+    ta, tb = torch.tensor([11], dtype=torch.int64, device=dev), torch.tensor([11], dtype=torch.int64, device=dev)
+    for _ in range(2):                                   # twice: the sticky flag and the running total accumulate
+        call("fgs_exclusive_scan_i64", ptr(counts), n, ptr(a), stream())
+        call("fgs_count_guard", ptr(a), n + 1, cap, ptr(fa), ptr(ta), stream())
+        call("fgs_exclusive_scan_guard_i64", ptr(counts), n, ptr(b), cap, ptr(fb), ptr(tb), stream())
+        assert torch.equal(a, b) and torch.equal(fa, fb) and torch.equal(ta, tb)
+    total = int(counts.sum())
+    assert int(fb[1]) == int(total > cap) and int(b[-1]) == min(total, cap)
