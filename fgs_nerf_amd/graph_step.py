@@ -41,15 +41,21 @@ class CapturedFineStep:
     lr_of            : (iteration index, param-group dict) -> learning rate used by that iteration's Adam update
     tv               : None, or (weight, dense) for model.sdf_total_variation_add_grad after the backward pass
     capacity         : rows the survivor buffers hold (see fused.set_sync_free)
+    variants         : None, or a list of dicts {'tv': ..., 'extra_loss': callable(model) -> scalar tensor or None}: one graph
+                       per entry over the SAME static inputs, schedule table and counters, chosen per iteration by
+                       `replay(batch, variant=k)` -- iterations of different SHAPE inside one window (the shipped fine config
+                       runs the TV add-grad and the autograd smooth-gradient TV term every third iteration,
+                       model/nerf_training.py:330-371).  `tv` is variant 0 when `variants` is None.
     """
 
     def __init__(self, model, optimizer, loss_cfg: Dict, render_kwargs: Dict, n_rays: int, n_iters: int,
                  global_step_of: Callable[[int], int], lr_of: Callable[[int, Dict], float], tv=None,
-                 capacity: int = 131072):
+                 capacity: int = 131072, variants=None):
         coarse = getattr(model, 'stage', 'fine') in ('coarse', 'geometry_searching')
         if not (fused.supports_coarse(model) if coarse else fused.supports(model)):
             raise RuntimeError("CapturedFineStep needs a model the fused path covers")
-        self.model, self.opt, self.loss_cfg, self.kw, self.tv = model, optimizer, dict(loss_cfg), dict(render_kwargs), tv
+        self.model, self.opt, self.loss_cfg, self.kw = model, optimizer, dict(loss_cfg), dict(render_kwargs)
+        self.variants = [dict(v) for v in variants] if variants else [dict(tv=tv, extra_loss=None)]
         self.n_rays, self.capacity = int(n_rays), int(capacity)
         dev = model.sdf.grid.device
         self.dev = dev
@@ -75,8 +81,8 @@ class CapturedFineStep:
         self.inputs = torch.zeros(4, n_rays, 3, device=dev)
         self.rays_o, self.rays_d, self.viewdirs, self.target = self.inputs.unbind(0)
         self._seed = torch.ones((), dtype=torch.float32, device=dev)
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.loss = None
+        self.graphs = [None] * len(self.variants)
+        self.losses = [None] * len(self.variants)
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _enter(self):
@@ -89,7 +95,15 @@ class CapturedFineStep:
         fused.set_sync_free(self.model, None)
         self.opt.use_device_schedule(None)
 
-    def _body(self, update: bool):
+    @property
+    def graph(self):
+        return self.graphs[0]
+
+    @property
+    def loss(self):
+        return self.losses[0]
+
+    def _body(self, update: bool, variant: int = 0):
         # (the warm-up pass ticks too, so that it renders with a real 1/s; capture() rewinds the counter.)  The tick also
         # writes this iteration's s_val into the model's parameter (model/nerf.py:520 refreshes it in every forward).
         call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
@@ -97,17 +111,19 @@ class CapturedFineStep:
         # (global_step only selects the training branch here: 1/s comes from the device scalars)
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
+        var = self.variants[variant]
+        if var.get('extra_loss') is not None:
+            loss = loss + var['extra_loss'](self.model)
         self.opt.zero_grad(set_to_none=True)
         loss.backward(self._seed)             # (d loss / d loss given: autograd would launch a ones_like fill per step)
         if update:
-            if self.tv is not None:
-                self.model.sdf_total_variation_add_grad(self.tv[0], self.tv[1])
+            if var.get('tv') is not None:
+                self.model.sdf_total_variation_add_grad(var['tv'][0], var['tv'][1])
             self.opt.step()
         return loss
 
     def _drop_autograd_leftovers(self) -> None:
         self.model.gradient = None                 # rebuilt by (coarse) or on first read after (fine) the next forward
-        self.loss = None
 
     def capture(self, batch: Sequence[torch.Tensor]) -> None:
         """Warm up (one eager forward + backward in the sync-free form on `batch`, no update: allocator pools, cached host
@@ -120,19 +136,24 @@ class CapturedFineStep:
             # over sdf.grid) on the model between iterations: after eager iterations that node sits on the DEFAULT stream,
             # and a capture whose backward touches the default stream dies inside hipStreamEndCapture.  Drop the old graph
             # before the warm-up (its nodes are then created on the warm-up's stream) and again before the capture.
-            self._drop_autograd_leftovers()
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._body(update=False)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.opt.zero_grad(set_to_none=True)
-            self._drop_autograd_leftovers()
-            fused.reset_grid_grad(self.model)      # the warm-up's k0.grad was not consumed: the captured step starts clean
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss = self._body(update=True)
+            for k in range(len(self.variants)):
+                self.losses[k] = None
+                self._drop_autograd_leftovers()
+                side = torch.cuda.Stream(device=self.dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._body(update=False, variant=k)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.opt.zero_grad(set_to_none=True)
+                self._drop_autograd_leftovers()
+                fused.reset_grid_grad(self.model)  # the warm-up's k0.grad was not consumed: the captured step starts clean
+                self.graphs[k] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graphs[k]):
+                    # (detached: the scalar lives in the graph's pool either way, and a loss that kept its autograd graph
+                    # -- the leaves' AccumulateGrad nodes, bound to THIS capture's stream -- would reach into the next capture)
+                    self.losses[k] = self._body(update=True, variant=k).detach()
+                self._drop_autograd_leftovers()    # (the next variant's warm-up must not find this capture's autograd nodes)
         finally:
             self._leave()
         # the capture pass itself launches nothing; schedule and counters start from a clean state
@@ -151,19 +172,19 @@ class CapturedFineStep:
         self.viewdirs.copy_(vd, non_blocking=True)
         self.target.copy_(target, non_blocking=True)
 
-    def replay(self, batch: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
-        """One training iteration: (optionally) copy the batch into the static inputs, launch the graph.  Returns the
-        device scalar holding this iteration's loss (overwritten by the next replay)."""
+    def replay(self, batch: Optional[Sequence[torch.Tensor]] = None, variant: int = 0) -> torch.Tensor:
+        """One training iteration: (optionally) copy the batch into the static inputs, launch the graph (of `variant`).
+        Returns the device scalar holding this iteration's loss (overwritten by the next replay of the same variant)."""
         if batch is not None:
             self.load(batch)
-        self.graph.replay()
+        self.graphs[variant].replay()
         self.iteration += 1
         for g in self.opt.param_groups:                    # host mirror of the step counters (state_dict, schedules)
             for p in g['params']:
                 st = self.opt.state.get(p)
                 if st:
                     st['step'] += 1
-        return self.loss
+        return self.losses[variant]
 
     def clear_counters(self) -> None:
         buf = self.model._fused_cache['sync_free_buffers']

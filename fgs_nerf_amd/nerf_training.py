@@ -269,9 +269,9 @@ class TrainStepper:
         """Iterations first_step .. first_step + n_steps - 1 of the fine stage as hipGraph replays
         (graph_step.CapturedFineStep): one capture, then per iteration a batch gather + one graph launch, nothing read by the
         host.  Equivalent to calling `step()` for each of them, for windows in which the iteration's SHAPE does not change:
-        no grid rescale, no voxel increment, no autograd TV terms (`ori_tv`, smooth-gradient TV), the TV add-grad either on
-        in every iteration of the window or in none, no `decay_step_module` / `tv_updates` / `s_updates` / `smooth_updates`
-        entry inside it, one GPU.  The learning-rate decay (model/nerf_training.py:389-436) and the NeuS s_val schedule
+        no grid rescale, no voxel increment, no `ori_tv` terms, no `decay_step_module` / `tv_updates` / `s_updates` /
+        `smooth_updates` entry inside it, one GPU.  Iterations with and without the TV schedule active (sdf TV add-grad +
+        the autograd smooth-gradient TV term, every `tv_every`-th iteration) are two graphs over the same state.  The learning-rate decay (model/nerf_training.py:389-436) and the NeuS s_val schedule
         become rows of the device-resident table.  Returns (losses [n_steps] device tensor, overflowed: bool); on overflow
         (more survivors than `capacity` in some iteration: that iteration's update was skipped) the caller re-runs with a
         larger capacity or falls back to `step()`.  Per-iteration statistics are not collected in a captured window."""
@@ -290,21 +290,32 @@ class TrainStepper:
                          ('smooth_updates', self.cfg_model)):
             if any((g - 1) in cfg.get(key, {}) for g in steps):
                 raise RuntimeError(f"run_captured: a {key} entry falls inside the window")
-        tv_on = {self._tv_active(g) for g in steps}
+        # Iterations come in (at most) two shapes: plain ones, and those in which the TV schedule is active -- the sdf TV
+        # add-grad after the backward pass and the autograd smooth-gradient TV term added to the loss (:330-371; every
+        # `tv_every`-th iteration in the shipped configs).  One captured graph per shape, chosen per iteration.
         tv_terms = Cfg(ct.get('tv_terms', {}))
-        if len(tv_on) != 1:
-            raise RuntimeError("run_captured: the TV schedule switches inside the window")
-        tv_on = tv_on.pop()
-        if tv_on and (tv_terms.get('smooth_grad_tv', 0) > 0 and ct.get('weight_tv_density', 0) > 0):
-            raise RuntimeError("run_captured: the smooth-gradient TV term is an autograd loss; use step()")
-        if tv_on and ct.get('weight_tv_k0', 0) > 0:
+        tv_flags = [bool(self._tv_active(g)) for g in steps]
+        if any(tv_flags) and ct.get('weight_tv_k0', 0) > 0:
             raise RuntimeError("run_captured: TV add-grad on k0 is not part of the captured iteration; use step()")
-        dense = {g < ct.get('tv_dense_before', 0) for g in steps}
-        if tv_on and len(dense) != 1:
+        dense = {g < ct.get('tv_dense_before', 0) for g, on in zip(steps, tv_flags) if on}
+        if len(dense) > 1:
             raise RuntimeError("run_captured: tv_dense_before falls inside the window")
-        tv = None
-        if tv_on and ct.get('weight_tv_density', 0) > 0 and tv_terms.get('sdf_tv', 0) > 0:
-            tv = (ct.weight_tv_density * tv_terms.sdf_tv / ct.N_rand, dense.pop())
+        tv, extra = None, None
+        if any(tv_flags) and ct.get('weight_tv_density', 0) > 0:
+            if tv_terms.get('sdf_tv', 0) > 0:
+                tv = (ct.weight_tv_density * tv_terms.sdf_tv / ct.N_rand, dense.pop())
+            if tv_terms.get('smooth_grad_tv', 0) > 0:
+                w_tv, s_tv = ct.weight_tv_density, tv_terms.smooth_grad_tv
+                extra = lambda m: w_tv * m.density_total_variation(sdf_tv=0, smooth_grad_tv=s_tv)   # noqa: E731
+        variants = [dict(tv=None, extra_loss=None)]
+        tv_variant = 0
+        if tv is not None or extra is not None:
+            if all(tv_flags):
+                variants = [dict(tv=tv, extra_loss=extra)]
+            else:
+                variants.append(dict(tv=tv, extra_loss=extra))
+                tv_variant = 1
+        which = [tv_variant if on else 0 for on in tv_flags]
         # learning rates: iteration i runs with lr_now * prod_{j < i} decay(first_step + j)   (step() decays AFTER its update)
         factors = [1.0]
         for g in steps:
@@ -317,7 +328,7 @@ class TrainStepper:
             capacity = (int(probe['weights'].shape[0] * 1.5) + 4095) // 4096 * 4096
         cap = CapturedFineStep(model, opt, ct, self.render_kwargs, ct.N_rand, n_iters=n_steps,
                                global_step_of=lambda it: first_step + it,
-                               lr_of=lambda it, g: base_lr[id(g)] * factors[it], tv=tv, capacity=capacity)
+                               lr_of=lambda it, g: base_lr[id(g)] * factors[it], capacity=capacity, variants=variants)
         batch = (first[1], first[2], first[3], first[0])           # (rays_o, rays_d, viewdirs, target)
         self.last_result = None          # (an earlier step()'s result would keep its autograd graph -- and the leaves'
         cap.capture(batch)               # AccumulateGrad nodes, bound to the default stream -- alive across the capture)
@@ -326,7 +337,7 @@ class TrainStepper:
             if i:
                 t, ro, rd, vd = self._select_rays()
                 batch = (ro, rd, vd, t)
-            losses[i:i + 1].copy_(cap.replay(batch).detach().reshape(1))
+            losses[i:i + 1].copy_(cap.replay(batch, variant=which[i]).detach().reshape(1))
         for g in opt.param_groups:                                  # the host's copy of the schedule catches up
             g['lr'] = base_lr[id(g)] * factors[-1]
         overflow, _ = cap.check()

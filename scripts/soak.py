@@ -20,6 +20,20 @@ train = dict(N_iters=20000, N_rand=4096, lrate_k0=0.1, lrate_sdf=0.005, lrate_rg
              decay_step_module={}, skip_zero_grad_fields=['density', 'k0', 'k1'])
 st = nt.TrainStepper(model, train, {}, synth.RENDER_KWARGS, target, *rays, stage=stage, seed=0)
 torch.cuda.synchronize()
+if len(sys.argv) > 3 and sys.argv[3] == "captured":
+    # the same iterations as captured windows (TrainStepper.run_captured: two graphs, with / without the TV schedule active)
+    W = 500
+    t0 = time.perf_counter()
+    for first in range(1, iters + 1, W):
+        n = min(W, iters + 1 - first)
+        tw = time.perf_counter()
+        losses, overflow = st.run_captured(first, n)
+        torch.cuda.synchronize()
+        print(f"iters {first:6d}..{first + n - 1:6d}  {1e3 * (time.perf_counter() - tw) / n:6.3f} ms/iter (capture included)  "
+              f"loss {float(losses[-1]):.5f}  overflow {overflow}  alloc {torch.cuda.memory_allocated() / 2**30:.2f} GiB  "
+              f"reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB", flush=True)
+    print(f"total {1e3 * (time.perf_counter() - t0) / iters:6.3f} ms/iter")
+    sys.exit(0)
 t0 = time.perf_counter()
 for g in range(1, iters + 1):
     loss = st.step(g)
