@@ -330,34 +330,64 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
   // the tile's 16 VGPRs then ARE the next layer's B operand
   // the HBM copy of this output is deferred into the next layer's chunks when that layer multiplies by all of its tiles
   // (next.nch >= NTT); the last layer of the chain stores here
-  const bool defer = L.defer_store != 0;
-  s.pend_row = (defer && L.out && row_ok) ? L.out + row * L.ldo : nullptr;
-  s.pend_nstore = L.n_store;
+  // Everything layer-uniform is read ONCE into scalars here, and the per-element work below is branch-free: written with the
+  // conditions inside the unrolled loops (if (L.relu) ..., if (!defer && L.out && ...) ..., L.out + row * L.ldo per store)
+  // hipcc re-read the layer record from the kernel-argument segment and rebuilt masks and 64-bit addresses per element --
+  // behind the `memory` clobbers of the hand-issued instructions nothing is hoisted for it: 67 K cycles of epilogue per
+  // 128-sample block where the arithmetic (read, bias, max, sign bit: five vector instructions per element) needs ~35 K.
+  const bool defer = __builtin_amdgcn_readfirstlane(L.defer_store) != 0;
+  const int n_store = __builtin_amdgcn_readfirstlane(L.n_store);
+  float *const out_row = (L.out && row_ok) ? L.out + row * L.ldo : nullptr;      // this lane's output row
+  s.pend_row = defer ? out_row : nullptr;
+  s.pend_nstore = n_store;
+  float *const st_row = defer ? nullptr : out_row;
+  const float lo = __builtin_amdgcn_readfirstlane(L.relu) ? 0.f : -INFINITY;      // max(v, -inf) = v: no ReLU
   unsigned bits[4] = {0u, 0u, 0u, 0u};
-  const unsigned mb[4] = {mbits.x, mbits.y, mbits.z, mbits.w};
+  // (backward, a layer without a mask: all ones keep every element)
+  const bool has_mask = BWD && L.mask_r != nullptr;
+  const unsigned mb[4] = {has_mask ? mbits.x : ~0u, has_mask ? mbits.y : ~0u, has_mask ? mbits.z : ~0u,
+                          has_mask ? mbits.w : ~0u};
   const float *bias_l = s.ring + RC_SLOTS * RC_SLOT_FLOATS + 4 * 256 + L.bias_slot * 256 + 4 * h;
+  // (the bias values of tile t + 1 are fetched while tile t is worked on: read where they are used, each of the 4 NTT
+  // ds_read_b128 of a layer was waited for on the spot -- the compiler does not move an LDS read across the output stores)
+  float4 bn[4];
+  if (!BWD) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(bias_l + 8 * q);
+  }
 #pragma unroll
   for (int t = 0; t < NTT; ++t) {
     floatx16 v = acc[t];
+    float4 bc[4];
+    if (!BWD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bc[q] = bn[q];
+      if (t + 1 < NTT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(bias_l + 32 * (t + 1) + 8 * q);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!BWD) {
-        const float4 b = *reinterpret_cast<const float4 *>(bias_l + 32 * t + 8 * q);
+        const float4 b = bc[q];
         v[4 * q] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * q + j;
         if (!BWD) {
-          if (L.relu) v[r] = fmaxf(v[r], 0.f);
-          if (t < 8) bits[t >> 1] |= (v[r] > 0.f) ? (1u << ((t & 1) * 16 + r)) : 0u;
+          v[r] = fmaxf(v[r], lo);
+          // sign bit of a ReLU output (only layers with ReLU store their bits): v >= +0 there, so v > 0 <=> its bit pattern
+          // is non-zero -- min(pattern, 1) and a shift-or, two vector instructions without the compare's VCC round trip
+          if (t < 8) bits[t >> 1] |= min(__float_as_uint(v[r]), 1u) << ((t & 1) * 16 + r);
         } else if (t < 8) {
-          if (L.mask_r && !((mb[t >> 1] >> ((t & 1) * 16 + r)) & 1u)) v[r] = 0.f;
+          v[r] = ((mb[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? v[r] : 0.f;
         }
       }
       const int col = 32 * t + 8 * q + 4 * h;
-      if (!defer && L.out && row_ok && col < L.n_store)
-        *reinterpret_cast<float4 *>(L.out + row * L.ldo + col) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      if (st_row && col < n_store)
+        *reinterpret_cast<float4 *>(st_row + col) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
     if (t < 8) prev[t] = v;
     __builtin_amdgcn_sched_barrier(0);      // one tile at a time: 16 staging registers, not 128
