@@ -382,7 +382,10 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
           // is non-zero -- min(pattern, 1) and a shift-or, two vector instructions without the compare's VCC round trip
           if (t < 8) bits[t >> 1] |= min(__float_as_uint(v[r]), 1u) << ((t & 1) * 16 + r);
         } else if (t < 8) {
-          v[r] = ((mb[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? v[r] : 0.f;
+          // keep / zero by the saved sign bit: the bit sign-extended to a 0 / ~0 word (one bit-field extract) and an AND --
+          // a compare + select goes through an SGPR pair and its wait states
+          const int keep = (int)(mb[t >> 1] << (31 - ((t & 1) * 16 + r))) >> 31;
+          v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
         }
       }
       const int col = 32 * t + 8 * q + 4 * h;

@@ -59,3 +59,29 @@ print(f"in-kernel: shader cycles per workgroup median {cyc.median():.0f}, wall {
       f"(min {ghz.min():.3f}, max {ghz.max():.3f}); ideal MFMA cycles per pass {54 * 128 * 64} x passes {(M + 32767) // 32768}", flush=True)
 print("phases (median shader cycles per workgroup): init %.0f, chunks %.0f, epilogue %.0f, input load %.0f" %
       tuple(float(st[:, k].median()) for k in (4, 5, 6, 7)), flush=True)
+
+# the backward data-gradient chain on the same buffers (layers 6 .. 1, masks from the forward's sign bits)
+dY = torch.randn(M, 256, device=dev)
+douts = [torch.empty(M, 256, device=dev) for _ in range(6)]
+bwd_layers = [dict(W=Ws[6], mask_bits=bits[5], out=douts[0], n_store=256), dict(W=Ws[5], mask_bits=bits[4], out=douts[1], n_store=256),
+              dict(W=Ws[4][:, :256], out=douts[2], n_store=256), dict(W=Ws[3], mask_bits=bits[2], out=douts[3], n_store=256),
+              dict(W=Ws[2], mask_bits=bits[1], out=douts[4], n_store=256), dict(W=Ws[1], mask_bits=bits[0], out=douts[5], n_store=256)]
+def run_bwd(): fo.rc_chain(True, M, dY, 256, bwd_layers)
+for _ in range(20):
+    run_bwd()
+ts = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run_bwd()
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 5 * 1e3)
+print(f"M={M} backward chain median {sorted(ts)[2]:.1f} us")
+stamps.zero_()
+call("fgs_mlp_rc_debug_stamps", stamps.data_ptr())
+run_bwd()
+torch.cuda.synchronize()
+call("fgs_mlp_rc_debug_stamps", None)
+st = stamps.view(-1, 8)[:256].cpu().double()
+print("backward phases (median shader cycles per workgroup of %d): total %.0f, init %.0f, chunks %.0f, epilogue %.0f, input load %.0f" %
+      ((M + 32767) // 32768, float((st[:, 2] - st[:, 0]).median()), *(float(st[:, k].median()) for k in (4, 5, 6, 7))), flush=True)
