@@ -25,7 +25,7 @@
 //
 // Forward extras: bias is the accumulators' initial value; ReLU in registers; each layer's output goes to HBM for the
 // weight-gradient kernel (mlp_wgrad.hip); the SIGN of every ReLU input is kept as one bit per element in exactly the
-// register layout (16 bytes per lane per layer), so that the backward chain applies the ReLU mask from 16 bytes instead of
+// register layout (16 bytes per lane per layer; element e of a word at bit 31 - e), so that the backward chain applies the ReLU mask from 16 bytes instead of
 // re-reading the 512-byte-per-lane activation.
 // Backward: the same kernel on images of W^T (the pack kernel transposes), dY of the top layer loaded once from HBM, every
 // layer's dY written out for the weight-gradient kernel.
@@ -378,13 +378,15 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
         const int r = 4 * q + j;
         if (!BWD) {
           v[r] = fmaxf(v[r], lo);
-          // sign bit of a ReLU output (only layers with ReLU store their bits): v >= +0 there, so v > 0 <=> its bit pattern
-          // is non-zero -- min(pattern, 1) and a shift-or, two vector instructions without the compare's VCC round trip
-          if (t < 8) bits[t >> 1] |= min(__float_as_uint(v[r]), 1u) << ((t & 1) * 16 + r);
+          // "v > 0" of a ReLU output (only layers with ReLU store their bits): v >= +0 there, so v > 0 <=> its bit pattern p
+          // is non-zero <=> bit 31 of p + 0x7fffffff.  One add and one v_alignbit that shifts the word left and takes that
+          // bit in at the bottom: element e = 16 (t & 1) + r of a word ends up at bit 31 - e.  (Written as a compare and a
+          // select -- also what hipcc makes of min(p, 1) -- every element cost a VCC round trip with its wait states.)
+          if (t < 8) bits[t >> 1] = __builtin_amdgcn_alignbit(bits[t >> 1], __float_as_uint(v[r]) + 0x7fffffffu, 31);
         } else if (t < 8) {
           // keep / zero by the saved sign bit: the bit sign-extended to a 0 / ~0 word (one bit-field extract) and an AND --
           // a compare + select goes through an SGPR pair and its wait states
-          const int keep = (int)(mb[t >> 1] << (31 - ((t & 1) * 16 + r))) >> 31;
+          const int keep = (int)(mb[t >> 1] << ((t & 1) * 16 + r)) >> 31;      // element e sits at bit 31 - e
           v[r] = __uint_as_float(__float_as_uint(v[r]) & (unsigned)keep);
         }
       }

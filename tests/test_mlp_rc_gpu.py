@@ -61,7 +61,7 @@ def _unpack_bits(bits, M):
     out = torch.zeros(G * 32, 256, dtype=torch.bool)
     for t in range(8):
         for r in range(16):
-            word, sh = t >> 1, (t & 1) * 16 + r
+            word, sh = t >> 1, 31 - ((t & 1) * 16 + r)           # element e of a word sits at bit 31 - e (v_alignbit shift-in)
             b = ((w[:, :, word] >> sh) & 1).bool()            # [G][64]
             for h in range(2):
                 f = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3)
