@@ -234,8 +234,11 @@ __device__ __forceinline__ void rc_chunk(RcState &s, const float *__restrict__ S
     // (the chunk's vector-memory instructions stay spread over its steps, one per step: in an isolated probe --
     // scripts/diag/rc_step_probe.hip -- one burst per chunk was cheaper, 230 vs 480 idle cycles for 8 LDS-DMA pieces, but in
     // this kernel, with the pieces' address arithmetic around them, the burst form measured 1.5 % slower)
-    if (STORE_TILE >= 0 && i < 4 * 2 && (i & 1) == 1) {       // steps 1, 3, 5, 7: the four float4 of the pending tile
-      const int qs = i >> 1;
+    // the four float4 of the pending tile go out at steps HALF + 1, + 3, + 5, + 7 -- BEHIND the chunk's barrier.  On gfx9-class
+    // hardware stores count in vmcnt like loads, and the barrier's s_waitcnt vmcnt(0) waits for their write acknowledgements:
+    // issued in the first half (steps 1 .. 7) they had 2 - 3.6 K cycles to come back, from here a chunk and a half.
+    if (STORE_TILE >= 0 && i >= HALF && i < HALF + 8 && (i & 1) == 1) {
+      const int qs = (i - HALF) >> 1;
       const int col = 32 * STORE_TILE + 8 * qs + 4 * h;
       if (s.pend_row && col < s.pend_nstore)
         *reinterpret_cast<float4 *>(s.pend_row + col) = make_float4(B[4 * qs], B[4 * qs + 1], B[4 * qs + 2], B[4 * qs + 3]);
