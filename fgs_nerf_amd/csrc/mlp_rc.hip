@@ -468,21 +468,28 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
       unsigned long long tl = 0;
       if (s.timed) tl = __builtin_amdgcn_s_memtime();
       if (L.in) {
+        // the carried input of this lane's sample: 32 float4 loads issued back to back (no per-load branch: a column group
+        // beyond the buffer re-reads the row's last float4), THEN the padding columns are zeroed (they may hold anything:
+        // 0 * NaN would poison the sum)
+        const float *in_row = L.in + rowc * L.ld_in;
+        const int in_cols = __builtin_amdgcn_readfirstlane(L.in_cols), in_valid = __builtin_amdgcn_readfirstlane(L.in_valid);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int col = 32 * c + 8 * q + 4 * h;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < L.in_cols) v = *reinterpret_cast<const float4 *>(L.in + rowc * L.ld_in + col);
-            if (col + 3 >= L.in_valid) {     // padding columns of the buffer may hold anything: 0 * NaN would poison the sum
-              if (col + 1 >= L.in_valid) v.y = 0.f;
-              if (col + 2 >= L.in_valid) v.z = 0.f;
-              v.w = 0.f;
-              if (col >= L.in_valid) v.x = 0.f;
-            }
+            const float4 v = *reinterpret_cast<const float4 *>(in_row + (col < in_cols ? col : in_cols - 4));
             prev[c][4 * q] = v.x; prev[c][4 * q + 1] = v.y; prev[c][4 * q + 2] = v.z; prev[c][4 * q + 3] = v.w;
           }
+        if (in_valid < 256) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                prev[c][4 * q + i] = (32 * c + 8 * q + 4 * h + i < in_valid) ? prev[c][4 * q + i] : 0.f;
+        }
       }
       if (s.timed) s.t_load += __builtin_amdgcn_s_memtime() - tl;
       rc_layer<NTT, BWD>(s, L, rdoff, prev, A, row, rowc, row_ok, group, h);
