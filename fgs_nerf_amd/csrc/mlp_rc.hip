@@ -53,6 +53,7 @@ constexpr int RC_MAXCH = 80;          // chunks per pass over all layers
 constexpr int RC_THREADS = 256;
 constexpr int RC_SLOTS = 3;
 constexpr int RC_SLOT_FLOATS = 256 * 32;   // 256 rows x 32 columns
+constexpr int RC_SINK_FLOATS = 512;  // sink for the deferred stores of lanes without a sample: 256 floats + slack
 constexpr int RC_BLOCK = 128;         // samples per workgroup pass (4 waves x 32)
 
 struct RcLayer {
@@ -81,6 +82,7 @@ struct RcArgs {
   int n_layers, total_chunks;
   unsigned long long *stamps;              // diagnostics (fgs_mlp_rc_debug_stamps): per workgroup {s_memtime, s_memrealtime} x 2
   const float *img;
+  int64_t sink_off;                        // floats from img to the sink (RC_SINK_FLOATS of them)
   // (chunk j of the stream starts at 1 KB piece j * 4 NTT of the image and has 4 NTT pieces: every layer of a launch has the
   // same padded row count, so no per-chunk table is needed -- a table lookup per chunk was two scalar loads and an exposed
   // s_waitcnt in front of every DMA issue)
@@ -129,20 +131,32 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_rc_pack(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ the chain
+// Per-phase cycle counters (what scripts/rc_bench.py prints as "phases") cost eight scalar registers plus the stamp temporaries
+// in a kernel that has none to spare (106 of 106: two more and hipcc spills scalars to scratch -- 576 bytes per lane, everything
+// 1.85 x slower).  They are compiled in only with -DFGS_RC_PHASE_STAMPS (make rc-stamps); start / end stamps are always there.
+#ifdef FGS_RC_PHASE_STAMPS
+constexpr bool RC_PHASES = true;
+#else
+constexpr bool RC_PHASES = false;
+#endif
 struct RcState {
   const RcArgs *a;
   float *ring;
-  int64_t issued, done, total_steps;
+  float *sink;                // 1 KB of global memory nobody reads (behind the weight image)
+  int issued, done, total_steps;     // chunk counters of this workgroup (uniform, 32-bit: compared in scalar registers)
   int issue_j, issue_slot, slot, total_chunks;
   int wave, lane;
   // the chunk whose DMA is being issued piece by piece between the MFMAs of the running chunk
-  const float *dma_src;
+  const float *dma_src;       // UNIFORM base of the chunk being fetched (scalar registers); the lane's 16 bytes are dma_lane
+  unsigned dma_lane;          // lane * 16: with a uniform base the instruction takes the scalar-base form -- no vector
+                              // address arithmetic per piece (every vector instruction between the MFMAs costs matrix-pipe time)
   float *dma_dst;
   int dma_p, dma_pieces;
   // output of the layer that just finished: its tiles (now the B operands in `prev`) are written to HBM tile by tile from
   // inside the NEXT layer's chunks (a 128 KB burst per layer and workgroup is store-issue bound: ~12k idle cycles)
-  float *pend_row;            // this lane's output row (out + row * ldo), or null
-  int pend_nstore;
+  float *pend_row;            // deferred output: this lane's row + 4 h (out + row * ldo + 4 h) or the sink; the four float4 of
+                              // a pending tile sit at compile-time offsets from it
+  int pend_on;                // uniform: the layer that just finished left an output to be stored from inside these chunks
   unsigned long long t_init, t_chunks, t_epi, t_load;   // diagnostics (fgs_mlp_rc_debug_stamps): shader cycles per phase
   bool timed;
 };
@@ -152,7 +166,7 @@ template <int NTT>
 __device__ __forceinline__ void rc_dma_begin(RcState &s) {
   const RcArgs &a = *s.a;
   s.dma_pieces = 4 * NTT;
-  s.dma_src = a.img + (int64_t)s.issue_j * (4 * NTT * 256) + s.lane * 4;
+  s.dma_src = a.img + (int64_t)s.issue_j * (4 * NTT * 256);
   s.dma_dst = s.ring + s.issue_slot * RC_SLOT_FLOATS;
   s.dma_p = s.wave;
   ++s.issued;
@@ -168,7 +182,11 @@ __device__ __forceinline__ void rc_dma_piece(RcState &s) {
   const bool ok = s.dma_p < s.dma_pieces;
   const int p = ok ? s.dma_p : 0;
   float *dst = ok ? s.dma_dst + p * 256 : s.ring + RC_SLOTS * RC_SLOT_FLOATS + s.wave * 256;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s.dma_src + p * 256),
+  // (uniform base + this lane's 16-byte offset.  Issued by hand in the scalar-base form -- s_mov m0 / global_load_lds_dwordx4
+  // v_off, s[base] -- the kernel lost its register allocation: 576 bytes of scratch per lane, everything 1.85 x slower; through
+  // the builtin the address is a vector pair, one v_lshl_add_u64 per piece.)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(
+                                       reinterpret_cast<const char *>(s.dma_src + p * 256) + s.dma_lane),
                                    (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   s.dma_p += 4;
 }
@@ -239,9 +257,12 @@ __device__ __forceinline__ void rc_chunk(RcState &s, const float *__restrict__ S
     // issued in the first half (steps 1 .. 7) they had 2 - 3.6 K cycles to come back, from here a chunk and a half.
     if (STORE_TILE >= 0 && i >= HALF && i < HALF + 8 && (i & 1) == 1) {
       const int qs = (i - HALF) >> 1;
-      const int col = 32 * STORE_TILE + 8 * qs + 4 * h;
-      if (s.pend_row && col < s.pend_nstore)
-        *reinterpret_cast<float4 *>(s.pend_row + col) = make_float4(B[4 * qs], B[4 * qs + 1], B[4 * qs + 2], B[4 * qs + 3]);
+      constexpr int off = 32 * (STORE_TILE >= 0 ? STORE_TILE : 0);
+      // UNCONDITIONAL: pend_row was chosen once per layer -- this lane's output row, or (sample beyond M) a 1 KB sink behind the
+      // weight image.  A per-lane test here costs a vector compare whose result the scalar unit waits for behind whatever MFMA
+      // is in the pipe: ~100 cycles per store, four stores per chunk.
+      if (s.pend_on)
+        *reinterpret_cast<float4 *>(s.pend_row + off + 8 * qs) = make_float4(B[4 * qs], B[4 * qs + 1], B[4 * qs + 2], B[4 * qs + 3]);
     }
     if (i >= HALF) {      // issue slot k of NS sits at step HALF + k * HALF / NS (compile-time)
 #pragma unroll
@@ -310,7 +331,7 @@ template <int NTT, bool BWD>
 __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int (&rdoff)[4], floatx16 (&prev)[8],
                                          floatx4 (&A)[3], int64_t row, int64_t rowc, bool row_ok, int64_t group, int h) {
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  if (s.timed) t0 = __builtin_amdgcn_s_memtime();
+  if (RC_PHASES && s.timed) t0 = __builtin_amdgcn_s_memtime();
   floatx16 acc[NTT];
 #pragma unroll
   for (int t = 0; t < NTT; ++t)
@@ -318,11 +339,11 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   uint4 mbits = make_uint4(0u, 0u, 0u, 0u);
   if (BWD && L.mask_r) mbits = L.mask_r[group * 64 + s.lane];
-  if (s.timed) t1 = __builtin_amdgcn_s_memtime();
+  if (RC_PHASES && s.timed) t1 = __builtin_amdgcn_s_memtime();
   const int nch = __builtin_amdgcn_readfirstlane(L.nch);
   const bool has_ext = L.ext != nullptr;
   rc_chunks<NTT, BWD, 0>(s, L, nch, has_ext, rdoff, prev, acc, A, rowc, h);
-  if (s.timed) t2 = __builtin_amdgcn_s_memtime();
+  if (RC_PHASES && s.timed) t2 = __builtin_amdgcn_s_memtime();
   {   // the two operands prefetched for the next layer's first steps sit at rotation index (nch * 4 NTT) % 3: make that 0
     const int ph = (L.nch * 4 * NTT) % 3;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the hand-issued reads must have landed before they are copied)
@@ -341,8 +362,8 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
   const bool defer = __builtin_amdgcn_readfirstlane(L.defer_store) != 0;
   const int n_store = __builtin_amdgcn_readfirstlane(L.n_store);
   float *const out_row = (L.out && row_ok) ? L.out + row * L.ldo : nullptr;      // this lane's output row
-  s.pend_row = defer ? out_row : nullptr;
-  s.pend_nstore = n_store;
+  s.pend_on = (defer && L.out) ? 1 : 0;
+  s.pend_row = (out_row ? out_row : s.sink) + 4 * h;     // (whole tiles: the launcher defers only outputs of 32 NTT columns)
   float *const st_row = defer ? nullptr : out_row;
   const float lo = __builtin_amdgcn_readfirstlane(L.relu) ? 0.f : -INFINITY;      // max(v, -inf) = v: no ReLU
   unsigned bits[4] = {0u, 0u, 0u, 0u};
@@ -401,7 +422,7 @@ __device__ __forceinline__ void rc_layer(RcState &s, const RcLayer &L, const int
     __builtin_amdgcn_sched_barrier(0);      // one tile at a time: 16 staging registers, not 128
   }
   if (!BWD && L.mask_w) L.mask_w[group * 64 + s.lane] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
-  if (s.timed) {
+  if (RC_PHASES && s.timed) {
     s.t_init += t1 - t0; s.t_chunks += t2 - t1; s.t_epi += __builtin_amdgcn_s_memtime() - t2;
   }
 }
@@ -425,11 +446,11 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
     a.stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
   RcState s;
-  s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = my_blocks * a.total_chunks;
+  s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = __builtin_amdgcn_readfirstlane((int)(my_blocks * a.total_chunks));
   s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane; s.done = 0; s.total_chunks = a.total_chunks;
-  s.dma_p = 0; s.dma_pieces = 0; s.dma_src = a.img + lane * 4; s.dma_dst = ring;
-  s.pend_row = nullptr; s.pend_nstore = 0;
-  s.timed = a.stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
+  s.dma_p = 0; s.dma_pieces = 0; s.dma_src = a.img; s.dma_lane = (unsigned)lane * 16u; s.dma_dst = ring;
+  s.pend_row = nullptr; s.pend_on = 0; s.sink = const_cast<float *>(a.img) + a.sink_off;
+  s.timed = RC_PHASES && a.stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
   rc_dma<NTT>(s);
   if (s.total_steps > 1) rc_dma<NTT>(s);
   {   // bias table -> LDS, once (a layer's epilogue then reads 16 bytes per output group instead of waiting on HBM)
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
     for (int l = 0; l < a.n_layers; ++l) {
       const RcLayer &L = a.L[l];
       unsigned long long tl = 0;
-      if (s.timed) tl = __builtin_amdgcn_s_memtime();
+      if (RC_PHASES && s.timed) tl = __builtin_amdgcn_s_memtime();
       if (L.in) {
         // the carried input of this lane's sample: 32 float4 loads issued back to back (no per-load branch: a column group
         // beyond the buffer re-reads the row's last float4), THEN the padding columns are zeroed (they may hold anything:
@@ -491,7 +512,7 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
                 prev[c][4 * q + i] = (32 * c + 8 * q + 4 * h + i < in_valid) ? prev[c][4 * q + i] : 0.f;
         }
       }
-      if (s.timed) s.t_load += __builtin_amdgcn_s_memtime() - tl;
+      if (RC_PHASES && s.timed) s.t_load += __builtin_amdgcn_s_memtime() - tl;
       rc_layer<NTT, BWD>(s, L, rdoff, prev, A, row, rowc, row_ok, group, h);
     }
   }
@@ -529,7 +550,7 @@ FGS_API int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc
     const int rows = backward ? layers[l].n_in : layers[l].n_out, k = backward ? layers[l].n_out : layers[l].n_in;
     total += (int64_t)rc_round_tiles(rows) * 32 * ((k + 31) / 32) * 32;
   }
-  return total;
+  return total + RC_SINK_FLOATS;
 }
 
 FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0,
@@ -596,8 +617,10 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
     carried = rows < 256 ? rows : 256;      // what the next layer finds in the registers
   }
   for (int l = 0; l < n_layers; ++l)     // deferred stores need the next layer to walk every tile of this output
-    a.L[l].defer_store = (l + 1 < n_layers && a.L[l + 1].nch >= a.L[l].nt && !a.L[l + 1].in) ? 1 : 0;
+    a.L[l].defer_store = (l + 1 < n_layers && a.L[l + 1].nch >= a.L[l].nt && !a.L[l + 1].in &&
+                          (!a.L[l].out || a.L[l].n_store == 32 * a.L[l].nt)) ? 1 : 0;      // (deferred stores are whole tiles)
   a.total_chunks = chunk;
+  a.sink_off = need - RC_SINK_FLOATS;
   p.f4_total = f4;
   hipStream_t st = fgs_s(stream);
   hipLaunchKernelGGL(k_rc_pack, dim3(fgs_blocks(f4)), dim3(FGS_BLOCK), 0, st, p);

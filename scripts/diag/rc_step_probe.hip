@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
   for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int r = 0; r < 16; ++r) B[r] = lane * 0.01f + r;
   floatx4 A[3];
+  floatx4 stage[8];
+  for (int k = 0; k < 8; ++k) stage[k] = floatx4{0.f, 0.f, 0.f, 0.f};
   const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)ring + lane * 16;
   rd<0>(A[0], base); rd<4096>(A[1], base);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -42,7 +44,15 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
     for (int i = 0; i < 32; ++i) {
       const int q = i / 8, t = i % 8;
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE >= 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      if (MODE == 18) {
+        // register staging with EXACT waits: LDS operations return in order, so the operand read of this step has landed once
+        // at most (1 + the ds_writes issued behind it) operations are outstanding -- a flat lgkmcnt(1) also waits for the writes
+        const int w2 = (it > 0 && i - 2 >= 0 && i - 2 < 16 && ((i - 2) & 1) == 0) ? 1 : 0;
+        const int w1 = (it > 0 && i - 1 >= 0 && i - 1 < 16 && ((i - 1) & 1) == 0) ? 1 : 0;
+        if (w1 + w2 == 0) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else if (w1 + w2 == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+      } else if (MODE >= 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
       const floatx4 a = A[(MODE >= 1) ? (i + 2 * 0) % 3 : 0];
       __builtin_amdgcn_sched_barrier(0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, B[4 * q + 0], acc[t], 0, 0, 0);
@@ -85,6 +95,28 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, const float *img, un
         if (MODE == 8) { n_here = i == 16 ? 8 : 0; first = 0; }
         if (MODE == 9) { n_here = (i == 16 || i == 24) ? 4 : 0; first = i == 16 ? 0 : 4; }
         if (MODE == 12 || MODE == 13) { n_here = 0; }
+        // 14: mode 3 with the waves' pieces on DIFFERENT steps (wave parity picks even / odd steps): do the four lock-stepped
+        // waves of a CU queue up behind one another at the texture-address unit?   15: mode 3 launched with ONE wave per CU
+        if (MODE == 14) { n_here = (i >= 16 && ((i + wave) & 1) == 0 && i - (wave & 1) < 32) ? 1 : 0; first = (i - 16) >> 1; }
+        if (MODE == 15) { n_here = (i >= 16 && (i & 1) == 0) ? 1 : 0; first = (i - 16) >> 1; }
+        // 16: pieces spread over all four quarter positions: wave w issues at steps 16 + 2 k + (w & 1), waves 2, 3 one MFMA later
+        if (MODE == 16) { n_here = (i >= 16 && ((i + wave) & 1) == 0) ? 1 : 0; first = (i - 16) >> 1; }
+        // 17: register staging -- a plain global_load_dwordx4 per piece at the even steps of the second half (as 12) and, one
+        // chunk later, a ds_write_b128 of what arrived at the even steps of the FIRST half (vmcnt waited before the first)
+        if (MODE == 17 || MODE == 18) {
+          if (i >= 16 && (i & 1) == 0) {
+            const int k = (i - 16) >> 1;
+            const int p = (wave + 4 * k) & 31;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stage[k]) : "v"(src + p * 256) : "memory");
+          }
+          if (i < 16 && (i & 1) == 0 && it > 0) {
+            const int k = i >> 1;
+            const int p = (wave + 4 * k) & 31;
+            if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned da = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)(dst + p * 256) + lane * 16;
+            asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(stage[k]) : "memory");
+          }
+        }
         if ((MODE == 12 || MODE == 13) && i >= 16 && (i & 1) == 0) {
           const int p = (wave + 4 * ((i - 16) >> 1)) & 31;
           const float *gp = src + p * 256;
@@ -127,7 +159,7 @@ int main() {
   float *wbuf; (void)hipMalloc(&wbuf, 256 * 8192 * 4 + 65536);
   const int iters = 540;
   unsigned long long h[256];
-  for (int mode = 0; mode < 14; ++mode) {
+  for (int mode = 0; mode < 19; ++mode) {
     for (int rep = 0; rep < 3; ++rep) {
       if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
@@ -143,6 +175,11 @@ int main() {
       if (mode == 11) hipLaunchKernelGGL(probe<11>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 12) hipLaunchKernelGGL(probe<12>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
       if (mode == 13) hipLaunchKernelGGL(probe<13>, dim3(256), dim3(256), 0, 0, out, (const float *)wbuf, cyc, iters);
+      if (mode == 18) hipLaunchKernelGGL(probe<18>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 17) hipLaunchKernelGGL(probe<17>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 14) hipLaunchKernelGGL(probe<14>, dim3(256), dim3(256), 0, 0, out, img, cyc, iters);
+      if (mode == 15) hipLaunchKernelGGL(probe<15>, dim3(256), dim3(64), 0, 0, out, img, cyc, iters);
+      if (mode == 16) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(128), 0, 0, out, img, cyc, iters);
       (void)hipDeviceSynchronize();
     }
     (void)hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost);
