@@ -185,8 +185,10 @@ __device__ __forceinline__ void rc_dma_piece(RcState &s) {
   // (uniform base + this lane's 16-byte offset.  Issued by hand in the scalar-base form -- s_mov m0 / global_load_lds_dwordx4
   // v_off, s[base] -- the kernel lost its register allocation: 576 bytes of scratch per lane, everything 1.85 x slower; through
   // the builtin the address is a vector pair, one v_lshl_add_u64 per piece.)
+  unsigned lane_off = s.dma_lane;
+  asm volatile("" : "+v"(lane_off));      // (opaque: keeps hipcc from folding the lane offset into a 64-bit vector base)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(
-                                       reinterpret_cast<const char *>(s.dma_src + p * 256) + s.dma_lane),
+                                       reinterpret_cast<const char *>(s.dma_src + p * 256) + lane_off),
                                    (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   s.dma_p += 4;
 }
