@@ -150,15 +150,19 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const int wr = pos / NWC, wc = pos % NWC;
   const int row_base = wr * RT * 32, colp_base = wc * CT * 32;     // first row of the wave / first panel column
   // chunk range of this workgroup
-  const int64_t NC = (M + WG_ROWS - 1) / WG_ROWS;
+  // (chunk indices and the row count as 32-bit SCALARS: M < 2^31 is checked by the launcher.  As 64-bit values -- the shares
+  // below come out of floating-point arithmetic, i.e. out of vector registers -- every loop test was a vector compare whose
+  // result the scalar branch had to wait for behind the MFMA in the pipe)
+  const int Mi = __builtin_amdgcn_readfirstlane((int)M);
+  const int NC = (Mi + WG_ROWS - 1) / WG_ROWS;
   // Staggered shares: workgroup j of n takes the chunks [NC F(j / n), NC F((j + 1) / n)), F(x) = (1 - a) x + a x^2 -- the
   // first a few per cent fewer than the last.  With equal shares all 256 workgroups reach the flush together and the memory-
   // side atomic units, idle until then, become the bottleneck for the last ~40 us (64 MB of fp32 atomics); staggered, the
   // early finishers' atomics run under the matrix work of the others.
   const double xa = (double)j_in_block / b.n_wg, xb = (double)(j_in_block + 1) / b.n_wg;
   const double sa = b.stagger;
-  const int64_t c0 = j_in_block == 0 ? 0 : (int64_t)((double)NC * ((1.0 - sa) * xa + sa * xa * xa));
-  const int64_t c1 = j_in_block + 1 == b.n_wg ? NC : (int64_t)((double)NC * ((1.0 - sa) * xb + sa * xb * xb));
+  const int c0 = __builtin_amdgcn_readfirstlane(j_in_block == 0 ? 0 : (int)((double)NC * ((1.0 - sa) * xa + sa * xa * xa)));
+  const int c1 = __builtin_amdgcn_readfirstlane(j_in_block + 1 == b.n_wg ? NC : (int)((double)NC * ((1.0 - sa) * xb + sa * xb * xb)));
   if (c0 >= c1) return;
   const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
@@ -168,29 +172,27 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const unsigned va0 = wave * ld_a4 + lane * 16;
   const unsigned col0_4 = (unsigned)b.col0 * 4u;
   const unsigned step_a = 4 * ld_a4;
-  const int64_t bytes_a = M * (int64_t)ld_a4, bytes_b = M * (int64_t)ld_b4;
+  // (limits from 32-bit row counts: the scalar unit has no 64-bit signed compare, so `bytes - 16 - offset < 2^31` on uniform
+  // 64-bit values became vector compares inside the loop.  A limit only has to cover the 16 rows of a chunk: rows are capped.)
+  constexpr int ROW_CAP = 1 << 16;                 // x row pitch (<= 1280 bytes) stays below 2^31
   WgDma d;
-  int64_t issue_c = c0;
+  int issue_c = c0;
   int issue_slot = 0;
   auto dma_begin = [&]() __attribute__((always_inline)) {
-    if (issue_c < c1) {
-      const int64_t oa = issue_c * WG_ROWS * (int64_t)ld_a4, ob = issue_c * WG_ROWS * (int64_t)ld_b4;
-      const int64_t la = bytes_a - 16 - oa, lb = bytes_b - 16 - ob;          // >= 0: the chunk's first row exists
-      d.base_a = (const char *)b.dY + oa; d.base_b = (const char *)b.X + ob;
-      d.lim_a = la < 0x7fffffff ? (unsigned)la : 0x7fffffffu; d.lim_b = lb < 0x7fffffff ? (unsigned)lb : 0x7fffffffu;
-      d.dst = lds + issue_slot * SLOT;
-    } else {
-      d.base_a = (const char *)b.dY; d.base_b = (const char *)b.X;
-      d.lim_a = (unsigned)(bytes_a - 16 < 0x7fffffff ? bytes_a - 16 : 0x7fffffff);
-      d.lim_b = (unsigned)(bytes_b - 16 < 0x7fffffff ? bytes_b - 16 : 0x7fffffff);
-      d.dst = lds + issue_slot * SLOT;
-    }
+    const int first = issue_c < c1 ? issue_c * WG_ROWS : 0;           // first sample row the pieces address
+    int rows = Mi - first;                                           // >= 1: that row exists
+    rows = rows < ROW_CAP ? rows : ROW_CAP;
+    d.base_a = (const char *)b.dY + (int64_t)first * ld_a4;
+    d.base_b = (const char *)b.X + (int64_t)first * ld_b4;
+    d.lim_a = (unsigned)rows * ld_a4 - 16u;
+    d.lim_b = (unsigned)rows * ld_b4 - 16u;
+    d.dst = lds + issue_slot * SLOT;
     ++issue_c;
     issue_slot = issue_slot + 1 == WG_NS ? 0 : issue_slot + 1;
   };
   // rows of chunk c beyond M are zeroed in its slot (after it landed, before anybody reads it); uniform per workgroup
-  auto zero_tail = [&](int64_t c, int slot_of_c) __attribute__((always_inline)) {
-    const int rows_left = (int)(M - c * WG_ROWS);
+  auto zero_tail = [&](int c, int slot_of_c) __attribute__((always_inline)) {
+    const int rows_left = Mi - c * WG_ROWS;
     if (rows_left >= WG_ROWS) return;
     float *S = lds + slot_of_c * SLOT;
     for (int i = rows_left * 256 + tid; i < WG_ROWS * 256; i += WG_THREADS) S[i] = 0.f;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
 #pragma unroll
     for (int t = 0; t < CT; ++t) fb[0][t] = S[offB + 32 * t];
   }
-  for (int64_t c = c0; c < c1; ++c) {
+  for (int c = c0; c < c1; ++c) {
     const float *S = lds + slot * SLOT;
     const int slot_next = slot + 1 == WG_NS ? 0 : slot + 1;
     const float *S_next = lds + slot_next * SLOT;
