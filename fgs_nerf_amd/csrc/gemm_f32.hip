@@ -22,6 +22,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4n __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDK = 36;   // floats per staged row of a K-contiguous operand
@@ -55,9 +56,42 @@ __device__ __forceinline__ float4 ld4_guard(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// CLAMP: the caller guarantees that every k of the chunk exists (K a multiple of BK); rows / indices beyond the operand are
+// CLAMPED to its last row / last float4 instead of guarded -- what they feed are accumulator rows / columns the epilogue never
+// stores.  No per-load test: a guarded load is a 64-bit vector compare, an exec-mask round trip through the scalar unit (which
+// waits for the compare behind whatever MFMA is in the pipe) and a select, eight times per chunk.
 template <bool KC>
+__device__ __forceinline__ void stage_load_clamped(Stage<KC> &s, const float *__restrict__ base, int64_t ld, int64_t row0,
+                                                   int64_t n_rows, int64_t k0, int tid) {
+  if (KC) {
+    const int k4 = tid & 7;
+    const int last = (int)n_rows - 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = (int)row0 + (tid >> 3) + 32 * p;
+      r = r < last ? r : last;
+      const floatx4n t = *reinterpret_cast<const floatx4n *>(base + (int64_t)r * ld + k0 + 4 * k4);
+      s.v[p] = make_float4(t.x, t.y, t.z, t.w);      // (element-wise: a float4 struct copy kept the staging arrays in scratch)
+    }
+  } else {
+    const int i4 = tid & 31;
+    int i = (int)row0 + 4 * i4;
+    i = i < (int)n_rows - 4 ? i : (int)n_rows - 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const floatx4n t = *reinterpret_cast<const floatx4n *>(base + (k0 + (tid >> 5) + 8 * p) * ld + i);
+      s.v[p] = make_float4(t.x, t.y, t.z, t.w);
+    }
+  }
+}
+
+template <bool KC, bool CLAMP = false>
 __device__ __forceinline__ void stage_load(Stage<KC> &s, const float *__restrict__ base, int64_t ld, int64_t row0,
                                            int64_t n_rows, int64_t k0, int64_t k_end, int tid) {
+  if constexpr (CLAMP) {
+    stage_load_clamped<KC>(s, base, ld, row0, n_rows, k0, tid);
+    return;
+  } else {
   if (KC) {
     // element (row0 + r, k0 + 4*k4 ..)
     const int k4 = tid & 7;
@@ -76,6 +110,7 @@ __device__ __forceinline__ void stage_load(Stage<KC> &s, const float *__restrict
       const int64_t k = k0 + (tid >> 5) + 8 * p;
       s.v[p] = ld4_guard(base + k * ld + i, k < k_end && i < n_rows);
     }
+  }
   }
 }
 
@@ -142,7 +177,7 @@ __device__ __forceinline__ void acc_zero(floatx16 (&acc)[2][2]) {
 // epilogue of a data-gradient tile took 23 us on average (10..46) next to a 32 us main loop.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool CLAMP = false>
 __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
                                               floatx16 (&acc)[2][2], LdsImage &lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,14 +192,14 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
   Stage<A_KC> sa;
   Stage<B_KC> sb;
   const int ia0 = wave_m * 64 + l31, ib0 = wave_n * 64 + l31;
-  const int64_t n_chunks = (k_end - k_begin + BK - 1) / BK;
-  stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin, k_end, tid);
-  stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin, k_end, tid);
+  const int n_chunks = (int)((k_end - k_begin + BK - 1) / BK);      // (32-bit: loop tests stay on the scalar unit)
+  stage_load<A_KC, CLAMP>(sa, g.A, g.lda, m0, g.M, k_begin, k_end, tid);
+  stage_load<B_KC, CLAMP>(sb, g.B, g.ldb, n0, g.N, k_begin, k_end, tid);
   stage_store<A_KC>(sa, lds[0][0], tid);
   stage_store<B_KC>(sb, lds[0][1], tid);
   if (n_chunks > 1) {
-    stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin + BK, k_end, tid);
-    stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin + BK, k_end, tid);
+    stage_load<A_KC, CLAMP>(sa, g.A, g.lda, m0, g.M, k_begin + BK, k_end, tid);
+    stage_load<B_KC, CLAMP>(sb, g.B, g.ldb, n0, g.N, k_begin + BK, k_end, tid);
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -174,14 +209,14 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
     half_load<A_KC>(f0a[t], lds[0][0], ia0 + t * 32, h, 0);
     half_load<B_KC>(f0b[t], lds[0][1], ib0 + t * 32, h, 0);
   }
-  for (int64_t c = 0; c < n_chunks; ++c) {
-    const int cur = (int)(c & 1);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int cur = c & 1;
     if (c + 1 < n_chunks) {
       stage_store<A_KC>(sa, lds[cur ^ 1][0], tid);
       stage_store<B_KC>(sb, lds[cur ^ 1][1], tid);
       if (c + 2 < n_chunks) {
-        stage_load<A_KC>(sa, g.A, g.lda, m0, g.M, k_begin + (c + 2) * BK, k_end, tid);
-        stage_load<B_KC>(sb, g.B, g.ldb, n0, g.N, k_begin + (c + 2) * BK, k_end, tid);
+        stage_load<A_KC, CLAMP>(sa, g.A, g.lda, m0, g.M, k_begin + (c + 2) * BK, k_end, tid);
+        stage_load<B_KC, CLAMP>(sb, g.B, g.ldb, n0, g.N, k_begin + (c + 2) * BK, k_end, tid);
       }
     }
 #pragma unroll
@@ -257,31 +292,31 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int
   const bool col_ok = col < g.N;  // N % 4 == 0 on every path that reaches here
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.bias && col_ok) bv = *reinterpret_cast<const float4 *>(g.bias + col);
-  float4 mk[16];
-  if (g.mask) {
+  // Rows: one uniform test per tile (all 128 rows exist, true for every tile but the last row tile) instead of sixteen per-lane
+  // ones -- each a 64-bit vector compare and an exec mask held in scalar registers across the loads: the guarded form alone
+  // kept this kernel at 106 scalar registers with 156 more spilled.  Columns: one per-lane test around everything.
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool rows_full = m0 + BM <= g.M;
+  if (col_ok) {
+    float *crow = g.C + (m0 + (tid >> 5)) * g.ldc + col;
+    const float *mrow = g.mask ? g.mask + (m0 + (tid >> 5)) * g.ldm + col : nullptr;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
-      const int64_t row = m0 + (tid >> 5) + 8 * p;
-      mk[p] = (col_ok && row < g.M) ? *reinterpret_cast<const float4 *>(g.mask + row * g.ldm + col) : make_float4(0, 0, 0, 0);
+      const int rl = (tid >> 5) + 8 * p;
+      if (!rows_full && m0 + rl >= g.M) continue;
+      float4 v = *reinterpret_cast<const float4 *>(ct + rl * LDC + 4 * c4);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (mrow) {
+        const float4 mkp = *reinterpret_cast<const float4 *>(mrow + (int64_t)8 * p * g.ldm);
+        if (!(mkp.x > 0.f)) v.x = 0.f;
+        if (!(mkp.y > 0.f)) v.y = 0.f;
+        if (!(mkp.z > 0.f)) v.z = 0.f;
+        if (!(mkp.w > 0.f)) v.w = 0.f;
+      }
+      *reinterpret_cast<float4 *>(crow + (int64_t)8 * p * g.ldc) = v;
+      cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
     }
-  }
-  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int rl = (tid >> 5) + 8 * p;
-    const int64_t row = m0 + rl;
-    if (!(col_ok && row < g.M)) continue;
-    float4 v = *reinterpret_cast<const float4 *>(ct + rl * LDC + 4 * c4);
-    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (g.mask) {
-      if (!(mk[p].x > 0.f)) v.x = 0.f;
-      if (!(mk[p].y > 0.f)) v.y = 0.f;
-      if (!(mk[p].z > 0.f)) v.z = 0.f;
-      if (!(mk[p].w > 0.f)) v.w = 0.f;
-    }
-    *reinterpret_cast<float4 *>(g.C + row * g.ldc + col) = v;
-    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
   }
   if (g.colsum) {  // 8 threads (tid >> 5) share a column quad: reduce through LDS, one atomic per column
     lds_barrier();
@@ -298,7 +333,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int
 }
 
 // One workgroup per output tile (EPI_STORE) or per (tile, K slice) (EPI_ATOMIC).
-template <bool A_KC, bool B_KC, int EPI>
+template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false>
 __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &lds) {
   // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
   int tile_m, tile_n;
@@ -323,15 +358,19 @@ __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &l
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   floatx16 acc[2][2];
   acc_zero(acc);
-  tile_mainloop<A_KC, B_KC>(g, m0, n0, k_begin, k_end, acc, lds);
+  tile_mainloop<A_KC, B_KC, CLAMP>(g, m0, n0, k_begin, k_end, acc, lds);
   tile_epilogue<EPI>(g, m0, n0, acc, lds);
 }
 
-template <bool A_KC, bool B_KC, int EPI>
+// CLAMP (chosen by the launcher for store-epilogue products with K a multiple of 32 and, for an index-contiguous B, N a
+// multiple of 4): operand loads without guards, see stage_load.  A kernel of its own: the guarded main loop keeps ~16 exec
+// masks and 64-bit row bounds alive in scalar registers -- 106 used and 156 more spilled to vector lanes in the guarded
+// instantiation -- and both loops in one kernel pushed the spills to scratch.
+template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) LdsImage lds;
   if (EPI != EPI_ATOMIC) g.M = fgs_rows(g.M, g.m_dev);       // row tiles beyond the device-side count return at once
-  gemm_block<A_KC, B_KC, EPI>(g, (int)blockIdx.x, lds);
+  gemm_block<A_KC, B_KC, EPI, CLAMP>(g, (int)blockIdx.x, lds);
 }
 
 // Backward of one Linear layer in ONE launch: the data-gradient product (NN, store epilogue with ReLU mask / column sums)
@@ -451,7 +490,10 @@ template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
   const unsigned groups = (unsigned)((g.tiles_m + 7) / 8);
   dim3 grid(EPI == EPI_ATOMIC ? (unsigned)(g.tiles_m * g.tiles_n) * splits : groups * 8 * (unsigned)g.tiles_n, 1, 1);
-  hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI>), grid, dim3(256), 0, st, g);
+  if (EPI == EPI_STORE && (g.K % BK) == 0 && (B_KC || ((g.N & 3) == 0 && g.N >= 4)) && g.M >= 1)
+    hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, EPI == EPI_STORE>), grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, false>), grid, dim3(256), 0, st, g);
   FGS_LAUNCH_OK("fgs_gemm_f32");
   return 0;
 }
