@@ -290,11 +290,13 @@ def main():
     averager = GradAverager(model.parameters(), force=force_dist)
     averager.attach(model)          # gradients are handed to the exchange from inside the backward pass (N > 1)
     averager.attach_optimizer(opt)  # ... and the optimizer waits for k0's exchange only when it reaches k0
-    if not args.composed and os.environ.get("FGS_EARLY_ADAM", "1" if (world > 1 or force_dist) else "0") == "1":
-        # N > 1: k0's Adam pass follows its gradient exchange on the exchange stream, beside the rest of the backward pass
-        # (no TV on k0 in this step).  On one GPU it only competes with the scatter kernels for HBM: 2.33 vs 2.32 ms, off.
+    early_adam = os.environ.get("FGS_EARLY_ADAM", "1")
+    if not args.composed and early_adam == "1":
+        # k0's Adam pass is issued from inside the backward pass, right behind the feature-grid scatter (no TV on k0 in this
+        # step).  N > 1: on the exchange stream, behind k0's gradient exchange.  One GPU: in place on the backward pass's own
+        # stream, i.e. beside the weight-gradient launch of the side branch instead of at the end of the step behind it.
         from fgs_nerf_amd import fused
-        fused.enable_early_update(model, opt, averager)
+        fused.enable_early_update(model, opt, averager, inline=not (world > 1 or force_dist))
     n_global = RAYS_PER_GPU * world
 
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)

@@ -121,6 +121,23 @@ class MaskedAdam(torch.optim.Optimizer):
 
     def _update_one(self, p, g, group):
         """The reference's per-tensor rule (model/adam.py:205-221) for one big tensor."""
+        if self._dev is not None:             # captured step: step size and skip flag come from device memory
+            from ._lib import ptr
+            dev = self._dev
+            gi = next(i for i, gr in enumerate(self.param_groups) if gr is group)
+            ss_ptr = dev['ss'][gi]
+            st = self._state_of(p)
+            g = _as_layout_of(g, p)
+            if self._bricks(p, g, group, st, dev=dev, ss_ptr=ss_ptr):
+                return
+            b1, b2 = group['betas']
+            if self.per_lr is not None and p.shape == self.per_lr.shape:
+                mode, perlr = 2, _as_layout_of(self.per_lr, p)
+            else:
+                mode, perlr = (1 if group['skip_zero_grad'] else 0), None
+            call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), ptr(perlr), p.numel(), ss_ptr,
+                 float(b1), float(b2), float(group['eps']), mode, dev['skip'], stream())
+            return
         b1, b2 = group['betas']
         hyper = (b1, b2, group['lr'], group['eps'])
         st = self._state_of(p)
@@ -150,8 +167,11 @@ class MaskedAdam(torch.optim.Optimizer):
             return False
         if on_stream is not None:
             self._update_one(p, grad, group)
-            done = torch.cuda.Event()
-            done.record()
+            if on_stream == 'inline':          # the caller's stream IS the stream step() runs on: ordered by issue
+                done = None
+            else:
+                done = torch.cuda.Event()
+                done.record()
         else:
             if self._early_stream is None:
                 self._early_stream = torch.cuda.Stream(device=p.device, priority=-1)
@@ -170,13 +190,14 @@ class MaskedAdam(torch.optim.Optimizer):
         """step() with the device-resident schedule (see use_device_schedule): same kernels, same per-tensor rule."""
         from ._lib import ptr
         dev = self._dev
+        early, self._early = self._early, {}
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group['betas']
             ss_ptr = dev['ss'][gi]
             masked = group['skip_zero_grad']
             small = []
             for p in group['params']:
-                if p.grad is None:
+                if p.grad is None or id(p) in early:    # already updated by early_update()
                     continue
                 st = self._state_of(p)
                 g = _as_layout_of(p.grad, p)
@@ -193,6 +214,9 @@ class MaskedAdam(torch.optim.Optimizer):
                 call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(m), ptr(v), ptr(perlr), p.numel(), ss_ptr, float(b1), float(b2),
                      float(group['eps']), mode, dev['skip'], stream())
             self._flush_small(small, b1, b2, group['eps'], dev=dev, ss_ptr=ss_ptr)
+        for done in early.values():
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
 
     @torch.no_grad()
     def step(self):
@@ -225,4 +249,5 @@ class MaskedAdam(torch.optim.Optimizer):
                     adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
             self._flush_small(small, b1, b2, group['eps'])
         for done in early.values():                     # everything after step() sees the early updates
-            torch.cuda.current_stream().wait_event(done)
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)

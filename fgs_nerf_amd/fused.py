@@ -1254,7 +1254,7 @@ def _own_workspace(run, needs_grad: bool) -> None:
         run.workspace['owner'] = weakref.ref(run)
 
 
-def enable_early_update(model, optimizer, averager=None) -> None:
+def enable_early_update(model, optimizer, averager=None, inline: bool = False) -> None:
     """Let `optimizer` (MaskedAdam) update the feature grid from inside the fused backward pass, right after the grid's
     gradient is final -- on several GPUs right after that gradient's exchange, on the exchange stream.  The ~45 us Adam
     pass over k0 (and the wait for its exchange) then leave the end of the step.  Only for steps in which nothing else
@@ -1262,6 +1262,11 @@ def enable_early_update(model, optimizer, averager=None) -> None:
     cache = model.__dict__.setdefault('_fused_cache', {})
     if averager is not None and (averager.world_size > 1 or averager.force):
         averager.after_early = lambda p, g: optimizer.early_update(p, g, on_stream=True)
+    elif inline:
+        # one GPU: issued in place, on the backward pass's own stream, right behind the feature-grid scatter and the voxel
+        # marking -- i.e. beside the weight-gradient launch running on the side branch (_wgrad), instead of at the end of the
+        # step behind it.  (On a stream of its own, high priority, the same pass made every kernel of a captured step slower.)
+        cache['opt_hook'] = lambda p, g: optimizer.early_update(p, g, on_stream='inline')
     else:
         cache['opt_hook'] = optimizer.early_update
 

@@ -242,3 +242,55 @@ def test_scan_with_capacity_guard_equals_scan_then_guard(dev, n, cap):
         assert torch.equal(a, b) and torch.equal(fa, fb) and torch.equal(ta, tb)
     total = int(counts.sum())
     assert int(fb[1]) == int(total > cap) and int(b[-1]) == min(total, cap)
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_inline_early_k0_update_matches_the_update_in_step(dev, captured):
+    """fused.enable_early_update(inline=True) -- k0's Adam pass issued from inside the backward pass, right behind the
+    feature-grid scatter, beside the weight-gradient launch -- against the same iterations with every update in opt.step():
+    eager (host schedule) and captured (device schedule: step size and skip flag read from device memory).  One step from the
+    same state: k0 and its moments agree to the float-atomics order of k0.grad; several steps: parameters in norm; the optimizer's
+    step counters advance once per iteration either way."""
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.graph_step import CapturedFineStep
+    from fgs_nerf_amd.losses import fused_render_losses
+    N, ITERS, TV = 512, 3, (0.01 * 0.1 / 512, True)
+    runs = {}
+    for early in (False, True):
+        model, opt, batches = _setup(dev)
+        if early:
+            fused.enable_early_update(model, opt, None, inline=True)
+        if captured:
+            base = {id(g): g['lr'] for g in opt.param_groups}
+            step = CapturedFineStep(model, opt, synth.FINE_LOSS, synth.RENDER_KWARGS, N, n_iters=ITERS,
+                                    global_step_of=lambda it: 1000 + it, lr_of=lambda it, g: base[id(g)], tv=TV, capacity=8192)
+            step.capture(batches[0])
+            snaps = []
+            for it in range(ITERS):
+                step.replay(batches[it % 3])
+                if it == 0:
+                    torch.cuda.synchronize()
+                    snaps = [model.k0.grid.detach().clone(), opt.state[model.k0.grid]['exp_avg'].clone()]
+            assert not step.check()[0]
+        else:
+            snaps = []
+            for it in range(ITERS):
+                ro, rd, vd, target = batches[it % 3]
+                res = model(ro, rd, vd, global_step=1000 + it, **synth.RENDER_KWARGS)
+                loss = fused_render_losses(res, target, synth.FINE_LOSS, model)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                model.sdf_total_variation_add_grad(*TV)
+                opt.step()
+                if it == 0:
+                    snaps = [model.k0.grid.detach().clone(), opt.state[model.k0.grid]['exp_avg'].clone()]
+        torch.cuda.synchronize()
+        runs[early] = (snaps, [p.detach().clone() for p in model.parameters()], [st['step'] for st in opt.state.values()])
+        fused.disable_early_update(model)
+    for a, b in zip(runs[False][0], runs[True][0]):          # after ONE step from the same state
+        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) < 2e-5
+    # (several steps of two runs whose gradients are summed with float atomics: Adam's first updates are ~lr * sign(g), so a
+    # near-zero bias gradient that flips sign moves that entry by 2 lr -- 2.3e-3 of a bias vector's norm has been seen)
+    for pa, pb in zip(runs[False][1], runs[True][1]):
+        assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 5e-3
+    assert runs[False][2] == runs[True][2] and set(runs[True][2]) == {ITERS}
