@@ -827,16 +827,22 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
                               float *g_sdf, float *g_gradient, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_fine_bwd: M=%lld", (long long)M);
   if (M == 0) return 0;
+  // k0_grad_grid == NULL: only the encoding part (g_sdf / g_gradient);  g_sdf == g_gradient == NULL: only the k0 scatter -- the two
+  // kernels are independent, and the training step issues them on either side of its weight-gradient fork (fused.py)
   FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && Zbuf && dX0 &&
-                  dZ && sdf_grad_grid && k0_grad_grid && g_sdf && g_gradient, FGS_E_INVALID, "fgs_feat_fine_bwd: null pointer");
+                  dZ && (k0_grad_grid || (g_sdf && g_gradient)) && (!g_sdf == !g_gradient), FGS_E_INVALID,
+              "fgs_feat_fine_bwd: null pointer");
   SurvArgs S;
   S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
-  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
-  FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
+  if (k0_grad_grid) {
+    hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+    FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
+  }
+  if (!g_gradient) return 0;
 #define FGS_ENC_BWD(F) hipLaunchKernelGGL(k_feat_enc_bwd<F>, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, Zbuf, dX0, dZ, g_normal, g_sdf, g_gradient)
   switch (S.L.n_reffreq) {      // the shipped configs' frequency counts (config/shiny_blender.py: 3 / 5 / 8) unrolled
     case 3: FGS_ENC_BWD(3); break;

@@ -396,6 +396,10 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
 # captured step the fork / join become graph edges.  Not with a gradient exchange attached (the MLP gradients are exchanged
 # from inside the backward pass there).
 _WGRAD_FORK = os.environ.get("FGS_WGRAD_FORK", "1") == "1"
+# FGS_MARCH_FIRST=1: the vector-bound kernels of the sdf path (encoding backward, march backward) are issued BEFORE the fork and
+# only the memory-bound ones beside the weight-gradient launch.  Measured 1.89-1.90 ms/step against 1.87 for the default order
+# (the LDS-atomic sdf scatter, then under the matrix kernel for its whole length, costs it more than the march kernel saves).
+_MARCH_FIRST = os.environ.get("FGS_MARCH_FIRST", "0") == "1"
 _SIDE_PENDING = set()
 
 
@@ -882,8 +886,11 @@ class _FusedFine(torch.autograd.Function):
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
-        if wgrad is not None and hook is None:
-            wgrad(True)                          # one GPU: on a side stream, beside the scatter kernels below
+        # One GPU: the weight-gradient launch is forked off here and everything below runs beside it (_MARCH_FIRST: the two
+        # vector-bound kernels of the sdf path first, see there).
+        march_first = wgrad is not None and hook is None and _MARCH_FIRST
+        if wgrad is not None and hook is None and not march_first:
+            wgrad(True)                          # on a side stream, beside everything below
             wgrad = None
 
         # 5. features -> grids
@@ -898,9 +905,28 @@ class _FusedFine(torch.autograd.Function):
         tot_sdf = torch.empty(M, dtype=F32, device=dev)
         tot_grad = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
-        call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
-             g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
-             ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0), ksC, ksX, ksY, ksZ, ptr(g_sdf_s), ptr(g_grad_s), st)
+
+        def feat_bwd(k0_part: bool, enc_part: bool):
+            call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
+                 g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
+                 ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0) if k0_part else None, ksC, ksX, ksY, ksZ,
+                 ptr(g_sdf_s) if enc_part else None, ptr(g_grad_s) if enc_part else None, st)
+
+        def march_bwd():
+            call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
+                 g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
+                 ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
+                 ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
+                 ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), st)
+
+        if march_first:
+            feat_bwd(False, True)
+            march_bwd()
+            wgrad(True)
+            wgrad = None
+            feat_bwd(True, False)
+        else:
+            feat_bwd(True, True)
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:
             # the exchanges, in the order EVERY path of every rank issues them (k0, mlp, join: _backward_empty too): k0's is
@@ -913,11 +939,8 @@ class _FusedFine(torch.autograd.Function):
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)           # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
-        call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
-             g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
-             ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
-             ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
-             ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), st)
+        if not march_first:
+            march_bwd()
         # 7. every sdf.grad contribution of the survivors (24 taps + centre + six +/-1 taps), combined on chip
         call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
              run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)

@@ -418,7 +418,8 @@ int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts, const 
                       const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *X0, float *Zbuf,
                       float *normal_out, fgs_stream_t stream);
 /* Backward: scatter-adds into sdf_grad_grid and k0_grad_grid, writes g_sdf [M] and g_gradient [M,3] for
- * fgs_march_fine_bwd.  g_normal [M,3] (direct gradient on the `normal` output) may be NULL. */
+ * fgs_march_fine_bwd.  g_normal [M,3] (direct gradient on the `normal` output) may be NULL.  The k0 scatter and the encoding
+ * part are independent kernels: k0_grad_grid == NULL issues only the latter, g_sdf == g_gradient == NULL only the former. */
 int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *sdf, const float *gradient,
                       const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z,
                       float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
