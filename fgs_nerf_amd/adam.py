@@ -53,6 +53,11 @@ class MaskedAdam(torch.optim.Optimizer):
         `use_device_schedule(None)` returns to host scalars."""
         self._dev = None if step_size_ptrs is None else {'ss': dict(step_size_ptrs), 'skip': skip_ptr}
 
+    def zero_grad(self, set_to_none: bool = True):
+        """(also forgets updates recorded by early_update() for a backward pass whose step() never came)"""
+        self._early = {}
+        return super().zero_grad(set_to_none=set_to_none)
+
     def ensure_state(self) -> None:
         """Create every parameter's moment buffers now (a captured step must not allocate-and-zero them inside the graph)."""
         for group in self.param_groups:

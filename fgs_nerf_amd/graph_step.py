@@ -115,7 +115,17 @@ class CapturedFineStep:
         if var.get('extra_loss') is not None:
             loss = loss + var['extra_loss'](self.model)
         self.opt.zero_grad(set_to_none=True)
-        loss.backward(self._seed)             # (d loss / d loss given: autograd would launch a ones_like fill per step)
+        # An update issued from inside the backward pass (fused.enable_early_update: k0's Adam pass) belongs to the update: the
+        # warm-up pass (update=False) must not apply it, and no record of an earlier pass may make this one skip it.
+        cache = self.model.__dict__.setdefault('_fused_cache', {})
+        hook = None if update else cache.pop('opt_hook', None)
+        if hasattr(self.opt, '_early'):
+            self.opt._early = {}
+        try:
+            loss.backward(self._seed)         # (d loss / d loss given: autograd would launch a ones_like fill per step)
+        finally:
+            if hook is not None:
+                cache['opt_hook'] = hook
         if update:
             if var.get('tv') is not None:
                 self.model.sdf_total_variation_add_grad(var['tv'][0], var['tv'][1])

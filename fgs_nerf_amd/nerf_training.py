@@ -160,6 +160,16 @@ class TrainStepper:
         """(Re)connect the gradient exchange to the model's CURRENT parameters and optimizer."""
         av = self.averager
         if av is None:
+            # one GPU: k0's Adam pass is issued in place from inside the fused backward pass (beside the weight-gradient
+            # launch) whenever nothing else writes into k0.grad between backward and step -- no TV of either form on k0
+            from . import fused
+            ct = self.cfg_train
+            k0_tv = ct.get('weight_tv_k0', 0) > 0
+            if hasattr(self.optimizer, 'early_update') and not k0_tv and getattr(self.model, 'k0', None) is not None \
+                    and self.model.k0.grid.is_cuda:
+                fused.enable_early_update(self.model, self.optimizer, None, inline=True)
+            else:
+                fused.disable_early_update(self.model)
             return
         av.rebind(self.model.parameters())
         av.attach(self.model)

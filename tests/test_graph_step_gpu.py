@@ -119,8 +119,10 @@ def test_stepper_captured_window_matches_step_by_step(dev):
     la, lb = runs["steps"][0], runs["captured"][0]
     assert abs(float(la[0]) - float(lb[0])) < 2e-6 * abs(float(la[0])), (la, lb)          # same parameters, same batch
     assert float(((la - lb) / la).abs().max()) < 5e-4, (la, lb)
+    # (five Adam steps of two runs whose gradients are summed with float atomics: an entry whose tiny gradient flips sign moves
+    # by 2 lr; the one-step agreement of the early k0 update is pinned in test_inline_early_k0_update_matches_the_update_in_step)
     for pa, pb in zip(runs["steps"][1], runs["captured"][1]):
-        assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 2e-3
+        assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 5e-3
     for a, b in zip(runs["steps"][2], runs["captured"][2]):
         assert abs(a - b) <= 1e-12 * abs(a)                                                  # the host's lr copy caught up
     assert runs["steps"][3] == runs["captured"][3] and set(runs["captured"][3]) == {N}
@@ -264,12 +266,19 @@ def test_inline_early_k0_update_matches_the_update_in_step(dev, captured):
             base = {id(g): g['lr'] for g in opt.param_groups}
             step = CapturedFineStep(model, opt, synth.FINE_LOSS, synth.RENDER_KWARGS, N, n_iters=ITERS,
                                     global_step_of=lambda it: 1000 + it, lr_of=lambda it, g: base[id(g)], tv=TV, capacity=8192)
-            step.capture(batches[0])
-            snaps = []
+            trained = [p for g in opt.param_groups for p in g['params']]     # (s_val is a schedule mirror the tick kernel writes)
+            before = [p.detach().clone() for p in trained]
+            step.capture(batches[1])                    # (a different batch than the first replay's)
+            torch.cuda.synchronize()
+            for a, b in zip(before, trained):           # the warm-up pass of capture() applies NO update, early or not
+                assert torch.equal(a, b.detach())
+            snaps, prev = [], model.k0.grid.detach().clone()
             for it in range(ITERS):
                 step.replay(batches[it % 3])
+                torch.cuda.synchronize()
+                assert not torch.equal(prev, model.k0.grid.detach())     # ... and every replay does update k0
+                prev = model.k0.grid.detach().clone()
                 if it == 0:
-                    torch.cuda.synchronize()
                     snaps = [model.k0.grid.detach().clone(), opt.state[model.k0.grid]['exp_avg'].clone()]
             assert not step.check()[0]
         else:
