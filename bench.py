@@ -371,6 +371,11 @@ def main():
     STEP_STATS["survivors"] = 0
     # the cyclic collector stays out of the timed region: a generation-2 pass over torch's object graph takes milliseconds,
     # several steps' worth, and lands in some 30-step runs and not in others (2.29 vs 2.63 ms/step on the same box)
+    # guard against a step that is fast because it is broken: every parameter group must have moved by the end of the timed
+    # region (a captured step once ran without k0's Adam pass and read 2.6 % "faster")
+    def _digest():
+        return [torch.stack([p.detach().double().abs().sum() for p in g['params']]).sum() for g in opt.param_groups]
+    digest_before = _digest()
     import gc
     gc.collect()
     gc_was_enabled = gc.isenabled()
@@ -392,6 +397,10 @@ def main():
     if gc_was_enabled:
         gc.enable()
     fused.set_profiling(False)
+    stale = [g.get('name', str(i)) for i, (g, a, b) in enumerate(zip(opt.param_groups, digest_before, _digest()))
+             if bool(a == b)]
+    if stale and args.steps > 0:
+        raise SystemExit(f"bench: parameter group(s) {stale} did not change during the timed region -- the step is broken")
     roofline_note = "HIP events on the launch stream immediately around every MLP matrix-core launch in the timed region"
     if sync_free_eager:
         from fgs_nerf_amd import fused as _fused
