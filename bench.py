@@ -397,10 +397,8 @@ def main():
     if gc_was_enabled:
         gc.enable()
     fused.set_profiling(False)
-    stale = [g.get('name', str(i)) for i, (g, a, b) in enumerate(zip(opt.param_groups, digest_before, _digest()))
-             if bool(a == b)]
-    if stale and args.steps > 0:
-        raise SystemExit(f"bench: parameter group(s) {stale} did not change during the timed region -- the step is broken")
+    digest_after = _digest()          # (device scalars, compared at the very end: a host read here would let the GPU idle -- and
+                                      #  its clock drop -- in front of the profiling steps that follow)
     roofline_note = "HIP events on the launch stream immediately around every MLP matrix-core launch in the timed region"
     if sync_free_eager:
         from fgs_nerf_amd import fused as _fused
@@ -481,10 +479,17 @@ def main():
                 "note": "algorithmic bytes / step time / 8 TB/s; the step is bound by fp32 matrix throughput and atomics"}
         # (the CPU baseline is timed at N = 1 only: the other ranks of a multi-GPU run would sit in the final barrier meanwhile)
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine" or world > 1) else cpu_baseline()
+        stale = [g.get('name', str(i)) for i, (g, a, b) in enumerate(zip(opt.param_groups, digest_before, digest_after))
+                 if bool(a == b)]
+        if stale and args.steps > 0:
+            line["broken"] = f"parameter group(s) {stale} did not change during the timed region"
+            print("[bench] " + line["broken"] + " -- the step is broken", file=sys.stderr, flush=True)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0 and line.get("broken"):
+        raise SystemExit(2)
 
 
 if __name__ == "__main__":
