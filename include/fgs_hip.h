@@ -287,9 +287,10 @@ int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int 
  * through fgs_gemm_f32 on the dY tensors the chain writes out.
  *   out / ldo / n_store : row-major copy of the layer output (first n_store columns, multiple of 4), or NULL
  *   mask_bits           : forward + relu: receives one bit per output element (1 = positive), [ceil(M / 32)][64] x 16 bytes,
- *                         in the kernel's register order; backward: the bits to apply (those the forward wrote for the layer
+ *                         in the kernel's register order (element e of a word at bit 31 - e); backward: the bits to apply (those the forward wrote for the layer
  *                         whose input gradient this is); NULL: none
- *   image_ws            : scratch for the packed weight images, fgs_mlp_rc_image_floats() floats, 16-byte aligned
+ *   image_ws            : scratch for the packed weight images, fgs_mlp_rc_image_floats() floats, 16-byte aligned (its last
+ *                         2 KB are a sink that lanes without a sample store into; never read)
  * Honours fgs_set_row_count_ptr (M = capacity).  The reduction order of a sum differs from fgs_gemm_f32's (pairs (k, k+4));
  * results are deterministic but not bit-identical to the LDS-resident chain. */
 typedef struct fgs_rc_layer {
