@@ -177,9 +177,13 @@ __device__ __forceinline__ void acc_zero(floatx16 (&acc)[2][2]) {
 // epilogue of a data-gradient tile took 23 us on average (10..46) next to a 32 us main loop.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool A_KC, bool B_KC, bool CLAMP = false>
+// NARROW (N <= 64, chosen by the launcher): the four waves take 32 rows x 64 columns each (1 x 2 MFMA tiles) instead of 64 x 64
+// quadrants -- half the MFMAs; in the 2 x 2 arrangement the two waves of the right-hand quadrants would multiply columns
+// that do not exist (the 52-column encoding part of dZ ran at 41 % useful matrix work).
+template <bool A_KC, bool B_KC, bool CLAMP = false, bool NARROW = false>
 __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int64_t n0, int64_t k_begin, int64_t k_end,
                                               floatx16 (&acc)[2][2], LdsImage &lds) {
+  constexpr int RT = NARROW ? 1 : 2;          // A row tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave >> 1, wave_n = wave & 1, h = lane >> 5, l31 = lane & 31;
 
@@ -191,7 +195,7 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
   // The barrier is s_waitcnt lgkmcnt(0) + s_barrier (no vmcnt wait: __syncthreads() would drain the prefetch).
   Stage<A_KC> sa;
   Stage<B_KC> sb;
-  const int ia0 = wave_m * 64 + l31, ib0 = wave_n * 64 + l31;
+  const int ia0 = NARROW ? wave * 32 + l31 : wave_m * 64 + l31, ib0 = NARROW ? l31 : wave_n * 64 + l31;
   const int n_chunks = (int)((k_end - k_begin + BK - 1) / BK);      // (32-bit: loop tests stay on the scalar unit)
   stage_load<A_KC, CLAMP>(sa, g.A, g.lda, m0, g.M, k_begin, k_end, tid);
   stage_load<B_KC, CLAMP>(sb, g.B, g.ldb, n0, g.N, k_begin, k_end, tid);
@@ -206,7 +210,7 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
   float f0a[2][8], f0b[2][8], f1a[2][8], f1b[2][8];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    half_load<A_KC>(f0a[t], lds[0][0], ia0 + t * 32, h, 0);
+    if (t < RT) half_load<A_KC>(f0a[t], lds[0][0], ia0 + t * 32, h, 0);
     half_load<B_KC>(f0b[t], lds[0][1], ib0 + t * 32, h, 0);
   }
   for (int c = 0; c < n_chunks; ++c) {
@@ -221,14 +225,14 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      half_load<A_KC>(f1a[t], lds[cur][0], ia0 + t * 32, h, 1);
+      if (t < RT) half_load<A_KC>(f1a[t], lds[cur][0], ia0 + t * 32, h, 1);
       half_load<B_KC>(f1b[t], lds[cur][1], ib0 + t * 32, h, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0a[i][s], f0b[j][s], acc[i][j], 0, 0, 0);
@@ -237,7 +241,7 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
     if (c + 1 < n_chunks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        half_load<A_KC>(f0a[t], lds[cur ^ 1][0], ia0 + t * 32, h, 0);
+        if (t < RT) half_load<A_KC>(f0a[t], lds[cur ^ 1][0], ia0 + t * 32, h, 0);
         half_load<B_KC>(f0b[t], lds[cur ^ 1][1], ib0 + t * 32, h, 0);
       }
     }
@@ -245,7 +249,7 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1a[i][s], f1b[j][s], acc[i][j], 0, 0, 0);
@@ -255,7 +259,7 @@ __device__ __forceinline__ void tile_mainloop(const GemmArgs &g, int64_t m0, int
 }
 
 // ---- epilogue: accumulator (reg r, lane) -> C[row, col]; col = lane & 31, row = (r&3) + 8*(r>>2) + 4*h
-template <int EPI>
+template <int EPI, bool NARROW = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int64_t n0, floatx16 (&acc)[2][2],
                                               LdsImage &lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,10 +286,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < (NARROW ? 1 : 2); ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        ct[(wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC + wave_n * 64 + j * 32 + l31] = acc[i][j][r];
+        ct[((NARROW ? wave * 32 : wave_m * 64 + i * 32) + (r & 3) + 8 * (r >> 2) + 4 * h) * LDC +
+           (NARROW ? 0 : wave_n * 64) + j * 32 + l31] = acc[i][j][r];
   lds_barrier();
   const int c4 = tid & 31;
   const int64_t col = n0 + 4 * c4;
@@ -333,7 +338,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs &g, int64_t m0, int
 }
 
 // One workgroup per output tile (EPI_STORE) or per (tile, K slice) (EPI_ATOMIC).
-template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false>
+template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false, bool NARROW = false>
 __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &lds) {
   // XCD-aware tile assignment: ids b, b+8, b+16.. (same XCD) walk the column tiles of one row tile
   int tile_m, tile_n;
@@ -358,19 +363,19 @@ __device__ __forceinline__ void gemm_block(const GemmArgs &g, int b, LdsImage &l
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   floatx16 acc[2][2];
   acc_zero(acc);
-  tile_mainloop<A_KC, B_KC, CLAMP>(g, m0, n0, k_begin, k_end, acc, lds);
-  tile_epilogue<EPI>(g, m0, n0, acc, lds);
+  tile_mainloop<A_KC, B_KC, CLAMP, NARROW>(g, m0, n0, k_begin, k_end, acc, lds);
+  tile_epilogue<EPI, NARROW>(g, m0, n0, acc, lds);
 }
 
 // CLAMP (chosen by the launcher for store-epilogue products with K a multiple of 32 and, for an index-contiguous B, N a
 // multiple of 4): operand loads without guards, see stage_load.  A kernel of its own: the guarded main loop keeps ~16 exec
 // masks and 64-bit row bounds alive in scalar registers -- 106 used and 156 more spilled to vector lanes in the guarded
 // instantiation -- and both loops in one kernel pushed the spills to scratch.
-template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false>
+template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) LdsImage lds;
   if (EPI != EPI_ATOMIC) g.M = fgs_rows(g.M, g.m_dev);       // row tiles beyond the device-side count return at once
-  gemm_block<A_KC, B_KC, EPI, CLAMP>(g, (int)blockIdx.x, lds);
+  gemm_block<A_KC, B_KC, EPI, CLAMP, NARROW>(g, (int)blockIdx.x, lds);
 }
 
 // Backward of one Linear layer in ONE launch: the data-gradient product (NN, store epilogue with ReLU mask / column sums)
@@ -490,9 +495,10 @@ template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgs &g, unsigned splits, hipStream_t st) {
   const unsigned groups = (unsigned)((g.tiles_m + 7) / 8);
   dim3 grid(EPI == EPI_ATOMIC ? (unsigned)(g.tiles_m * g.tiles_n) * splits : groups * 8 * (unsigned)g.tiles_n, 1, 1);
-  if (EPI == EPI_STORE && (g.K % BK) == 0 && (B_KC || ((g.N & 3) == 0 && g.N >= 4)) && g.M >= 1)
-    hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, EPI == EPI_STORE>), grid, dim3(256), 0, st, g);
-  else
+  if (EPI == EPI_STORE && (g.K % BK) == 0 && (B_KC || ((g.N & 3) == 0 && g.N >= 4)) && g.M >= 1) {
+    if (g.N <= 64) hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, EPI == EPI_STORE, EPI == EPI_STORE>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, EPI == EPI_STORE, false>), grid, dim3(256), 0, st, g);
+  } else
     hipLaunchKernelGGL((k_gemm<A_KC, B_KC, EPI, false>), grid, dim3(256), 0, st, g);
   FGS_LAUNCH_OK("fgs_gemm_f32");
   return 0;

@@ -165,6 +165,29 @@ def test_gemm_variants(dev):
         fo.gemm(fo.GEMM_NT, X[:, :106], W[:, :106], Y, M, N, 106)
 
 
+@pytest.mark.parametrize("M,K,N", [(777, 256, 52), (1, 256, 64), (4099, 256, 4), (129, 64, 108), (513, 32, 36), (640, 256, 256),
+                                   (300, 108, 52)])
+def test_gemm_store_products_every_instantiation(dev, M, K, N):
+    """The store-epilogue products (NT forward, NN data gradient) through each instantiation the launcher picks: K % 32 == 0 ->
+    unguarded clamped-operand main loop (rows beyond M and columns beyond N read the operand's last row / last float4), N <= 64
+    -> the 4 x (32 rows x 64 columns) wave arrangement, otherwise the guarded loop; bias / ReLU / mask / column sums in the
+    epilogue, a partial last row tile, outputs beyond N untouched."""
+    from fgs_nerf_amd import fused_ops as fo
+    g = torch.Generator().manual_seed(M + K + N)
+    ldc = N + 8
+    X, W, b = torch.randn(M, K, generator=g).to(dev), (torch.randn(N, K, generator=g) * 0.1).to(dev), torch.randn(N, generator=g).to(dev)
+    Y, cs = torch.full((M, ldc), 7.0, device=dev), torch.zeros(N, device=dev)
+    fo.gemm(fo.GEMM_NT, X, W, Y[:, :N], M, N, K, bias=b, relu=True, colsum=cs)
+    ref = torch.relu(X.double() @ W.double().T + b.double())
+    assert rel_l2(Y[:, :N], ref) < 1e-6 and rel_l2(cs, ref.sum(0)) < 1e-5 and bool((Y[:, N:] == 7.0).all())
+    # NN: dX[M, N] = dY[M, K] . Wt[K, N], masked
+    dY, Wt = torch.randn(M, K, generator=g).to(dev), (torch.randn(K, N, generator=g) * 0.1).to(dev)
+    act, dX, cs2 = torch.randn(M, N, generator=g).to(dev), torch.full((M, ldc), 7.0, device=dev), torch.zeros(N, device=dev)
+    fo.gemm(fo.GEMM_NN, dY, Wt, dX[:, :N], M, N, K, mask=act, colsum=cs2)
+    ref2 = (dY.double() @ Wt.double()) * (act > 0)
+    assert rel_l2(dX[:, :N], ref2) < 1e-6 and rel_l2(cs2, ref2.sum(0)) < 1e-5 and bool((dX[:, N:] == 7.0).all())
+
+
 def test_fused_losses_match_torch_losses(dev):
     """csrc/losses.hip vs the reference statements in torch (model/nerf_training.py:308-327): value and every gradient."""
     from fgs_nerf_amd import synth
