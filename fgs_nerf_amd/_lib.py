@@ -43,8 +43,10 @@ _SIGNATURES = {
     "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
     "fgs_pad_cols_multi": [I32, P, P, P, P, P, P, P],
+    "fgs_copy_cols_multi": [I32, P, P, P, P, P, P, P, P],
     "fgs_set_row_count_ptr": [P],
     "fgs_set_inv_s_ptr": [P],
+    "fgs_set_dx0_compact": [I32],
     "fgs_step_scalars_tick": [P, I32, I32, P, P, I32, P, P],
     "fgs_count_guard": [P, I64, I64, P, P, P],
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, F32, F32, F32, I32, P, P],

@@ -20,6 +20,9 @@ struct FeatLayout {
   int K;
   float disp[MAXK];
   int off_k0, off_xyz, off_view, off_sdf, off_feat, off_hgrad, off_grad, x0_cols, ldx0;
+  int dx_ld, dx_gap;     // dX0 as the backward kernels read it: row pitch, and what to subtract from a column behind the k0
+                         // block (fgs_set_dx0_compact: the xyz / view-direction encodings -- functions of the fixed ray inputs,
+                         // no gradient needed -- are left out of dX0: 12 + 40 of 106 columns at the fine stage)
   int off_ref, z_cols, ldz;
   // coarse stages (model/nerf.py:993-1009): ONE operand buffer [k0, xyz_emb, reflect_emb, normal, viewdirs_emb];
   // off_ref / ldz then address the reflection block inside X0 and off_grad holds the NORMAL, not the raw gradient
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= S.M * kd.C) return;
   const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
-  const float g = dX0[m * S.L.ldx0 + S.L.off_k0 + c];
+  const float g = dX0[m * S.L.dx_ld + S.L.off_k0 + c];
   if (g == 0.f) return;
   const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
   fgs_tri_scatter(k0_grad, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz), g);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
       tp = fgs_tap_point(pc, gd, j / K, S.L.disp[j % K]);
       f = X0[m * S.L.ldx0 + S.L.off_feat + j];  // saved forward value
       cl = tp.clamped;
-      d_f = dX0[m * S.L.ldx0 + S.L.off_feat + j];
+      d_f = dX0[m * S.L.dx_ld + S.L.off_feat - S.L.dx_gap + j];
     }
     // lanes j < 3K: gradient of the (optionally normalised) finite difference w.r.t. the raw difference
     const int a = (j < 3 * K) ? j / K : 0, k = (j < 3 * K) ? j % K : 0;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
     const float cp = group_shfl(cl, (2 * a + 1) * K + k), cm = group_shfl(cl, (2 * a) * K + k);
     const float diff = cp - cm;
     const float g_raw = ((fp - fm) / diff) / S.geom.voxel_size;
-    float dy = (row_ok && j < 3 * K) ? dX0[m * S.L.ldx0 + S.L.off_hgrad + j] : 0.f;
+    float dy = (row_ok && j < 3 * K) ? dX0[m * S.L.dx_ld + S.L.off_hgrad - S.L.dx_gap + j] : 0.f;
     float dg = dy;
     if (S.L.use_grad_norm) {
       const float g0 = group_shfl(g_raw, k), g1 = group_shfl(g_raw, K + k), g2 = group_shfl(g_raw, 2 * K + k);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     dn[c] = -2.f * (v[c] * drn + s * dr[c]) + (g_normal ? g_normal[3 * m + c] : 0.f);
-    if (L.coarse) dn[c] += dX0[m * L.ldx0 + L.off_grad + c];  // the normal itself is an MLP input column
+    if (L.coarse) dn[c] += dX0[m * L.dx_ld + L.off_grad + c];  // the normal itself is an MLP input column
   }
   // normal = x / sqrt(max(sum x^2, eps))
   const float dnx = (dn[0] * x[0] + dn[1] * x[1]) + dn[2] * x[2];
@@ -421,9 +424,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
   for (int c = 0; c < 3; ++c) {
     float dg = dx[c] / (rn + 1e-7f);
     if (rn > 0.f) dg -= dxg / ((rn + 1e-7f) * (rn + 1e-7f)) * (g[c] / rn);
-    g_gradient[3 * m + c] = L.coarse ? dg : dg + dX0[m * L.ldx0 + L.off_grad + c];
+    g_gradient[3 * m + c] = L.coarse ? dg : dg + dX0[m * L.dx_ld + L.off_grad - L.dx_gap + c];
   }
-  if (g_sdf) g_sdf[m] = L.center_sdf ? dX0[m * L.ldx0 + L.off_sdf] : 0.f;
+  if (g_sdf) g_sdf[m] = L.center_sdf ? dX0[m * L.dx_ld + L.off_sdf - L.dx_gap] : 0.f;
 }
 
 // ------------------------------------------------------------------------- 3-wide output head (refnet last Linear)
@@ -711,6 +714,8 @@ int fill_layout(const int *li, const float *disp, FeatLayout *L) {
   L->off_hgrad = c; c += 3 * L->K;
   L->off_grad = c; c += 3;
   L->x0_cols = c;
+  L->dx_gap = fgs_dx0_compact() ? L->off_sdf - L->off_xyz : 0;
+  L->dx_ld = fgs_dx0_compact() ? (L->x0_cols - L->dx_gap + 3) / 4 * 4 : L->ldx0;
   L->z_cols = L->off_ref + 3 + 6 * L->n_reffreq;
   if (L->ldx0 < L->x0_cols || L->ldz < L->z_cols || (L->ldx0 & 3) || (L->ldz & 3))
     return fgs_set_error(FGS_E_INVALID, "feature layout: ldx0=%d (need >= %d), ldz=%d (need >= %d), multiples of 4",
@@ -732,6 +737,7 @@ int fill_layout_coarse(const int *li, FeatLayout *L) {
   L->off_view = c; c += L->use_viewdir ? 3 + 6 * L->n_viewfreq : 0;
   L->off_sdf = L->off_feat = L->off_hgrad = c;
   L->x0_cols = c;
+  L->dx_gap = 0; L->dx_ld = L->ldx0;
   L->ldz = L->ldx0; L->z_cols = L->ldx0;
   if (L->ldx0 < L->x0_cols || (L->ldx0 & 3))
     return fgs_set_error(FGS_E_INVALID, "coarse feature layout: ldx0=%d (need >= %d, multiple of 4)", L->ldx0, L->x0_cols);

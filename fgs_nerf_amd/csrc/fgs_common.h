@@ -33,6 +33,8 @@ static inline hipStream_t fgs_s(fgs_stream_t s) { return reinterpret_cast<hipStr
 const int64_t *fgs_row_ptr();
 // Device-side NeuS 1/s (fgs_set_inv_s_ptr): when set, the march kernels read inv_s from there instead of their argument.
 const float *fgs_inv_s_ptr();
+// fgs_set_dx0_compact: the fine-stage backward entries read dX0 in its compact form (see include/fgs_hip.h).
+int fgs_dx0_compact();
 
 constexpr int FGS_WAVE = 64;      // gfx950 wavefront
 constexpr int FGS_BLOCK = 256;    // 4 waves: one per SIMD of a CU

@@ -379,7 +379,7 @@ struct PadArgs {
   int n;
   const float *src[MAXL];
   float *dst[MAXL];
-  int rows[MAXL], cols[MAXL];
+  int rows[MAXL], cols[MAXL], width[MAXL];     // width: columns WRITTEN per destination row (cols copied, the rest zero)
   int64_t ld_src[MAXL], ld_dst[MAXL];
   int64_t elem0[MAXL + 1];   // first destination element of each matrix in the flat range
 };
@@ -389,28 +389,37 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_pad_cols_multi(PadArgs a) {
   int m = 0;
   while (m + 1 < a.n && i >= a.elem0[m + 1]) ++m;
   const int64_t e = i - a.elem0[m];
-  const int64_t r = e / a.ld_dst[m], c = e - r * a.ld_dst[m];
-  a.dst[m][e] = c < a.cols[m] ? a.src[m][r * a.ld_src[m] + c] : 0.f;
+  const int64_t r = e / a.width[m], c = e - r * a.width[m];
+  a.dst[m][r * a.ld_dst[m] + c] = c < a.cols[m] ? a.src[m][r * a.ld_src[m] + c] : 0.f;
 }
 }  // namespace
 
-FGS_API int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
-                               float *const *dst, const int64_t *ld_dst, fgs_stream_t stream) {
-  FGS_REQUIRE(n >= 1 && n <= MAXL, FGS_E_RANGE, "fgs_pad_cols_multi: n=%d (1..%d)", n, MAXL);
-  FGS_REQUIRE(src && rows && cols && ld_src && dst && ld_dst, FGS_E_INVALID, "fgs_pad_cols_multi: null pointer");
+// width[i] columns are written per destination row (pitch ld_dst[i] >= width[i] >= cols[i]): destinations may be column
+// ranges of a wider matrix, i.e. several sources gathered side by side into one.  width == NULL: width[i] = ld_dst[i].
+FGS_API int fgs_copy_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
+                                float *const *dst, const int64_t *ld_dst, const int *width, fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 1 && n <= MAXL, FGS_E_RANGE, "fgs_copy_cols_multi: n=%d (1..%d)", n, MAXL);
+  FGS_REQUIRE(src && rows && cols && ld_src && dst && ld_dst, FGS_E_INVALID, "fgs_copy_cols_multi: null pointer");
   PadArgs a;
   a.n = n;
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
-    FGS_REQUIRE(src[i] && dst[i] && rows[i] > 0 && cols[i] > 0 && ld_src[i] >= cols[i] && ld_dst[i] >= cols[i], FGS_E_INVALID,
-                "fgs_pad_cols_multi: matrix %d: bad pointer or shape", i);
-    a.src[i] = src[i]; a.dst[i] = dst[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.ld_src[i] = ld_src[i]; a.ld_dst[i] = ld_dst[i];
+    const int64_t w = width ? width[i] : ld_dst[i];
+    FGS_REQUIRE(src[i] && dst[i] && rows[i] > 0 && cols[i] > 0 && ld_src[i] >= cols[i] && w >= cols[i] && ld_dst[i] >= w &&
+                    w < ((int64_t)1 << 31), FGS_E_INVALID, "fgs_copy_cols_multi: matrix %d: bad pointer or shape", i);
+    a.src[i] = src[i]; a.dst[i] = dst[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i]; a.width[i] = (int)w;
+    a.ld_src[i] = ld_src[i]; a.ld_dst[i] = ld_dst[i];
     a.elem0[i] = total;
-    total += (int64_t)rows[i] * ld_dst[i];
+    total += (int64_t)rows[i] * w;
   }
   a.elem0[n] = total;
   hipLaunchKernelGGL(k_pad_cols_multi, dim3(fgs_blocks(total)), dim3(FGS_BLOCK), 0, fgs_s(stream), a);
-  FGS_LAUNCH_OK("fgs_pad_cols_multi");
+  FGS_LAUNCH_OK("fgs_copy_cols_multi");
   return 0;
+}
+
+FGS_API int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
+                               float *const *dst, const int64_t *ld_dst, fgs_stream_t stream) {
+  return fgs_copy_cols_multi(n, src, rows, cols, ld_src, dst, ld_dst, nullptr, stream);
 }
 

@@ -375,9 +375,17 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     # register-resident chains of 4 row tiles they measured 63 us each against 47 for the tiled GEMM: with 64 MFMAs per chunk
     # the chain's per-chunk barrier / DMA and its uncoalesced input load dominate.)
     z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
-    dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
     _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
-    _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw))
+    if S.get('W0c') is not None:
+        # dX0 in compact form (fgs_set_dx0_compact): only the columns somebody differentiates through
+        W0c = S['W0c']
+        dX0 = torch.empty(M, W0c.shape[1], dtype=F32, device=dev)
+        _gemm(fo.GEMM_NN, dY_rgb[0], W0c, dX0, M, W0c.shape[1], rw, logical=(M, run.dx0_cols[2], rw))
+        run.dx0_compact = True
+    else:
+        dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+        _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw))
+        run.dx0_compact = False
     # all weight / bias gradients (the bias gradient of the top refnet layer came out of the head kernel)
     items = []
     for i in range(n_ref - 1):
@@ -400,6 +408,8 @@ _WGRAD_FORK = os.environ.get("FGS_WGRAD_FORK", "1") == "1"
 # only the memory-bound ones beside the weight-gradient launch.  Measured 1.89-1.90 ms/step against 1.87 for the default order
 # (the LDS-atomic sdf scatter, then under the matrix kernel for its whole length, costs it more than the march kernel saves).
 _MARCH_FIRST = os.environ.get("FGS_MARCH_FIRST", "0") == "1"
+# dX0 (d loss / d first-layer input) computed and read in compact form: without the columns of the xyz / view-direction encodings
+_DX0_COMPACT = os.environ.get("FGS_DX0_COMPACT", "1") == "1"
 _SIDE_PENDING = set()
 
 
@@ -620,7 +630,17 @@ class _FusedFine(torch.autograd.Function):
         sf = run.sync_free
         token = None if sf else _count_begin(run, ws['surv_off'], N)
         # K-padded first-layer weights of both MLPs, one launch (F.pad: a fill + a copy launch per matrix)
-        W0p, V0p = fo.pad_cols_multi([rgb_w[0].detach(), ref_w[0].detach()], [ldx0, ldz])
+        W0c = None
+        if _DX0_COMPACT and _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and any(ctx.needs_input_grad):
+            # ... and, in the same launch, the first rgbnet layer's weights WITHOUT the columns of the xyz / view-direction
+            # encodings: the backward pass needs d loss / d X0 only for the k0, sdf, tap and gradient columns (12 + 40 of 106)
+            k0d, gap, cw = run.dx0_cols
+            W0 = rgb_w[0].detach()
+            W0c = torch.empty(rw, (cw + 3) // 4 * 4, dtype=F32, device=dev)
+            W0p, V0p, _, _ = fo.pad_cols_multi([W0, ref_w[0].detach(), W0[:, :k0d], W0[:, k0d + gap:]],
+                                               [ldx0, ldz, k0d, cw - k0d], outs=[None, None, W0c[:, :k0d], W0c[:, k0d:cw]])
+        else:
+            W0p, V0p = fo.pad_cols_multi([rgb_w[0].detach(), ref_w[0].detach()], [ldx0, ldz])
         pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         if sf:
@@ -740,7 +760,7 @@ class _FusedFine(torch.autograd.Function):
         # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
-                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, WT=WT, relu_bits=relu_bits,
+                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, WT=WT, relu_bits=relu_bits,
                                    pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
@@ -906,7 +926,18 @@ class _FusedFine(torch.autograd.Function):
         tot_grad = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
 
+        compact = bool(getattr(run, 'dx0_compact', False))
+
         def feat_bwd(k0_part: bool, enc_part: bool):
+            if compact:
+                call("fgs_set_dx0_compact", 1)
+            try:
+                _feat_bwd(k0_part, enc_part)
+            finally:
+                if compact:
+                    call("fgs_set_dx0_compact", 0)
+
+        def _feat_bwd(k0_part: bool, enc_part: bool):
             call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
                  g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
                  ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0) if k0_part else None, ksC, ksX, ksY, ksZ,
@@ -942,8 +973,14 @@ class _FusedFine(torch.autograd.Function):
         if not march_first:
             march_bwd()
         # 7. every sdf.grad contribution of the survivors (24 taps + centre + six +/-1 taps), combined on chip
-        call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
-             run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
+        if compact:
+            call("fgs_set_dx0_compact", 1)
+        try:
+            call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
+                 run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
+        finally:
+            if compact:
+                call("fgs_set_dx0_compact", 0)
 
         _join_side(dev)
         if hook is not None:
@@ -1440,7 +1477,10 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
     dev = rays_o.device
     run, s_val = _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, default_depth=False)
     N = run.n_rays
-    run.layout_i, run.displace, run.ldx0, run.ldz, _ = _layout(model, run.geom)
+    run.layout_i, run.displace, run.ldx0, run.ldz, x0_cols = _layout(model, run.geom)
+    # (k0 columns, width of the xyz + view-direction encodings behind them, columns of X0 without those: see _DX0_COMPACT)
+    gap = (3 + 6 * len(model.posfreq)) + ((3 + 6 * len(model.viewfreq)) if model.use_viewdir else 0)
+    run.dx0_cols = (int(model.k0_dim), gap, x0_cols - gap)
     run.mask_grid = model.mask_cache.sdf_mask if model.mask_cache is not None else None
     rl, fl = mlp_layers(model.rgbnet), mlp_layers(model.refnet)
     run.n_rgb, run.n_ref = len(rl), len(fl)

@@ -98,17 +98,27 @@ def transpose_multi(mats) -> list:
     return outs
 
 
-def pad_cols_multi(mats, widths) -> list:
+def pad_cols_multi(mats, widths, outs=None) -> list:
     """[F.pad(W, (0, width - W.shape[1])) for W, width in zip(mats, widths)] in ONE launch (include/fgs_hip.h
-    fgs_pad_cols_multi; W: 2-D float32 CUDA with unit column stride, at most 8 of them)."""
+    fgs_copy_cols_multi; W: 2-D float32 CUDA with unit column stride, at most 8 of them).  `outs`: per matrix None (allocate) or
+    a caller's [rows, width] view to write into -- column slices of one tensor: a gather of column ranges in the same launch."""
     import ctypes
     n = len(mats)
-    outs = [torch.empty(w.shape[0], int(width), dtype=torch.float32, device=w.device) for w, width in zip(mats, widths)]
+    res = []
+    for i, (w, width) in enumerate(zip(mats, widths)):
+        o = outs[i] if outs is not None else None
+        if o is None:
+            o = torch.empty(w.shape[0], int(width), dtype=torch.float32, device=w.device)
+        elif not (o.is_cuda and o.dtype == torch.float32 and o.dim() == 2 and o.stride(1) == 1 and o.shape[0] == w.shape[0]
+                  and o.shape[1] == int(width) and o.stride(0) >= o.shape[1] and int(width) >= w.shape[1]):
+            # (checked on the host: the kernel writes rows x width elements at this pitch whatever the tensor behind it holds)
+            raise RuntimeError(f"pad_cols_multi: output {i} must be a [rows, width] float32 view with unit column stride")
+        res.append(o)
     PtrArr, I64Arr, IntArr = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
-    call("fgs_pad_cols_multi", n, PtrArr(*[ptr(w) for w in mats]), IntArr(*[w.shape[0] for w in mats]),
-         IntArr(*[w.shape[1] for w in mats]), I64Arr(*[w.stride(0) for w in mats]), PtrArr(*[ptr(o) for o in outs]),
-         I64Arr(*[o.stride(0) for o in outs]), stream())
-    return outs
+    call("fgs_copy_cols_multi", n, PtrArr(*[ptr(w) for w in mats]), IntArr(*[w.shape[0] for w in mats]),
+         IntArr(*[w.shape[1] for w in mats]), I64Arr(*[w.stride(0) for w in mats]), PtrArr(*[ptr(o) for o in res]),
+         I64Arr(*[o.stride(0) for o in res]), IntArr(*[o.shape[1] for o in res]), stream())
+    return res
 
 
 _RC_IMAGES = {}   # (device index, stream handle, backward) -> packed-weight scratch of the register-resident chains

@@ -47,6 +47,11 @@ int fgs_set_row_count_ptr(const int64_t *count_dev);
  * instead of their argument (model/nerf.py:514,522: s_val follows the iteration number, which a captured step cannot pass by
  * value).  NULL restores the argument. */
 int fgs_set_inv_s_ptr(const float *inv_s_dev);
+/* Thread-local, like the two above: while on, the fine-stage backward entries (fgs_feat_fine_bwd, fgs_sdf_scatter_surv) read dX0
+ * in COMPACT form -- the columns of the xyz and view-direction encodings (functions of the fixed ray inputs: no gradient is
+ * needed, model/nerf.py:837-874) are absent, i.e. row = [k0 | sdf | taps | tap differences | gradient], pitch = that width
+ * rounded up to 4 -- so that the caller's dX0 product only multiplies the weight columns that matter (52 of 106). */
+int fgs_set_dx0_compact(int on);
 /* Device-resident schedule of a captured training step (model/nerf_training.py:389-436, model/adam.py:205-221).  `table` is
  * [n_rows][n_cols] floats the host fills once per stage -- row = iteration, columns = whatever per-iteration scalars the
  * step's kernels read (Adam step sizes from fgs_adam_step_size, inv_s).  fgs_step_scalars_tick copies row
@@ -340,6 +345,11 @@ int fgs_transpose_multi(int n, const float *const *src, const int *rows, const i
  * launch (HOST arrays): the K-padded copies of the first-layer weights the narrow data-gradient products multiply by. */
 int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
                        float *const *dst, const int64_t *ld_dst, fgs_stream_t stream);
+/* The same with the number of columns WRITTEN per destination row given apart from the pitch (cols[i] <= width[i] <= ld_dst[i];
+ * NULL: the pitch): destinations may be column ranges of one wider matrix, i.e. a gather of column ranges in one launch (the
+ * first rgbnet layer's weights without the columns of the xyz / view-direction encodings, see fgs_set_dx0_compact). */
+int fgs_copy_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
+                        float *const *dst, const int64_t *ld_dst, const int *width, fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,

@@ -208,3 +208,16 @@ def test_pad_cols_multi_matches_torch_pad(dev):
     outs = fo.pad_cols_multi(mats, widths)
     for w, width, o in zip(mats, widths, outs):
         assert torch.equal(o, torch.nn.functional.pad(w, (0, width - w.shape[1])))
+    # the gather form: column ranges of one source written side by side into caller-provided column slices of one tensor (the
+    # first-layer weights without the encodings' columns), in the same launch as an ordinary padded copy; nothing outside the
+    # slices is touched (canary rows / columns around the destination)
+    W = torch.randn(256, 106, device=dev)
+    canvas = torch.full((258, 60), 7.0, device=dev)
+    dst = canvas[1:257, 4:56]                                  # [256, 52] inside the canvas, pitch 60
+    o = fo.pad_cols_multi([W[:, :12], W[:, 66:], big[:, 7:314]], [12, 40, 308], outs=[dst[:, :12], dst[:, 12:], None])
+    assert torch.equal(dst, torch.cat([W[:, :12], W[:, 66:]], 1))
+    assert torch.equal(o[2], torch.nn.functional.pad(big[:, 7:314], (0, 1)))
+    canvas[1:257, 4:56] = 7.0
+    assert bool((canvas == 7.0).all())
+    with pytest.raises(RuntimeError):                          # a destination whose shape is not [rows, width] is refused
+        fo.pad_cols_multi([W[:, :12]], [12], outs=[dst[:, :13]])
