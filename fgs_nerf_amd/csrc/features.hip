@@ -373,7 +373,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
   const FeatLayout &L = S.L;
   const int F = FREF ? FREF : L.n_reffreq;
   const float *z = Z + m * L.ldz + L.off_ref;
-  const float *dz = dZ + m * L.ldz + L.off_ref;
+  // (coarse stages: the reflection encoding is a block of X0 itself, so its gradient is a block of dX0 -- read in dX0's form)
+  const float *dz = L.coarse ? dZ + m * L.dx_ld + L.off_ref - L.dx_gap : dZ + m * L.ldz + L.off_ref;
   // d reflect_c = dE[c] + sum_f 2^f (cos * dE_sin - sin * dE_cos)
   float part[3] = {0.f, 0.f, 0.f};
   if (FREF) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     dn[c] = -2.f * (v[c] * drn + s * dr[c]) + (g_normal ? g_normal[3 * m + c] : 0.f);
-    if (L.coarse) dn[c] += dX0[m * L.dx_ld + L.off_grad + c];  // the normal itself is an MLP input column
+    if (L.coarse) dn[c] += dX0[m * L.dx_ld + L.off_grad - L.dx_gap + c];  // the normal itself is an MLP input column
   }
   // normal = x / sqrt(max(sum x^2, eps))
   const float dnx = (dn[0] * x[0] + dn[1] * x[1]) + dn[2] * x[2];
@@ -737,7 +738,10 @@ int fill_layout_coarse(const int *li, FeatLayout *L) {
   L->off_view = c; c += L->use_viewdir ? 3 + 6 * L->n_viewfreq : 0;
   L->off_sdf = L->off_feat = L->off_hgrad = c;
   L->x0_cols = c;
-  L->dx_gap = 0; L->dx_ld = L->ldx0;
+  // compact dX0 (fgs_set_dx0_compact): [k0 | reflect_emb | normal] -- the xyz encoding between k0 and the reflection block and
+  // the view-direction encoding at the end are functions of the fixed ray inputs
+  L->dx_gap = fgs_dx0_compact() ? L->off_ref - L->off_xyz : 0;
+  L->dx_ld = fgs_dx0_compact() ? (L->off_view - L->dx_gap + 3) / 4 * 4 : L->ldx0;
   L->ldz = L->ldx0; L->z_cols = L->ldx0;
   if (L->ldx0 < L->x0_cols || (L->ldx0 & 3))
     return fgs_set_error(FGS_E_INVALID, "coarse feature layout: ldx0=%d (need >= %d, multiple of 4)", L->ldx0, L->x0_cols);

@@ -1068,7 +1068,18 @@ class _FusedCoarse(torch.autograd.Function):
         ref_w = [mlp[2 * i] for i in range(n_ref)]
         ref_b = [mlp[2 * i + 1] for i in range(n_ref)]
         fw, ldx0 = ref_w[0].shape[0], run.ldx0
-        (V0p,) = fo.pad_cols_multi([ref_w[0].detach()], [ldx0])
+        V0c = None
+        rc_shapes = _MLP_IMPL == "rc" and fw % 32 == 0 and fw <= 256 and ldx0 <= 256 and n_ref - 1 <= 8
+        if _DX0_COMPACT and rc_shapes and any(ctx.needs_input_grad):
+            # (as in the fine stage: the first layer's weights without the xyz / view-direction encodings' columns, gathered in
+            # the launch that makes the padded copy -- dX0 is computed and read as [k0 | reflect_emb | normal])
+            k0d, gap, cw = run.dx0_cols
+            V0 = ref_w[0].detach()
+            V0c = torch.empty(fw, (cw + 3) // 4 * 4, dtype=F32, device=dev)
+            V0p, _, _ = fo.pad_cols_multi([V0, V0[:, :k0d], V0[:, k0d + gap:k0d + gap + cw - k0d]], [ldx0, k0d, cw - k0d],
+                                          outs=[None, V0c[:, :k0d], V0c[:, k0d:cw]])
+        else:
+            (V0p,) = fo.pad_cols_multi([ref_w[0].detach()], [ldx0])
         pre_k0 = _prefill_grid_grad(run, k0_grid) if (_PRE_FILL_AT_READ and any(ctx.needs_input_grad)) else None
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         if sf:       # sync-free (see _FusedFine.forward): the count stays on the device, M is the CAPACITY from here on
@@ -1131,7 +1142,7 @@ class _FusedCoarse(torch.autograd.Function):
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev), pre_k0)
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
-                                   V0p=V0p, relu_bits=relu_bits, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
+                                   V0p=V0p, V0c=V0c, relu_bits=relu_bits, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
@@ -1203,6 +1214,7 @@ class _FusedCoarse(torch.autograd.Function):
              ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), st)
         dX0 = None
         wgrad = None
+        dx0_compact = False
         grp = _gemm_group("backward chain (" + ("rc" if S.get('relu_bits') is not None else _LINEAR_BWD_MODE) + ")").__enter__()
         if S.get('relu_bits') is not None:
             # register-resident data-gradient chain (layers n_ref-2 .. 1), dX0 as one narrow NN product, every weight / bias
@@ -1217,8 +1229,14 @@ class _FusedCoarse(torch.autograd.Function):
                 dYs[i - 1] = out
             if layers:
                 fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers))
-            dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-            _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
+            if S.get('V0c') is not None:     # compact dX0 (fgs_set_dx0_compact)
+                V0c = S['V0c']
+                dX0 = torch.empty(M, V0c.shape[1], dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dYs[0], V0c, dX0, M, V0c.shape[1], fw, logical=(M, run.dx0_cols[2], fw))
+                dx0_compact = True
+            else:
+                dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
+                _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
             wg_items = [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
                         for i in range(n_ref - 1)]
             wgrad = lambda fork: _wgrad(dev, M, wg_items, 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), fork)
@@ -1247,9 +1265,15 @@ class _FusedCoarse(torch.autograd.Function):
         grad_k0, k0_state = pre_k0 if pre_k0 is not None else _take_grid_grad(run.cache, k0_grid)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
-        call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
-             g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
-             ptr(g_grad_s), st)
+        if dx0_compact:
+            call("fgs_set_dx0_compact", 1)
+        try:
+            call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
+                 g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
+                 ptr(g_grad_s), st)
+        finally:
+            if dx0_compact:
+                call("fgs_set_dx0_compact", 0)
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:                     # (k0, mlp, join: the order of every path, see _FusedFine)
             hook('k0', [k0_grid], grad_k0)
@@ -1399,6 +1423,10 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     run.ldx0 = (cols + 3) // 4 * 4
     run.layout_i = (ctypes.c_int * 6)(model.k0_dim, len(model.posfreq), len(model.viewfreq), len(model.reffreq),
                                       int(model.use_viewdir), run.ldx0)
+    # compact dX0 (_DX0_COMPACT): columns [k0 | reflect_emb | normal] of [k0, xyz_emb, reflect_emb, normal, viewdirs_emb]:
+    # (k0 columns, width of the xyz block behind them, compact width)
+    gap_c = 3 + 6 * len(model.posfreq)
+    run.dx0_cols = (int(model.k0_dim), gap_c, int(model.k0_dim) + (3 + 6 * len(model.reffreq)) + 3)
     # the mask cache only prunes in stage 'coarse' (model/nerf.py:951)
     run.mask_grid = model.mask_cache.sdf_mask if (model.stage == 'coarse' and model.mask_cache is not None) else None
     run.inc = None

@@ -50,7 +50,8 @@ int fgs_set_inv_s_ptr(const float *inv_s_dev);
 /* Thread-local, like the two above: while on, the fine-stage backward entries (fgs_feat_fine_bwd, fgs_sdf_scatter_surv) read dX0
  * in COMPACT form -- the columns of the xyz and view-direction encodings (functions of the fixed ray inputs: no gradient is
  * needed, model/nerf.py:837-874) are absent, i.e. row = [k0 | sdf | taps | tap differences | gradient], pitch = that width
- * rounded up to 4 -- so that the caller's dX0 product only multiplies the weight columns that matter (52 of 106). */
+ * rounded up to 4 -- so that the caller's dX0 product only multiplies the weight columns that matter (52 of 106).  Coarse
+ * stages (fgs_feat_coarse_bwd): row = [k0 | reflect_emb | normal] (48 of 90 columns with the shipped coarse config). */
 int fgs_set_dx0_compact(int on);
 /* Device-resident schedule of a captured training step (model/nerf_training.py:389-436, model/adam.py:205-221).  `table` is
  * [n_rows][n_cols] floats the host fills once per stage -- row = iteration, columns = whatever per-iteration scalars the
