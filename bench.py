@@ -324,8 +324,10 @@ def main():
         opt.zero_grad(set_to_none=True)
         del res
     torch.cuda.synchronize()
-    use_graph = (args.mode == "graph" and world == 1 and not force_dist and not args.composed
-                 and os.environ.get("FGS_MLP", "rc") == "rc")
+    # (N > 1: the gradient exchange is part of the captured step -- RCCL collectives as graph nodes, the k0 brick exchange in its
+    # device-counted form; the warm-up steps below run the host-counted exchange and thereby measure the union's brick count,
+    # identical on every rank, from which the exchange capacity is derived)
+    use_graph = (args.mode == "graph" and not args.composed and os.environ.get("FGS_MLP", "rc") == "rc")
     STEP_STATS["max_survivors"] = 0
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
@@ -340,6 +342,7 @@ def main():
         from fgs_nerf_amd import fused as _fused
         seen = max(STEP_STATS["max_survivors"], 16384)
         _fused.set_sync_free(model, (int(1.5 * seen) + 4095) // 4096 * 4096)
+        opt.use_skip_flag(model._fused_cache['sync_free']['flags'][1:2].data_ptr())   # an overflowed step changes nothing
         for i in range(2):                       # allocator warm-up of the capacity-sized buffers
             train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
         torch.cuda.synchronize()
@@ -350,11 +353,16 @@ def main():
         from fgs_nerf_amd.graph_step import CapturedFineStep
         # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
         seen = max(STEP_STATS["max_survivors"], 16384)
+        if world > 1:     # (buffers are rank-local, but one number for all keeps the ranks' graphs alike)
+            seen_t = torch.tensor([seen], dtype=torch.int64, device=dev)
+            dist.all_reduce(seen_t, op=dist.ReduceOp.MAX)
+            seen = int(seen_t.item())
         capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
         captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
                                     synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
                                     global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
-                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity)
+                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity,
+                                    averager=averager if (world > 1 or force_dist) else None)
         captured.capture(batches[0])
         packed = [torch.stack(b).contiguous() for b in batches]     # rays_o / rays_d / viewdirs / target as one [4, N, 3] block
         for i in range(2):                       # two untimed replays (the first launch of a graph uploads it)
@@ -411,8 +419,13 @@ def main():
         STEP_STATS["overflow"] = bool(overflow)
     if captured is not None:
         overflow, total = captured.check()
-        if overflow:
-            raise SystemExit(f"survivor capacity {captured.capacity} overflowed during the timed region: rerun with --mode eager")
+        if overflow and world == 1:
+            raise SystemExit(f"survivor capacity {captured.capacity} (or the k0 exchange capacity {captured.exchange_capacity}) "
+                             "overflowed during the timed region: rerun with --mode eager")
+        if overflow:          # (several ranks: leaving here would strand the others in the collectives below; flag the line)
+            print(f"[bench] rank {rank}: a capacity overflowed during the timed region (exchange: {captured.exchange_overflowed()})",
+                  file=sys.stderr, flush=True)
+            STEP_STATS["overflow"] = True
         survivors_timed = total
         # A graph replay cannot carry timing events around individual kernels: the MLP kernels are timed right behind the
         # timed region, in the same process on the same model and batches, by PROFILE_STEPS eager steps of the same loop
@@ -452,7 +465,13 @@ def main():
         }
         if STEP_STATS.get("overflow"):
             line["config"]["capacity_overflow_on_rank0"] = True
-        line["config"]["step_mode"] = ("one hipGraph replay per step, no device->host read" if captured is not None
+        if captured is not None and captured.exchange_capacity is not None:
+            line["config"]["k0_exchange"] = {"form": "brick-sparse, device-counted, inside the captured step",
+                                             "capacity_bricks": captured.exchange_capacity,
+                                             "bytes_per_step": captured.exchange_capacity * 64 * 12 * 4}
+        line["config"]["step_mode"] = ("one hipGraph replay per step (gradient exchange included), no device->host read"
+                                       if captured is not None and captured.averager is not None else
+                                       "one hipGraph replay per step, no device->host read" if captured is not None
                                        else "eager launches, no device->host read (device-side survivor count)" if sync_free_eager
                                        else "eager launches, one survivor-count read per step")
         # (sync-free eager launches are issued for the buffers' CAPACITY; their algorithmic work is the rows behind the
@@ -487,6 +506,8 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or force_dist:
+        if captured is not None:
+            captured.release()        # graphs holding RCCL nodes go before the communicator does
         dist.destroy_process_group()
     if rank == 0 and line.get("broken"):
         raise SystemExit(2)

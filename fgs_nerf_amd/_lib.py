@@ -17,6 +17,10 @@ LIB_PATH = os.path.join(_HERE, "libfgs_hip.so")
 
 P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
+# The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
+# header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
+ABI_VERSION = 3
+
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
     "fgs_infer_t_minmax": [P, P, P, P, F32, F32, I64, P, P, P],
@@ -49,8 +53,8 @@ _SIGNATURES = {
     "fgs_set_dx0_compact": [I32],
     "fgs_step_scalars_tick": [P, I32, I32, P, P, I32, P, P],
     "fgs_count_guard": [P, I64, I64, P, P, P],
-    "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, F32, F32, F32, I32, P, P],
-    "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, F32, F32, F32, P, P],
+    "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, I32, F32, F32, F32, F32, I32, P, P],
+    "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, P, P, F32, F32, F32, P, P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
     "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
@@ -71,6 +75,9 @@ _SIGNATURES = {
     "fgs_brick_scatter": [P, I32, I32, I32, I32, P, I64, P, F32, P],
     "fgs_brick_flags_pts": [P, I64, P, P, I32, I32, I32, P, P],
     "fgs_brick_compact": [P, I64, P, P, P],
+    "fgs_brick_gather_dev": [P, I32, I32, I32, I32, P, P, I64, P, P],
+    "fgs_brick_scatter_dev": [P, I32, I32, I32, I32, P, P, I64, P, F32, P],
+    "fgs_brick_count_guard": [P, I64, P, P, P, P],
     "fgs_tv_loss_value": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P],
     "fgs_tv_loss_grad": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I32, P],
     "fgs_brick_masks_pts": [P, I64, P, P, I32, I32, I32, P, P],
@@ -143,13 +150,18 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run __graft_entry__.build() or `make -C fgs-nerf_amd/csrc`). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        handle.fgs_version.restype = c_int
+        handle.fgs_version.argtypes = []
+        built = int(handle.fgs_version())
+        if built != ABI_VERSION:
+            raise FgsError(f"{LIB_PATH} was built for ABI version {built}, this binding is written against {ABI_VERSION}: "
+                           "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI and the header drifted apart
             fn.argtypes = argtypes
             fn.restype = c_int
         handle.fgs_last_error.restype = c_char_p
         handle.fgs_last_error.argtypes = []
-        handle.fgs_version.restype = c_int
         handle.fgs_gemm_workspace_bytes.restype = c_int64
         handle.fgs_gemm_workspace_bytes.argtypes = []
         handle.fgs_head_bwd_scratch_floats.restype = c_int64
@@ -170,7 +182,10 @@ def lib() -> ctypes.CDLL:
 def call(name: str, *args) -> None:
     """Invoke an int-returning entry point; raise FgsError carrying fgs_last_error() on failure."""
     handle = lib()
-    rc = getattr(handle, name)(*args)
+    fn = getattr(handle, name)
+    if len(args) != len(fn.argtypes):      # (ctypes itself accepts surplus arguments to a cdecl function without a word)
+        raise FgsError(f"{name}: {len(args)} arguments given, the ABI takes {len(fn.argtypes)}")
+    rc = fn(*args)
     if rc != 0:
         msg = handle.fgs_last_error()
         raise FgsError(f"{name} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -42,6 +42,7 @@ class MaskedAdam(torch.optim.Optimizer):
         self._early = {}              # id(param) -> event of an update already applied by early_update() in this step
         self._early_stream = None
         self._dev = None              # device-resident schedule (use_device_schedule): {'ss': {group index: ptr}, 'skip': ptr}
+        self._skip = None             # skip-flag device pointer of a host-scheduled sync-free step (use_skip_flag)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def use_device_schedule(self, step_size_ptrs=None, skip_ptr=None) -> None:
@@ -68,6 +69,26 @@ class MaskedAdam(torch.optim.Optimizer):
     def set_pervoxel_lr(self, count):
         self.per_lr = count.float() / count.max()
 
+    @staticmethod
+    def _check_layout(p, st) -> None:
+        if st['exp_avg'].stride() != p.stride() or st['exp_avg_sq'].stride() != p.stride():
+            raise RuntimeError("MaskedAdam: exp_avg / exp_avg_sq must share the parameter's memory layout (the update kernels "
+                               "walk all four tensors with one flat index); load_state_dict re-lays loaded moments out")
+
+    def load_state_dict(self, state_dict) -> None:
+        """torch.optim.Optimizer.load_state_dict keeps the strides the file's tensors were saved with: moments written by the
+        reference (NCDHW-contiguous, model/adam.py state) would sit next to a channel-last `k0` here, and the kernels -- which
+        walk parameter, gradient and both moments with ONE flat offset -- would pair each element with another voxel's
+        moments.  Re-lay every loaded moment out like its parameter (a no-op when the layouts already agree)."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                if st:
+                    for k in ('exp_avg', 'exp_avg_sq'):
+                        if torch.is_tensor(st.get(k)) and st[k].shape == p.shape:
+                            st[k] = _as_layout_of(st[k].to(p.device), p)
+
     def _state_of(self, p):
         st = self.state[p]
         if not st:
@@ -76,8 +97,20 @@ class MaskedAdam(torch.optim.Optimizer):
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
-    @staticmethod
-    def _flush_small(batch, b1, b2, eps, dev=None, ss_ptr=None):
+    def use_skip_flag(self, skip_ptr=None) -> None:
+        """Sync-free steps that are NOT captured (fused.set_sync_free without a device schedule): step sizes stay host scalars,
+        but every update kernel honours the device int at `skip_ptr` -- a step whose survivor list overflowed its buffers
+        consumes its gradient and changes nothing, exactly like a captured one.  None switches it off."""
+        self._skip = skip_ptr
+
+    def _sched(self, group):
+        """(step-size device pointer or None, skip-flag device pointer or None) for `group` under the current schedule."""
+        if self._dev is not None:
+            gi = next(i for i, gr in enumerate(self.param_groups) if gr is group)
+            return self._dev['ss'][gi], self._dev['skip']
+        return None, self._skip
+
+    def _flush_small(self, batch, b1, b2, eps, ss_ptr=None, skip=None):
         n = len(batch)
         if n == 0:
             return
@@ -85,15 +118,16 @@ class MaskedAdam(torch.optim.Optimizer):
         tables = [(P * n)(*[row[k].data_ptr() for row in batch]) for k in range(4)]
         sizes = (ctypes.c_int64 * n)(*[row[0].numel() for row in batch])
         masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
-        if dev is not None:
-            ss = (P * n)(*[ss_ptr] * n)
-            call("fgs_adam_upd_multi_dev", n, *tables, sizes, ss, masked, float(b1), float(b2), float(eps), dev['skip'], stream())
-            return
         steps = (ctypes.c_int * n)(*[row[4] for row in batch])
         lrs = (ctypes.c_float * n)(*[row[5] for row in batch])
+        if ss_ptr is not None or skip is not None:
+            ss = (P * n)(*[ss_ptr] * n) if ss_ptr is not None else None
+            call("fgs_adam_upd_multi_dev", n, *tables, sizes, ss, steps, lrs, masked, float(b1), float(b2), float(eps), skip,
+                 stream())
+            return
         call("fgs_adam_upd_multi", n, *tables, sizes, steps, lrs, masked, float(b1), float(b2), float(eps), stream())
 
-    def _bricks(self, p, g, group, st, dev=None, ss_ptr=None) -> bool:
+    def _bricks(self, p, g, group, st, ss_ptr=None, skip=None) -> bool:
         """The masked update of a feature grid whose gradient lives in fused.py's persistent self-cleaning buffer: visit
         only the 4x4x4-voxel bricks recorded for this step (`p._fgs_touched`, fused._publish_touched / dist.GradAverager)
         and zero the gradient consumed (fgs_adam_upd_bricks; per element the arithmetic of masked_adam_upd,
@@ -112,51 +146,53 @@ class MaskedAdam(torch.optim.Optimizer):
         from ._lib import ptr
         b1, b2 = group['betas']
         idx, n = t['idx'], t['n']
-        tail = (int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']),
-                ss_ptr if dev is not None else None, dev['skip'] if dev is not None else None, stream())
+        self._check_layout(p, st)
+        tail = (int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']), ss_ptr, skip, stream())
         if idx is None:       # this rank's own scatter: the voxels recorded in the 64-bit brick masks
             call("fgs_adam_upd_voxels", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'], ptr(t['flags']),
                  *tail)
         else:                 # after a brick-sparse exchange: the union's bricks, whole (other ranks' voxels are not in the masks)
-            call("fgs_adam_upd_bricks", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'], ptr(idx), None,
-                 int(n), None, *tail)
+            # (device-counted exchange, dist.GradAverager.use_device_counts: the list's length is a device int64, n its capacity)
+            call("fgs_adam_upd_bricks", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *t['dims'], ptr(idx),
+                 ptr(t.get('count_dev')), int(n), None, *tail)
             t['flags'].zero_()
         gb['clean'] = True
         return True
 
-    def _update_one(self, p, g, group):
-        """The reference's per-tensor rule (model/adam.py:205-221) for one big tensor."""
-        if self._dev is not None:             # captured step: step size and skip flag come from device memory
-            from ._lib import ptr
-            dev = self._dev
-            gi = next(i for i, gr in enumerate(self.param_groups) if gr is group)
-            ss_ptr = dev['ss'][gi]
-            st = self._state_of(p)
-            g = _as_layout_of(g, p)
-            if self._bricks(p, g, group, st, dev=dev, ss_ptr=ss_ptr):
-                return
-            b1, b2 = group['betas']
-            if self.per_lr is not None and p.shape == self.per_lr.shape:
-                mode, perlr = 2, _as_layout_of(self.per_lr, p)
-            else:
-                mode, perlr = (1 if group['skip_zero_grad'] else 0), None
-            call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), ptr(perlr), p.numel(), ss_ptr,
-                 float(b1), float(b2), float(group['eps']), mode, dev['skip'], stream())
-            return
+    def _big(self, p, g, st, group, ss_ptr, skip) -> None:
+        """One launch for one big tensor: the reference's per-tensor rule (model/adam.py:205-221) -- per-voxel lr if a
+        same-shape table is set, else masked if the group says skip_zero_grad, else dense."""
+        from ._lib import ptr
         b1, b2 = group['betas']
-        hyper = (b1, b2, group['lr'], group['eps'])
-        st = self._state_of(p)
-        st['step'] += 1
-        g = _as_layout_of(g, p)
-        m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
-        if self._bricks(p, g, group, st):
-            pass
-        elif self.per_lr is not None and p.shape == self.per_lr.shape:
-            adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
-        elif group['skip_zero_grad']:
-            adam_upd_cuda.masked_adam_upd(p, g, m, v, t, *hyper)
+        if self.per_lr is not None and p.shape == self.per_lr.shape:
+            mode, perlr = 2, _as_layout_of(self.per_lr, p)
         else:
-            adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
+            mode, perlr = (1 if group['skip_zero_grad'] else 0), None
+        m, v = st['exp_avg'], st['exp_avg_sq']
+        if ss_ptr is None and skip is None:        # the reference's own three entry points (ops.adam_upd_cuda)
+            hyper = (st['step'], b1, b2, group['lr'], group['eps'])
+            if mode == 2:
+                adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, perlr, *hyper)
+            elif mode == 1:
+                adam_upd_cuda.masked_adam_upd(p, g, m, v, *hyper)
+            else:
+                adam_upd_cuda.adam_upd(p, g, m, v, *hyper)
+            return
+        self._check_layout(p, st)
+        if not (p.is_cuda and g.is_cuda and p.dtype == torch.float32 and g.stride() == p.stride()):
+            raise RuntimeError("MaskedAdam: device-schedule / skip-flag updates need float32 CUDA tensors of one layout")
+        call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(m), ptr(v), ptr(perlr), p.numel(), ss_ptr, int(st['step']),
+             float(group['lr']), float(b1), float(b2), float(group['eps']), mode, skip, stream())
+
+    def _update_one(self, p, g, group):
+        """The update of one big tensor under the current schedule (early_update's body)."""
+        ss_ptr, skip = self._sched(group)
+        st = self._state_of(p)
+        if self._dev is None:
+            st['step'] += 1           # (with a device schedule the host mirror is advanced by whoever replays the step)
+        g = _as_layout_of(g, p)
+        if not self._bricks(p, g, group, st, ss_ptr=ss_ptr, skip=skip):
+            self._big(p, g, st, group, ss_ptr, skip)
 
     @torch.no_grad()
     def early_update(self, p, grad, on_stream=None) -> bool:
@@ -168,8 +204,14 @@ class MaskedAdam(torch.optim.Optimizer):
         and ends by making the current stream wait for the update, so everything after `step()` sees the new values.
         Only valid when nothing else adds to this parameter's gradient between backward and step (no TV on it)."""
         group = next((gr for gr in self.param_groups if any(q is p for q in gr['params'])), None)
-        if group is None or not p.is_cuda or id(p) in self._early:
+        if group is None or not p.is_cuda:
             return False
+        if id(p) in self._early:
+            # a second backward pass before step() (gradient accumulation, two losses backpropagated separately): the first
+            # pass's gradient has already been applied and consumed, this one would be dropped without a word
+            raise RuntimeError("MaskedAdam.early_update: this parameter was already updated from inside an earlier backward pass "
+                               "of the same step; with several backward passes per step switch the in-backward update off "
+                               "(fused.disable_early_update)")
         if on_stream is not None:
             self._update_one(p, grad, group)
             if on_stream == 'inline':          # the caller's stream IS the stream step() runs on: ordered by issue
@@ -191,46 +233,16 @@ class MaskedAdam(torch.optim.Optimizer):
         self._early[id(p)] = done
         return True
 
-    def _step_device(self):
-        """step() with the device-resident schedule (see use_device_schedule): same kernels, same per-tensor rule."""
-        from ._lib import ptr
-        dev = self._dev
-        early, self._early = self._early, {}
-        for gi, group in enumerate(self.param_groups):
-            b1, b2 = group['betas']
-            ss_ptr = dev['ss'][gi]
-            masked = group['skip_zero_grad']
-            small = []
-            for p in group['params']:
-                if p.grad is None or id(p) in early:    # already updated by early_update()
-                    continue
-                st = self._state_of(p)
-                g = _as_layout_of(p.grad, p)
-                m, v = st['exp_avg'], st['exp_avg_sq']
-                if self._bricks(p, g, group, st, dev=dev, ss_ptr=ss_ptr):
-                    continue
-                if self.per_lr is not None and p.shape == self.per_lr.shape:
-                    mode, perlr = 2, _as_layout_of(self.per_lr, p)
-                elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
-                    small.append((p, g, m, v, 0, 0.0, masked))
-                    continue
-                else:
-                    mode, perlr = (1 if masked else 0), None
-                call("fgs_adam_upd_dev", ptr(p), ptr(g), ptr(m), ptr(v), ptr(perlr), p.numel(), ss_ptr, float(b1), float(b2),
-                     float(group['eps']), mode, dev['skip'], stream())
-            self._flush_small(small, b1, b2, group['eps'], dev=dev, ss_ptr=ss_ptr)
-        for done in early.values():
-            if done is not None:
-                torch.cuda.current_stream().wait_event(done)
-
     @torch.no_grad()
     def step(self):
-        if self._dev is not None:
-            return self._step_device()
+        """One update of every parameter that has a gradient.  Host schedule (default): step sizes from `state[p]['step']`
+        and the group's lr, as model/adam.py:195-221; device schedule (`use_device_schedule`): step sizes and the skip flag
+        are read from device memory, nothing that changes from step to step is passed by value."""
         early, self._early = self._early, {}
+        host = self._dev is None
         for group in self.param_groups:
             b1, b2 = group['betas']
-            hyper = (b1, b2, group['lr'], group['eps'])
+            ss_ptr, skip = self._sched(group)
             masked = group['skip_zero_grad']
             small = []
             for p in group['params']:
@@ -239,20 +251,18 @@ class MaskedAdam(torch.optim.Optimizer):
                 if self.before_param is not None:       # dist.GradAverager.wait_for: this gradient's exchange is done
                     self.before_param(p)
                 st = self._state_of(p)
-                st['step'] += 1
+                if host:
+                    st['step'] += 1
                 g = _as_layout_of(p.grad, p)
-                m, v, t = st['exp_avg'], st['exp_avg_sq'], st['step']
-                if self._bricks(p, g, group, st):
-                    pass
-                elif self.per_lr is not None and p.shape == self.per_lr.shape:
-                    adam_upd_cuda.adam_upd_with_perlr(p, g, m, v, _as_layout_of(self.per_lr, p), t, *hyper)
-                elif p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32:
-                    small.append((p, g, m, v, t, group['lr'], masked))
-                elif masked:
-                    adam_upd_cuda.masked_adam_upd(p, g, m, v, t, *hyper)
+                if self._bricks(p, g, group, st, ss_ptr=ss_ptr, skip=skip):
+                    continue
+                per_lr = self.per_lr is not None and p.shape == self.per_lr.shape
+                if (not per_lr and p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous()
+                        and p.dtype == torch.float32):
+                    small.append((p, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], masked))
                 else:
-                    adam_upd_cuda.adam_upd(p, g, m, v, t, *hyper)
-            self._flush_small(small, b1, b2, group['eps'])
+                    self._big(p, g, st, group, ss_ptr, skip)
+            self._flush_small(small, b1, b2, group['eps'], ss_ptr=ss_ptr, skip=skip)
         for done in early.values():                     # everything after step() sees the early updates
             if done is not None:
                 torch.cuda.current_stream().wait_event(done)

@@ -40,7 +40,7 @@ int fgs_set_error(int code, const char *fmt, ...) {
 
 FGS_API const char *fgs_last_error(void) { return g_last_error; }
 
-FGS_API int fgs_version(void) { return 1; }
+FGS_API int fgs_version(void) { return FGS_ABI_VERSION; }
 
 FGS_API int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wave_size, int64_t *lds_bytes) {
   hipDeviceProp_t prop;

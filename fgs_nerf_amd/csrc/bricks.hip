@@ -61,6 +61,64 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_brick_copy(float *__restrict__ gr
   }
 }
 
+// The same copies with the brick count in DEVICE memory (the captured multi-GPU step: nothing that sizes the exchange may pass
+// through the host).  The launch covers `capacity` rows; rows at or beyond min(*count_dev, capacity) are not part of the
+// exchange: the gather writes zeros there (the fixed-size collective then sums zeros, never stale or non-finite leftovers),
+// the scatter skips them.
+template <bool SCATTER>
+__global__ __launch_bounds__(FGS_BLOCK) void k_brick_copy_dev(float *__restrict__ grad, BrickGrid g,
+                                                              const int64_t *__restrict__ idx,
+                                                              const int64_t *__restrict__ count_dev, int64_t capacity,
+                                                              float *__restrict__ buf, float scale) {
+  __builtin_amdgcn_s_setprio(2);     // runs beside k_mlp_wgrad (the exchange branch of the captured step): memory-bound, its
+                                     // few vector instructions go first (221 -> us without: starved of issue slots)
+  const int64_t i = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= capacity) return;
+  const int64_t n = min(*count_dev, capacity);
+  float4 *row = reinterpret_cast<float4 *>(buf + i * 64 * g.C);
+  if (i >= n) {
+    if (!SCATTER)
+      for (int q = lane; q < 16 * g.C; q += FGS_WAVE) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const int64_t b = idx[i];
+  const int bz = (int)(b % g.nbz), by = (int)((b / g.nbz) % g.nby), bx = (int)(b / ((int64_t)g.nbz * g.nby));
+  for (int q = lane; q < 16 * g.C; q += FGS_WAVE) {
+    float4 *gp = reinterpret_cast<float4 *>(grad + brick_f4_offset(g, bx, by, bz, q));
+    if (SCATTER) {
+      float4 v = row[q];
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+      *gp = v;
+    } else {
+      row[q] = *gp;
+    }
+  }
+}
+
+// Guard of a device-counted brick list against the capacity of its exchange buffer.  An exchange that did not fit cannot be
+// repaired inside a captured step (every rank must issue the same fixed-size collective), and it leaves gradient behind in
+// the persistent buffer's unlisted bricks: from then on EVERY step's update is skipped (sticky[0]) until the host has looked
+// (flags[0]), cleaned up and chosen a larger capacity.  The count is all-reduced before it gets here (the union's), so all
+// ranks take the same decision in the same step.  flags as in fgs_count_guard: [0] sticky "something overflowed", [1] "the
+// optimizer kernels skip this step".
+// peer_skip (optional): the MAX over ranks of every rank's own "skip this step" flag (its survivor list did not fit), which
+// travelled with the occupancy all-reduce: a step one rank must skip is skipped by all, or the replicas would drift apart.
+__global__ void k_brick_count_guard(int64_t *__restrict__ count, int64_t capacity, int *__restrict__ flags,
+                                    int *__restrict__ sticky, const int *__restrict__ peer_skip) {
+  const int64_t n = *count;
+  if (n > capacity || *sticky) {
+    *sticky = 1;
+    flags[0] = 1;
+    flags[1] = 1;
+  }
+  if (peer_skip && *peer_skip) {
+    flags[0] = 1;
+    flags[1] = 1;
+  }
+  if (n > capacity) *count = capacity;
+}
+
 // flags[b] = 1 for every brick holding one of the 8 trilinear corners of a sample point: the bricks a DenseGrid backward
 // (fgs_trilerp_bwd / k_feat_k0_bwd) can write for these points -- known as soon as the forward has its survivor list,
 // i.e. ~2 ms before the gradient itself exists.  Plain stores of the same value: the race is benign.
@@ -166,6 +224,38 @@ FGS_API int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int
   hipLaunchKernelGGL(k_brick_copy<true>, dim3(fgs_blocks(n * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), grad, g, idx, n,
                      const_cast<float *>(buf), scale);
   FGS_LAUNCH_OK("fgs_brick_scatter");
+  return 0;
+}
+
+FGS_API int fgs_brick_gather_dev(const float *grad, int C, int X, int Y, int Z, const int64_t *idx, const int64_t *count_dev,
+                                 int64_t capacity, float *buf, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_gather_dev", C, X, Y, Z, &g)) return e;
+  FGS_REQUIRE(grad && idx && count_dev && buf && capacity > 0 && capacity <= (int64_t)g.nbx * g.nby * g.nbz, FGS_E_INVALID,
+              "fgs_brick_gather_dev: null pointer or capacity=%lld outside 1..bricks", (long long)capacity);
+  hipLaunchKernelGGL(k_brick_copy_dev<false>, dim3(fgs_blocks(capacity * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream),
+                     const_cast<float *>(grad), g, idx, count_dev, capacity, buf, 1.f);
+  FGS_LAUNCH_OK("fgs_brick_gather_dev");
+  return 0;
+}
+
+FGS_API int fgs_brick_scatter_dev(float *grad, int C, int X, int Y, int Z, const int64_t *idx, const int64_t *count_dev,
+                                  int64_t capacity, const float *buf, float scale, fgs_stream_t stream) {
+  BrickGrid g;
+  if (int e = make_grid("fgs_brick_scatter_dev", C, X, Y, Z, &g)) return e;
+  FGS_REQUIRE(grad && idx && count_dev && buf && capacity > 0 && capacity <= (int64_t)g.nbx * g.nby * g.nbz, FGS_E_INVALID,
+              "fgs_brick_scatter_dev: null pointer or capacity=%lld outside 1..bricks", (long long)capacity);
+  hipLaunchKernelGGL(k_brick_copy_dev<true>, dim3(fgs_blocks(capacity * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), grad, g,
+                     idx, count_dev, capacity, const_cast<float *>(buf), scale);
+  FGS_LAUNCH_OK("fgs_brick_scatter_dev");
+  return 0;
+}
+
+FGS_API int fgs_brick_count_guard(int64_t *count_dev, int64_t capacity, int *flags, int *sticky, const int *peer_skip,
+                                  fgs_stream_t stream) {
+  FGS_REQUIRE(count_dev && flags && sticky && capacity >= 0, FGS_E_INVALID, "fgs_brick_count_guard: bad argument");
+  hipLaunchKernelGGL(k_brick_count_guard, dim3(1), dim3(1), 0, fgs_s(stream), count_dev, capacity, flags, sticky, peer_skip);
+  FGS_LAUNCH_OK("fgs_brick_count_guard");
   return 0;
 }
 

@@ -356,26 +356,28 @@ FGS_API int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *
 }
 
 FGS_API int fgs_adam_upd_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
-                             const float *step_size_dev, float beta1, float beta2, float eps, int mode, const int *skip_dev,
-                             fgs_stream_t stream) {
+                             const float *step_size_dev, int step, float lr, float beta1, float beta2, float eps, int mode,
+                             const int *skip_dev, fgs_stream_t stream) {
   FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_adam_upd_dev: n=%lld", (long long)n);
   FGS_REQUIRE(mode >= 0 && mode <= 2, FGS_E_INVALID, "fgs_adam_upd_dev: mode=%d", mode);
   if (n == 0) return 0;
-  FGS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_size_dev && (mode != FGS_ADAM_PERLR || perlr), FGS_E_INVALID,
+  FGS_REQUIRE(param && grad && exp_avg && exp_avg_sq && (mode != FGS_ADAM_PERLR || perlr), FGS_E_INVALID,
               "fgs_adam_upd_dev: null pointer");
+  // no device-resident step size: the host arithmetic of fgs_adam_upd (adam_upd_kernel.cu:72), with the skip flag honoured
+  const float ss = step_size_dev ? 0.f : fgs_adam_step_size(step, beta1, beta2, lr);
   hipStream_t st = fgs_s(stream);
   switch (mode) {
-    case FGS_ADAM_DENSE:  return launch_adam<0>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
-    case FGS_ADAM_MASKED: return launch_adam<1>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
-    default:              return launch_adam<2>(param, grad, exp_avg, exp_avg_sq, perlr, n, 0.f, beta1, beta2, eps, st, step_size_dev, skip_dev);
+    case FGS_ADAM_DENSE:  return launch_adam<0>(param, grad, exp_avg, exp_avg_sq, perlr, n, ss, beta1, beta2, eps, st, step_size_dev, skip_dev);
+    case FGS_ADAM_MASKED: return launch_adam<1>(param, grad, exp_avg, exp_avg_sq, perlr, n, ss, beta1, beta2, eps, st, step_size_dev, skip_dev);
+    default:              return launch_adam<2>(param, grad, exp_avg, exp_avg_sq, perlr, n, ss, beta1, beta2, eps, st, step_size_dev, skip_dev);
   }
 }
 
 FGS_API int fgs_adam_upd_multi_dev(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
                                    float *const *exp_avg_sqs, const int64_t *sizes, const float *const *step_size_dev,
-                                   const int *masked, float beta1, float beta2, float eps, const int *skip_dev,
-                                   fgs_stream_t stream) {
-  FGS_REQUIRE(step_size_dev, FGS_E_INVALID, "fgs_adam_upd_multi_dev: null step-size table");
-  return adam_multi_impl(n_tensors, params, grads, exp_avgs, exp_avg_sqs, sizes, nullptr, nullptr, step_size_dev, skip_dev,
+                                   const int *steps, const float *lrs, const int *masked, float beta1, float beta2, float eps,
+                                   const int *skip_dev, fgs_stream_t stream) {
+  FGS_REQUIRE(step_size_dev || (steps && lrs), FGS_E_INVALID, "fgs_adam_upd_multi_dev: neither a step-size table nor steps + lrs");
+  return adam_multi_impl(n_tensors, params, grads, exp_avgs, exp_avg_sqs, sizes, steps, lrs, step_size_dev, skip_dev,
                          masked, beta1, beta2, eps, stream);
 }

@@ -78,6 +78,8 @@ class GradAverager:
         self._bucket = None
         self.last_sparse_fill = None      # fraction of bricks exchanged by the last sparse reduction (diagnostics)
         self._hints = {}                  # id(param) -> state of hint_touched()
+        self._static = {}                 # id(param) -> device-counted exchange (use_device_counts): capacity, buffer, guard
+        self.max_union_bricks = {}        # id(param) -> largest union brick count a host-counted exchange has seen
         self.dense_sources = {}           # id(param) -> True while a dense term (TV loss) also writes that gradient
         self.last_hint_wait_us = 0.0      # host time spent waiting for the hinted brick count (diagnostics)
 
@@ -106,26 +108,37 @@ class GradAverager:
         h = self._hints.get(id(param))
         if h is None or h['total'] != total:
             dev = pts.device
-            h = dict(total=total, flags=torch.empty(total, dtype=torch.int32, device=dev),
+            # (one entry more than there are bricks: the device-counted form sends this rank's "my survivor list overflowed"
+            # flag along with the occupancy, so that the decision to skip a step's update is the same on every rank)
+            h = dict(total=total, flags=torch.zeros(total + 1, dtype=torch.int32, device=dev),
                      idx=torch.empty(total, dtype=torch.int64, device=dev), count=torch.empty(1, dtype=torch.int64, device=dev),
                      count_host=torch.empty(1, dtype=torch.int64).pin_memory(), stream=torch.cuda.Stream(device=dev),
                      event=torch.cuda.Event(), armed=False)
             self._hints[id(param)] = h
-        if h.get('box_key') != (id(xyz_min), id(xyz_max)):      # one device->host read per box, not per step
+        box_key = (id(xyz_min), getattr(xyz_min, '_version', 0), id(xyz_max), getattr(xyz_max, '_version', 0))
+        if h.get('box_key') != box_key:      # one device->host read per box, not per step
             h['lo'] = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(xyz_min).flatten().tolist()])
             h['hi'] = (ctypes.c_float * 3)(*[float(v) for v in torch.as_tensor(xyz_max).flatten().tolist()])
-            h['box_key'] = (id(xyz_min), id(xyz_max))
+            h['box_key'] = box_key
+            h['box_objs'] = (xyz_min, xyz_max)      # kept alive: an id() in the key cannot be reused by a successor
         lo, hi = h['lo'], h['hi']
         pts = pts.detach().contiguous()
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(h['stream']):
             h['stream'].wait_event(ready)
+            sc = self._static.get(id(param))
             h['flags'].zero_()
             call("fgs_brick_flags_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(h['flags']), stream())
+            if sc is not None and sc['guard_flags'] is not None:
+                h['flags'][total:].copy_(sc['guard_flags'][1:2])                               # this rank's skip flag rides along
             dist.all_reduce(h['flags'], op=dist.ReduceOp.MAX, group=self.group)               # union over ranks
             call("fgs_brick_compact", ptr(h['flags']), total, ptr(h['idx']), ptr(h['count']), stream())
-            h['count_host'].copy_(h['count'], non_blocking=True)
+            if sc is not None:     # the count stays on the device: checked against the capacity there (csrc/bricks.hip)
+                call("fgs_brick_count_guard", ptr(h['count']), sc['capacity'], ptr(sc['flags']), ptr(sc['sticky']),
+                     ptr(h['flags'][total:]) if sc['guard_flags'] is not None else None, stream())
+            else:
+                h['count_host'].copy_(h['count'], non_blocking=True)
             h['event'].record()
         pts.record_stream(h['stream'])
         h['armed'] = True
@@ -153,6 +166,22 @@ class GradAverager:
         on_gpu = g.is_cuda
         dims = (C, nbx * BRICK, nby * BRICK, nbz * BRICK)
         h = self._hints.get(id(param)) if param is not None else None
+        sc = self._static.get(id(param)) if param is not None else None
+        if on_gpu and sc is not None:
+            # device-counted form (use_device_counts): fixed-capacity buffer, fixed-size collective, nothing read by the host
+            from ._lib import call, ptr, stream
+            if not (h is not None and h['armed'] and h['total'] == total):
+                raise RuntimeError("GradAverager: the device-counted exchange needs hint_touched() before every backward pass")
+            h['armed'] = False
+            torch.cuda.current_stream().wait_event(h['event'])
+            cap, buf = sc['capacity'], sc['buf']
+            call("fgs_brick_gather_dev", ptr(g), *dims, ptr(h['idx']), ptr(h['count']), cap, ptr(buf), stream())
+            dist.all_reduce(buf, op=self._op(), group=group)
+            call("fgs_brick_scatter_dev", ptr(g), *dims, ptr(h['idx']), ptr(h['count']), cap, ptr(buf),
+                 1.0 if self.avg_in_collective else float(inv), stream())
+            self._note_union(param, g, h['idx'], cap, count_dev=h['count'])
+            self.last_sparse_fill = None
+            return True
         if on_gpu and h is not None and h['armed'] and h['total'] == total:
             from ._lib import call, ptr, stream
             h['armed'] = False
@@ -170,6 +199,7 @@ class GradAverager:
                 self.last_hint_wait_us = 0.0
             torch.cuda.current_stream().wait_event(h['event'])
             n = int(h['count_host'][0])
+            self.max_union_bricks[id(param)] = max(self.max_union_bricks.get(id(param), 0), n)
             self.last_sparse_fill = n / max(total, 1)
             if n > self.sparse_max_fill * total:
                 return False
@@ -183,6 +213,8 @@ class GradAverager:
             call("fgs_brick_scatter", ptr(g), *dims, ptr(idx), n, ptr(buf), 1.0 if self.avg_in_collective else float(inv),
                  stream())
             return True
+        if sc is not None:
+            return self._sparse_counted_host(g, bv, inv, sc, group)
         if on_gpu:       # csrc/bricks.hip: one streaming pass over the gradient
             from ._lib import call, ptr, stream
             flags = torch.empty(total, dtype=torch.int32, device=g.device)
@@ -215,14 +247,91 @@ class GradAverager:
         bv[bx, :, by, :, bz, :, :] = buf                                                        # scatter back
         return True
 
+    def _sparse_counted_host(self, g, bv, inv, sc, group) -> bool:
+        """The device-counted exchange on HOST tensors (gloo, the CPU tests): the same protocol with torch indexing -- the
+        occupancy and this rank's skip flag are all-reduced together, the union's count is checked against the capacity
+        with `sc`'s own state (the guard kernel's rules: csrc/bricks.hip k_brick_count_guard), the collective always
+        carries `capacity` rows, rows behind the count are zero, bricks behind the capacity are left alone."""
+        nbx, _, nby, _, nbz, _, C = bv.shape
+        total = nbx * nby * nbz
+        flags = torch.zeros(total + 1, dtype=torch.int32)
+        flags[:total] = (bv != 0).any(dim=6).any(dim=5).any(dim=3).any(dim=1).reshape(-1)
+        if sc['guard_flags'] is not None:
+            flags[total] = sc['guard_flags'][1]
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        idx = flags[:total].nonzero(as_tuple=False).squeeze(1)
+        n, cap = int(idx.numel()), sc['capacity']
+        if n > cap or int(sc['sticky'][0]):
+            sc['sticky'][0] = 1
+            sc['flags'][0] = 1
+            sc['flags'][1] = 1
+        if int(flags[total]):
+            sc['flags'][0] = 1
+            sc['flags'][1] = 1
+        idx = idx[:cap]
+        bx, by, bz = idx // (nby * nbz), (idx // nbz) % nby, idx % nbz
+        buf = sc['buf'].view(cap, BRICK, BRICK, BRICK, C)
+        buf.zero_()
+        buf[:idx.numel()] = bv[bx, :, by, :, bz, :, :]
+        dist.all_reduce(sc['buf'], op=dist.ReduceOp.SUM, group=group)                           # always `capacity` rows
+        bv[bx, :, by, :, bz, :, :] = buf[:idx.numel()] * inv
+        self.last_sparse_fill = None
+        return True
+
     @staticmethod
-    def _note_union(param, g, idx, n) -> None:
+    def _note_union(param, g, idx, n, count_dev=None) -> None:
         """After a brick-sparse exchange the gradient is non-zero only inside the union's bricks: hand that list to
         MaskedAdam's brick update (adam.MaskedAdam._bricks; the record was opened by fused._publish_touched).  A dense
         exchange reports nothing, and the update then goes dense as well."""
         t = getattr(param, '_fgs_touched', None) if param is not None else None
         if t is not None and t['exchange'] and t['grad_ptr'] == g.data_ptr():
-            t['idx'], t['n'] = idx, int(n)
+            t['idx'], t['n'], t['count_dev'] = idx, int(n), count_dev     # (count_dev: n is then the list's capacity)
+
+    def use_device_counts(self, param, capacity: Optional[int], guard_flags: Optional[torch.Tensor] = None) -> None:
+        """Switch the brick-sparse exchange of the grid `param` to its DEVICE-COUNTED form (or back, capacity=None): the
+        union's brick count never reaches the host.  The exchange buffer holds `capacity` bricks and the all-reduce always
+        carries all of them (rows behind the count are zero); gather / scatter / MaskedAdam's brick update read the count
+        from device memory.  What a host-counted step decides from the number -- "too full: go dense" -- cannot be decided
+        inside a captured step, where every rank must issue the same fixed-size collective: a union that does not fit
+        raises `guard_flags[0]` and keeps `guard_flags[1]` (the optimizer kernels' skip flag, fused.set_sync_free) raised
+        from then on, on every rank alike (the count is the all-reduced union's), until the host has looked
+        (`device_count_state`), reset the gradient buffer and chosen a larger capacity.  `guard_flags`: the 2-int flag
+        buffer of fused.set_sync_free; this rank's flags[1] (its survivor list overflowed) travels with the occupancy
+        all-reduce, so that a step one rank must skip is skipped by all of them.
+        `capacity` must be the same on every rank: derive it from `suggested_capacity` (the union count is all-reduced)."""
+        if capacity is None:
+            self._static.pop(id(param), None)
+            return
+        _, C, X, Y, Z = param.shape
+        total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
+        capacity = max(1, min(int(capacity), total))
+        sc = self._static.get(id(param))
+        if sc is None or sc['capacity'] != capacity or sc['buf'].device != param.device:
+            sc = dict(capacity=capacity, buf=torch.zeros(capacity, BRICK ** 3 * C, dtype=param.dtype, device=param.device),
+                      sticky=torch.zeros(1, dtype=torch.int32, device=param.device))
+        own = guard_flags is None
+        sc['flags'] = torch.zeros(2, dtype=torch.int32, device=param.device) if own else guard_flags
+        sc['guard_flags'] = None if own else guard_flags
+        self._static[id(param)] = sc
+
+    def suggested_capacity(self, param, margin: float = 1.25, granule: int = 256) -> Optional[int]:
+        """Capacity for `use_device_counts` from the largest union brick count the host-counted exchanges of `param` have
+        seen so far (identical on every rank: the count is the all-reduced union's), or None before the first one."""
+        n = self.max_union_bricks.get(id(param))
+        if not n:
+            return None
+        return (int(n * margin) + granule - 1) // granule * granule
+
+    def device_count_state(self, param, clear: bool = False):
+        """(exchange overflowed: bool) of the device-counted exchange of `param` -- one device->host read; `clear` lowers
+        the sticky flag again (after the caller has reset the gradient buffer: fused.reset_grid_grad)."""
+        sc = self._static.get(id(param))
+        if sc is None:
+            return False
+        over = bool(int(sc['sticky'].cpu()[0]))
+        if clear:
+            sc['sticky'].zero_()
+        return over
 
     def _disarm(self, param) -> None:
         h = self._hints.get(id(param)) if param is not None else None

@@ -427,6 +427,27 @@ def _wgrad(dev, M, items, flop, fork: bool) -> None:
     _SIDE_PENDING.add(dev.index)
 
 
+# With a gradient exchange attached: the weight-gradient launch still goes to the side branch, and the exchange of the MLP
+# gradients is issued from THERE (it needs that launch's result and nothing else), so that the scatter kernels of the main
+# branch run beside both.  FGS_WGRAD_FORK_DIST=0: everything on the main stream, in issue order (the round-2 form).
+_WGRAD_FORK_DIST = os.environ.get("FGS_WGRAD_FORK_DIST", "1") == "1"
+
+
+def _wgrad_then_exchange(dev, wgrad, hook, mlp, flat) -> None:
+    if wgrad is None:
+        hook('mlp', mlp, flat)
+        return
+    if not (_WGRAD_FORK and _WGRAD_FORK_DIST):
+        wgrad(False)
+        hook('mlp', mlp, flat)
+        return
+    wgrad(True)
+    side, keep = _side(dev)
+    with torch.cuda.stream(side):
+        hook('mlp', mlp, flat)
+    keep.append(flat)
+
+
 def _flush_tn(dev) -> None:
     """"late" mode: all weight-gradient products on the side stream, started when the data-gradient chain is done, so
     that they run under the atomics-bound scatter kernels that follow on the main stream."""
@@ -572,11 +593,12 @@ def _prefill_grid_grad(run, k0_grid):
     return _take_grid_grad(run.cache, k0_grid)
 
 
-def reset_grid_grad(model) -> None:
+def reset_grid_grad(model, force: bool = False) -> None:
     """Bring the persistent feature-grid gradient buffer back to all-zero (after a backward pass whose gradient no
-    optimizer step consumed, before capturing a step in a hipGraph)."""
+    optimizer step consumed, before capturing a step in a hipGraph).  `force`: also when the host-side record says "clean"
+    (after a device-counted exchange overflowed inside a captured step, which the host-side record cannot know)."""
     gb = model.__dict__.get('_fused_cache', {}).get('k0_grad')
-    if gb is not None and not gb['clean']:
+    if gb is not None and (force or not gb['clean']):
         gb['buf'].zero_()
         gb['flags'].zero_()
         gb['clean'] = True
@@ -964,9 +986,7 @@ class _FusedFine(torch.autograd.Function):
             # the long one (tens of MB at 8 ranks) and starts first, under the weight-gradient launch and the sdf scatter
             # kernels; the MLP gradients -- views of `flat`, final after that launch -- follow
             hook('k0', [k0_grid], grad_k0)
-            if wgrad is not None:
-                wgrad(False)
-            hook('mlp', mlp, flat)
+            _wgrad_then_exchange(dev, wgrad, hook, mlp, flat)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)           # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
@@ -1277,9 +1297,7 @@ class _FusedCoarse(torch.autograd.Function):
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:                     # (k0, mlp, join: the order of every path, see _FusedFine)
             hook('k0', [k0_grid], grad_k0)
-            if wgrad is not None:
-                wgrad(False)
-            hook('mlp', mlp, flat)
+            _wgrad_then_exchange(dev, wgrad, hook, mlp, flat)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of

@@ -41,6 +41,13 @@ class CapturedFineStep:
     lr_of            : (iteration index, param-group dict) -> learning rate used by that iteration's Adam update
     tv               : None, or (weight, dense) for model.sdf_total_variation_add_grad after the backward pass
     capacity         : rows the survivor buffers hold (see fused.set_sync_free)
+    averager         : None, or a dist.GradAverager (N > 1 ranks, or a forced single-rank group): the gradient exchange becomes
+                       part of the captured step -- RCCL collectives as graph nodes, the k0 brick exchange in its
+                       device-counted form (GradAverager.use_device_counts: fixed-capacity buffer, the union's brick count
+                       stays on the device), so a multi-GPU iteration is one graph launch per rank as well.  Every rank must
+                       construct, capture and replay in lockstep (same variants, same order).
+    exchange_capacity: bricks the k0 exchange buffer holds (the same number on every rank; default: the averager's
+                       `suggested_capacity` from the host-counted exchanges of the warm-up steps, else 1/2 of the grid)
     variants         : None, or a list of dicts {'tv': ..., 'extra_loss': callable(model) -> scalar tensor or None}: one graph
                        per entry over the SAME static inputs, schedule table and counters, chosen per iteration by
                        `replay(batch, variant=k)` -- iterations of different SHAPE inside one window (the shipped fine config
@@ -50,7 +57,7 @@ class CapturedFineStep:
 
     def __init__(self, model, optimizer, loss_cfg: Dict, render_kwargs: Dict, n_rays: int, n_iters: int,
                  global_step_of: Callable[[int], int], lr_of: Callable[[int, Dict], float], tv=None,
-                 capacity: int = 131072, variants=None):
+                 capacity: int = 131072, variants=None, averager=None, exchange_capacity: Optional[int] = None):
         coarse = getattr(model, 'stage', 'fine') in ('coarse', 'geometry_searching')
         if not (fused.supports_coarse(model) if coarse else fused.supports(model)):
             raise RuntimeError("CapturedFineStep needs a model the fused path covers")
@@ -59,6 +66,15 @@ class CapturedFineStep:
         self.n_rays, self.capacity = int(n_rays), int(capacity)
         dev = model.sdf.grid.device
         self.dev = dev
+        self.averager = averager if (averager is not None and (averager.world_size > 1 or averager.force)) else None
+        self.exchange_capacity = None
+        if self.averager is not None:
+            k0 = model.k0.grid
+            cap = exchange_capacity or self.averager.suggested_capacity(k0)
+            if cap is None:
+                _, _, X, Y, Z = k0.shape
+                cap = max(1, (X // 4) * (Y // 4) * (Z // 4) // 2)
+            self.exchange_capacity = int(cap)
         # ---- schedule table: column 0 = inv_s, column 1 + g = Adam step size of param group g, last column = s_val itself
         groups = optimizer.param_groups
         optimizer.ensure_state()
@@ -83,6 +99,9 @@ class CapturedFineStep:
         self._seed = torch.ones((), dtype=torch.float32, device=dev)
         self.graphs = [None] * len(self.variants)
         self.losses = [None] * len(self.variants)
+        self._updated = [[] for _ in self.variants]
+        self._pinned = None
+        self._exchange_state = None
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _enter(self):
@@ -90,10 +109,22 @@ class CapturedFineStep:
         st = self.model._fused_cache['sync_free']
         self.opt.use_device_schedule({gi: self.scalars[1 + gi:2 + gi].data_ptr() for gi in range(len(self.opt.param_groups))},
                                      skip_ptr=st['flags'][1:2].data_ptr())
+        if self.averager is not None and self._exchange_is_sparse():
+            self.averager.use_device_counts(self.model.k0.grid, self.exchange_capacity, guard_flags=st['flags'])
+            # (the graphs will hold the addresses of the exchange buffer and of its sticky flag: this reference outlives _leave())
+            self._exchange_state = self.averager._static[id(self.model.k0.grid)]
 
     def _leave(self):
         fused.set_sync_free(self.model, None)
         self.opt.use_device_schedule(None)
+        if self.averager is not None:
+            self.averager.use_device_counts(self.model.k0.grid, None)
+
+    def _exchange_is_sparse(self) -> bool:
+        """dist.GradAverager's own (shape-only) predicate for the brick-sparse k0 exchange."""
+        k0, av = self.model.k0.grid, self.averager
+        _, C, X, Y, Z = k0.shape
+        return not (X % 4 or Y % 4 or Z % 4 or C == 1 or k0.numel() < av.sparse_min_numel)
 
     @property
     def graph(self):
@@ -114,11 +145,20 @@ class CapturedFineStep:
         var = self.variants[variant]
         if var.get('extra_loss') is not None:
             loss = loss + var['extra_loss'](self.model)
+        av = self.averager
+        if av is not None:
+            # the bricks this step's k0 gradient can touch, their union over ranks and the union's brick list -- all on a side
+            # stream under the MLP forward / backward, the count never leaving the device (GradAverager.use_device_counts)
+            with fused._DeviceScalars(count=res['survivor_count_ptr']):
+                av.hint_touched(self.model.k0.grid, res['survivor_pts'], self.model.xyz_min, self.model.xyz_max)
         self.opt.zero_grad(set_to_none=True)
         # An update issued from inside the backward pass (fused.enable_early_update: k0's Adam pass) belongs to the update: the
         # warm-up pass (update=False) must not apply it, and no record of an earlier pass may make this one skip it.
         cache = self.model.__dict__.setdefault('_fused_cache', {})
         hook = None if update else cache.pop('opt_hook', None)
+        after = None
+        if av is not None and not update:
+            after, av.after_early = av.after_early, None
         if hasattr(self.opt, '_early'):
             self.opt._early = {}
         try:
@@ -126,6 +166,12 @@ class CapturedFineStep:
         finally:
             if hook is not None:
                 cache['opt_hook'] = hook
+            if after is not None:
+                av.after_early = after
+        if av is not None:
+            av.average()                      # sdf.grad (dense); k0 and the MLP gradients were exchanged inside the backward pass
+            if not update:
+                av.wait_all()                 # (no optimizer pass will wait for the k0 exchange: join its stream here)
         if update:
             if var.get('tv') is not None:
                 self.model.sdf_total_variation_add_grad(var['tv'][0], var['tv'][1])
@@ -163,12 +209,16 @@ class CapturedFineStep:
                     # (detached: the scalar lives in the graph's pool either way, and a loss that kept its autograd graph
                     # -- the leaves' AccumulateGrad nodes, bound to THIS capture's stream -- would reach into the next capture)
                     self.losses[k] = self._body(update=True, variant=k).detach()
+                # the parameters this variant's body updated: those that had a gradient when its optimizer pass ran
+                self._updated[k] = [p for g in self.opt.param_groups for p in g['params']
+                                    if p.grad is not None]
                 self._drop_autograd_leftovers()    # (the next variant's warm-up must not find this capture's autograd nodes)
         finally:
             self._leave()
         # the capture pass itself launches nothing; schedule and counters start from a clean state
         self.counter.zero_()
         self.clear_counters()
+        self._pin_static_buffers()
 
     # ------------------------------------------------------------------------------------------------ per iteration
     def load(self, batch) -> None:
@@ -187,14 +237,47 @@ class CapturedFineStep:
         Returns the device scalar holding this iteration's loss (overwritten by the next replay of the same variant)."""
         if batch is not None:
             self.load(batch)
+        self._check_static_buffers()
         self.graphs[variant].replay()
         self.iteration += 1
-        for g in self.opt.param_groups:                    # host mirror of the step counters (state_dict, schedules)
-            for p in g['params']:
-                st = self.opt.state.get(p)
-                if st:
-                    st['step'] += 1
+        for p in self._updated[variant]:                   # host mirror of the step counters (state_dict, schedules): the
+            st = self.opt.state.get(p)                     # parameters this variant's captured body updated
+            if st:
+                st['step'] += 1
         return self.losses[variant]
+
+    def _pin_static_buffers(self) -> None:
+        """The graphs hold raw addresses of buffers that live OUTSIDE their memory pool: the persistent k0 gradient buffer and
+        its voxel flags (fused._take_grid_grad REPLACES the buffer when an eager step in between still holds the old one as
+        p.grad), the packed weight images of the MLP chains, the sync-free counters.  Keep them alive for as long as the
+        graphs exist, and remember the addresses that may legitimately change hands."""
+        cache = self.model.__dict__.setdefault('_fused_cache', {})
+        gb = cache.get('k0_grad')
+        self._pinned = dict(k0_grad=None if gb is None else (gb, gb['buf'], gb['flags']),
+                            rc_images=dict(fused.fo._RC_IMAGES), sync_free=cache.get('sync_free_buffers'),
+                            hints=None if self.averager is None else dict(self.averager._hints))
+
+    def _check_static_buffers(self) -> None:
+        pin = self._pinned
+        if not pin or pin['k0_grad'] is None:
+            return
+        gb, buf, flags = pin['k0_grad']
+        now = self.model.__dict__.get('_fused_cache', {}).get('k0_grad')
+        if now is not gb or gb['buf'] is not buf or gb['flags'] is not flags:
+            raise RuntimeError("CapturedFineStep.replay: the model's persistent k0 gradient buffer was replaced after the capture "
+                               "(an eager step in between kept k0.grad alive, or the grid changed shape): capture() again")
+        if not gb['clean']:
+            raise RuntimeError("CapturedFineStep.replay: the persistent k0 gradient buffer holds an unconsumed gradient (an eager "
+                               "backward pass without optimizer step): call fused.reset_grid_grad(model) first")
+
+    def release(self) -> None:
+        """Drop the captured graphs (and their memory pool).  With an averager, call this BEFORE
+        torch.distributed.destroy_process_group(): destroying an RCCL communicator whose collectives are still nodes of a live
+        hipGraph aborts the process (seen on ROCm 7.0 / RCCL 2.26: SIGABRT inside destroy_process_group, no message)."""
+        self.graphs = [None] * len(self.variants)
+        self.losses = [None] * len(self.variants)
+        self._pinned = None
+        torch.cuda.synchronize(self.dev)
 
     def clear_counters(self) -> None:
         buf = self.model._fused_cache['sync_free_buffers']
@@ -202,8 +285,17 @@ class CapturedFineStep:
         buf['total'].zero_()
 
     def check(self):
-        """(overflowed, survivors processed since the last clear) -- one device->host read; not for every step."""
+        """(overflowed, survivors processed since the last clear) -- one device->host read; not for every step.  `overflowed`
+        covers both capacities: a survivor list that did not fit (that step's update was skipped, on every rank) and, with an
+        averager, a k0 exchange that did not fit (`exchange_overflowed()`: every update since then was skipped)."""
         return fused.sync_free_state(self.model)
+
+    def exchange_overflowed(self) -> bool:
+        """The union of touched k0 bricks exceeded `exchange_capacity` in some replay (one device->host read).  The replicas
+        are still identical -- every rank skipped every update from that step on -- but the persistent gradient buffer holds
+        leftovers: call fused.reset_grid_grad(model), then capture again with a larger capacity."""
+        st = self._exchange_state
+        return bool(int(st['sticky'].cpu()[0])) if st is not None else False
 
 
 CapturedStep = CapturedFineStep       # (the class serves both stages; the fine stage came first)

@@ -31,8 +31,14 @@ extern "C" {
 
 typedef void *fgs_stream_t;
 
+/* ABI version: bumped whenever an entry point is added, removed or changes its argument list.  fgs_version() returns the
+ * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
+ * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
+ * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3. */
+#define FGS_ABI_VERSION 3
+
 const char *fgs_last_error(void);
-int fgs_version(void);                       /* ABI version, currently 1 */
+int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
 /* Fills name (<=255 chars + NUL), CU count, wavefront size, LDS bytes per CU. */
 int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wave_size, int64_t *lds_bytes);
 
@@ -70,14 +76,16 @@ int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, i
  * of a sync-free step: model/nerf.py:802-833's nonzero / cumsum without the host). */
 int fgs_exclusive_scan_guard_i64(const int64_t *in, int64_t n, int64_t *out, int64_t capacity, int *flags, int64_t *total,
                                  fgs_stream_t stream);
-/* fgs_adam_upd / fgs_adam_upd_multi with the step size read from device memory (one float per call / per tensor) and an
- * optional skip flag; everything else as in the host-scalar forms. */
+/* fgs_adam_upd / fgs_adam_upd_multi with an optional skip flag and the step size read from device memory (one float per
+ * call / per tensor).  step_size_dev == NULL: the step size is computed on the host from (step, lr) / (steps, lrs) exactly as
+ * the host-scalar forms do -- the form a sync-free step that is NOT captured uses: host schedule, device-side skip flag. */
 int fgs_adam_upd_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, const float *perlr, int64_t n,
-                     const float *step_size_dev, float beta1, float beta2, float eps, int mode, const int *skip_dev,
-                     fgs_stream_t stream);
+                     const float *step_size_dev, int step, float lr, float beta1, float beta2, float eps, int mode,
+                     const int *skip_dev, fgs_stream_t stream);
 int fgs_adam_upd_multi_dev(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avgs,
                            float *const *exp_avg_sqs, const int64_t *sizes, const float *const *step_size_dev,
-                           const int *masked, float beta1, float beta2, float eps, const int *skip_dev, fgs_stream_t stream);
+                           const int *steps, const float *lrs, const int *masked, float beta1, float beta2, float eps,
+                           const int *skip_dev, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * render_utils_cuda  (model/cuda/render_utils.cpp:170-184)
@@ -190,6 +198,23 @@ int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, 
 /* idx[0 .. *count) = ascending indices of the set flags, entirely on the device (idx holds `total` entries, count is a
  * device int64): the exchange is sized from a count fetched asynchronously, never from a blocking nonzero(). */
 int fgs_brick_compact(const int *flags, int64_t total, int64_t *idx, int64_t *count, fgs_stream_t stream);
+/* The exchange with its brick count in DEVICE memory (the captured multi-GPU step: the count that sizes the exchange never
+ * reaches the host).  buf holds `capacity` rows of 64 C floats and the collective always carries all of them; the launches
+ * cover `capacity` rows and use the first min(*count_dev, capacity): the gather zero-fills the rows behind them, the
+ * scatter leaves their bricks alone.
+ * fgs_brick_count_guard (one thread, after fgs_brick_compact + the union all-reduce of the flags, hence identical on every
+ * rank): if *count_dev > capacity, or *sticky is already set: *sticky = flags[0] = flags[1] = 1 -- flags as in
+ * fgs_count_guard: the optimizer entry points skip their update while flags[1] != 0, and an exchange overflow keeps it
+ * raised (a truncated exchange leaves unconsumed gradient behind in the persistent buffer) until the host has reset the
+ * buffer and cleared *sticky; *count_dev is cut to the capacity.  peer_skip (may be NULL): a device int holding the MAX over
+ * ranks of each rank's own flags[1] (it travels with the flags' all-reduce); non-zero raises flags[0] and flags[1] for this
+ * step, so that a step one rank has to skip (its survivor list overflowed) is skipped by every rank. */
+int fgs_brick_gather_dev(const float *grad, int C, int X, int Y, int Z, const int64_t *idx, const int64_t *count_dev,
+                         int64_t capacity, float *buf, fgs_stream_t stream);
+int fgs_brick_scatter_dev(float *grad, int C, int X, int Y, int Z, const int64_t *idx, const int64_t *count_dev,
+                          int64_t capacity, const float *buf, float scale, fgs_stream_t stream);
+int fgs_brick_count_guard(int64_t *count_dev, int64_t capacity, int *flags, int *sticky, const int *peer_skip,
+                          fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Ray-dependent loss terms of one iteration -- model/nerf_training.py:308-327 (+ nerf.orientation_loss,

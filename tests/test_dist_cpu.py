@@ -84,3 +84,61 @@ def test_shard_rays_partitions_the_batch():
         assert all(parts[i].stop == parts[i + 1].start for i in range(p - 1))
         sizes = [s.stop - s.start for s in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _counted_worker(rank, world, port, out):
+    """The device-counted form of the brick exchange (GradAverager.use_device_counts), on host tensors: fixed-capacity buffer,
+    the union's count never used to size anything, overflow decided from the all-reduced count.  The two ranks touch
+    DIFFERENT voxels in every step (different histories); the schedule makes step 2 overflow the capacity."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fgs_nerf_amd.dist import GradAverager
+        k0 = torch.nn.Parameter(torch.zeros(1, 4, 8, 12, 16).contiguous(memory_format=torch.channels_last_3d))
+        n_bricks = 2 * 3 * 4
+        guard = torch.zeros(2, dtype=torch.int32)              # [0] sticky "something overflowed", [1] "skip this step"
+        avg = GradAverager([k0], big_numel=256, sparse_min_numel=1024)
+        avg.use_device_counts(k0, capacity=6, guard_flags=guard)
+        assert avg._static[id(k0)]['buf'].shape == (6, 64 * 4)
+        touched_per_step = [2, 3, 6, 1, 2]                     # voxels per rank; bricks in the union: <= 2x that
+        log = []
+        ok = True
+        for step, n_vox in enumerate(touched_per_step):
+            gen = torch.Generator().manual_seed(100 * step + rank)
+            g = torch.zeros_like(k0)
+            flat = g[0].permute(1, 2, 3, 0).reshape(-1, 4)
+            # each voxel in its own brick (one voxel per brick index), rank-dependent choice
+            bricks = torch.randperm(n_bricks, generator=gen)[:n_vox]
+            for b in bricks.tolist():
+                bx, by, bz = b // 12, (b // 4) % 3, b % 4
+                flat[((bx * 4) * 12 + by * 4) * 16 + bz * 4] = torch.randn(4, generator=gen)
+            k0.grad = g
+            local = g.detach().clone()
+            guard[1] = 1 if (step == 1 and rank == 1) else 0   # rank 1's own survivor list "overflowed" in step 1
+            avg.average()
+            ref = local.clone()
+            dist.all_reduce(ref)
+            ref /= world
+            union = int(((ref != 0).reshape(1, 4, 2, 4, 3, 4, 4, 4).any(7).any(5).any(3).any(1)).sum())
+            same = torch.allclose(k0.grad, ref, atol=1e-7)
+            log.append((step, union, int(guard[0]), int(guard[1]), bool(same)))
+        out[rank] = log
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_counted_exchange_world2_overflow_protocol():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_counted_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert [r[:4] for r in a] == [r[:4] for r in b], (a, b)       # both ranks: same union counts, same flags, every step
+    by_step = {r[0]: r for r in a}
+    assert by_step[0][1] <= 6 and by_step[0][2:] == (0, 0, True)   # fits: equal to the dense all-reduce, nothing raised
+    assert by_step[1][3] == 1 and by_step[1][4]                     # rank 1's skip flag reached rank 0 as well; values still exact
+    assert by_step[2][1] > 6 and by_step[2][2:4] == (1, 1)         # the union did not fit: sticky + skip on both ranks
+    assert by_step[3][1] <= 6 and by_step[3][2:4] == (1, 1)        # ... and it STAYS raised although this union fits
+    assert all(r[4] for r in a if r[0] in (0, 1)) and all(r[4] for r in b if r[0] in (0, 1))

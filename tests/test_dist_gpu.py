@@ -326,3 +326,90 @@ def test_sync_free_eager_steps_with_the_exchange_match_plain_steps(dev):
             assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 3e-3
     finally:
         dist.destroy_process_group()
+
+
+def _train(model, opt, avg, batches, steps, n_rays, captured_capacity=None, exchange_capacity=None):
+    """`steps` training iterations over `batches`: eager sync-free steps with the host-counted exchange (bench.train_step), or --
+    with `captured_capacity` -- one hipGraph replay each with the exchange captured inside (device-counted k0 exchange)."""
+    import bench
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.graph_step import CapturedFineStep
+    if captured_capacity is None:
+        fused.set_sync_free(model, 32768)
+        opt.use_skip_flag(model._fused_cache['sync_free']['flags'][1:2].data_ptr())
+        for i in range(steps):
+            bench.train_step(model, opt, avg, batches[i % len(batches)], n_rays)
+        torch.cuda.synchronize()
+        state = fused.sync_free_state(model)
+        fused.set_sync_free(model, None)
+        opt.use_skip_flag(None)
+        return state, None
+    cap = CapturedFineStep(model, opt, synth.FINE_LOSS, synth.RENDER_KWARGS, n_rays, n_iters=steps + 4,
+                           global_step_of=lambda it: bench.GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
+                           tv=(0.01 * 0.1 / n_rays, True), capacity=captured_capacity, averager=avg,
+                           exchange_capacity=exchange_capacity)
+    cap.capture(batches[0])
+    for i in range(steps):
+        cap.replay(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    return cap.check(), cap
+
+
+def test_captured_step_with_exchange_matches_eager_exchange(dev):
+    """The multi-GPU iteration as ONE graph replay: RCCL collectives captured as graph nodes (a real RCCL group of one), the k0
+    brick exchange in its device-counted form (fixed-capacity buffer, union count on the device), k0's Adam pass issued
+    behind it on the exchange stream -- against the same iterations issued eagerly with the host-counted exchange.  Then the
+    overflow contract: an exchange buffer that cannot hold the union raises the sticky flag, and from that replay on no
+    parameter changes any more."""
+    import bench
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.dist import GradAverager
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    caps = []
+    try:
+        N, STEPS = 1024, 5
+        batches = []
+        for b in range(2):
+            ro, rd, vd = synth.random_rays(N, seed=60 + b)
+            batches.append(tuple(t.to(dev).contiguous() for t in (ro, rd, vd, torch.rand(N, 3, generator=torch.Generator().manual_seed(b)))))
+        outs = {}
+        for mode in ("eager", "captured"):
+            model = synth.build_model(64, synth.FINE_MODEL, device=dev)
+            opt = bench.make_optimizer(model)
+            avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16)
+            avg.attach(model)
+            avg.attach_optimizer(opt)
+            fused.enable_early_update(model, opt, avg)
+            bench.STEP_STATS.update(survivors=0, max_survivors=0)
+            (overflow, total), cap = _train(model, opt, avg, batches, STEPS, N, captured_capacity=32768 if mode == "captured" else None,
+                                            exchange_capacity=2048 if mode == "captured" else None)
+            caps.append(cap)
+            assert not overflow and total > 0, mode
+            if cap is not None:
+                assert not cap.exchange_overflowed()
+                assert all(opt.state[p]['step'] == STEPS for g in opt.param_groups for p in g['params'])
+            outs[mode] = (total, [p.detach().clone() for p in model.parameters()])
+        assert abs(outs["eager"][0] - outs["captured"][0]) <= 8
+        for pa, pb in zip(outs["eager"][1], outs["captured"][1]):
+            assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 3e-3
+        # overflow: 16 bricks cannot hold the union of a 1024-ray batch
+        model = synth.build_model(64, synth.FINE_MODEL, device=dev)
+        opt = bench.make_optimizer(model)
+        avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16)
+        avg.attach(model)
+        avg.attach_optimizer(opt)
+        fused.enable_early_update(model, opt, avg)
+        before = [p.detach().clone() for p in model.parameters()]
+        (overflow, _), cap = _train(model, opt, avg, batches, 3, N, captured_capacity=32768, exchange_capacity=16)
+        caps.append(cap)
+        assert overflow and cap.exchange_overflowed()
+        assert all(torch.equal(p.detach(), b) for p, b in zip(model.parameters(), before))     # every update was skipped
+    finally:
+        for c in caps:            # graphs holding RCCL nodes go before the communicator does (CapturedFineStep.release)
+            if c is not None:
+                c.release()
+        dist.destroy_process_group()
