@@ -147,7 +147,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
                                                              const float *__restrict__ dX0,
                                                              const float *__restrict__ tot_sdf,
                                                              const float *__restrict__ tot_grad,
-                                                             float *__restrict__ sdf_grad_grid) {
+                                                             float *__restrict__ sdf_grad_grid, int prio) {
+  fgs_setprio(prio);      // (FGS_PRIO_TAPS_BWD: the kernel runs beside k_mlp_wgrad, see fused.py _wgrad)
   S.M = fgs_rows(S.M, S.m_dev);
   // (launched for a CAPACITY of rows under a device-side count: workgroups wholly beyond the count leave before they clear,
   // walk and flush their bricks -- 14 us of a 110 us launch at capacity = 1.5 x count)
@@ -878,8 +879,9 @@ FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_m
   S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  static const int prio = fgs_env_int("FGS_PRIO_TAPS_BWD", 0);
   hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks((M + TAPS_GROUP - 1) / TAPS_GROUP * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
-                     tot_grad, sdf_grad_grid);
+                     tot_grad, sdf_grad_grid, prio);
   FGS_LAUNCH_OK("fgs_sdf_scatter_surv");
   return 0;
 }

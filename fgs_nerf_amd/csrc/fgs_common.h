@@ -44,7 +44,22 @@ static inline unsigned fgs_blocks(int64_t n, int per_block = FGS_BLOCK) {
   return (unsigned)((n + per_block - 1) / per_block);
 }
 
+// Tuning knob read once per call site from the environment (experiments with the co-scheduling of the backward pass's two
+// graph branches: DESIGN.md section 3).  Not part of the ABI: a missing variable means the default.
+#include <stdlib.h>
+static inline int fgs_env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 // ------------------------------------------------------------------------------------ device
+
+// s_setprio with a run-time (wave-uniform) level: the instruction takes an immediate.
+__device__ __forceinline__ void fgs_setprio(int p) {
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
 
 // Rows a kernel really has to process: the host count, or -- under fgs_set_row_count_ptr -- the device count clamped to
 // the capacity the host count then stands for.  A wave-uniform scalar load.

@@ -205,9 +205,11 @@ struct MarchBwdArgs {
   const float *g_gradient;  // [M_s,3] from the feature path (normal, reflection, gradient feature), or null
   float *grad_sdf_grid;     // [X,Y,Z] accumulated with atomics
   float *tot_sdf, *tot_grad;  // [M_s], [M_s,3]: if non-null, survivors' totals are written here instead of scattered
+  int prio;                   // s_setprio level (FGS_PRIO_MARCH_BWD): the kernel runs beside k_mlp_wgrad, see fused.py _wgrad
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
+  fgs_setprio(A.prio);
   if (A.inv_s_dev) A.inv_s = *A.inv_s_dev;
   const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + fgs_uniform((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -426,6 +428,11 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
   A.g_weights = g_weights; A.g_last = g_last; A.g_sdf = g_sdf; A.g_gradient = g_gradient; A.grad_sdf_grid = grad_sdf_grid;
   FGS_REQUIRE(!tot_sdf == !tot_grad, FGS_E_INVALID, "fgs_march_fine_bwd: tot_sdf and tot_grad go together");
   A.tot_sdf = tot_sdf; A.tot_grad = tot_grad;
+  // (beside k_mlp_wgrad this kernel is the long pole of its branch: 160-170 us against 27 alone.  Level 1 lets its vector
+  // instructions go first: 1.820 -> 1.810 ms/step; levels 2 / 3, the same for the sdf scatter, fewer weight-gradient workgroups
+  // or k0's Adam pass moved to the branch's end all measured within +-0.5 % or worse: scripts/r3_branch_sweep*.sh)
+  static const int prio = fgs_env_int("FGS_PRIO_MARCH_BWD", 1);
+  A.prio = prio;
   hipLaunchKernelGGL(k_march_fine_bwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
   FGS_LAUNCH_OK("fgs_march_fine_bwd");
   return 0;

@@ -409,6 +409,10 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       cus <= 0)
     cus = 256;
+  // FGS_WGRAD_CUS: fewer workgroups than CUs (shares re-dealt over them) leaves whole CUs to the kernels of the other graph
+  // branch that run beside this launch (fused.py _wgrad); measured values in DESIGN.md section 3
+  static const int cus_env = fgs_env_int("FGS_WGRAD_CUS", 0);
+  if (cus_env > 0 && cus_env < cus) cus = cus_env;
   // one workgroup per CU (256 accumulator registers per lane); blocks get workgroups in proportion to their MFMA count,
   // at least one each, never more than one per 64 samples
   const int64_t max_per_block = (M + 63) / 64;

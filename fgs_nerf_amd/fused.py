@@ -410,6 +410,10 @@ _WGRAD_FORK = os.environ.get("FGS_WGRAD_FORK", "1") == "1"
 _MARCH_FIRST = os.environ.get("FGS_MARCH_FIRST", "0") == "1"
 # dX0 (d loss / d first-layer input) computed and read in compact form: without the columns of the xyz / view-direction encodings
 _DX0_COMPACT = os.environ.get("FGS_DX0_COMPACT", "1") == "1"
+# One GPU: where on the main branch k0's in-backward Adam pass (memory-bound; 35 us alone, ~180 us beside k_mlp_wgrad, whose
+# registers and LDS leave its waves two slots per SIMD) is issued: right behind the feature-grid scatter (0), or as the branch's
+# last kernel (1), where it mostly runs after the weight-gradient launch has drained.
+_K0_ADAM_LATE = os.environ.get("FGS_K0_ADAM_LATE", "0") == "1"
 _SIDE_PENDING = set()
 
 
@@ -427,25 +431,24 @@ def _wgrad(dev, M, items, flop, fork: bool) -> None:
     _SIDE_PENDING.add(dev.index)
 
 
-# With a gradient exchange attached: the weight-gradient launch still goes to the side branch, and the exchange of the MLP
-# gradients is issued from THERE (it needs that launch's result and nothing else), so that the scatter kernels of the main
-# branch run beside both.  FGS_WGRAD_FORK_DIST=0: everything on the main stream, in issue order (the round-2 form).
+# With a gradient exchange attached the weight-gradient launch goes to the side branch as well (issued BEFORE the feature-grid
+# scatter, like on one GPU), and the exchange of the MLP gradients is issued from that branch -- it needs that launch's result
+# and nothing else -- AFTER the host has issued k0's exchange: collectives of one communicator execute in issue order, and
+# k0's (the long one) must not queue behind a collective that waits ~430 us for the weight-gradient launch.
+# FGS_WGRAD_FORK_DIST=0: weight gradients and their exchange on the main stream, in issue order (the round-2 form).
 _WGRAD_FORK_DIST = os.environ.get("FGS_WGRAD_FORK_DIST", "1") == "1"
 
 
-def _wgrad_then_exchange(dev, wgrad, hook, mlp, flat) -> None:
-    if wgrad is None:
-        hook('mlp', mlp, flat)
+def _exchange_mlp(dev, wgrad, forked, hook, mlp, flat) -> None:
+    if forked:
+        side, keep = _side(dev)
+        with torch.cuda.stream(side):
+            hook('mlp', mlp, flat)
+        keep.append(flat)
         return
-    if not (_WGRAD_FORK and _WGRAD_FORK_DIST):
+    if wgrad is not None:
         wgrad(False)
-        hook('mlp', mlp, flat)
-        return
-    wgrad(True)
-    side, keep = _side(dev)
-    with torch.cuda.stream(side):
-        hook('mlp', mlp, flat)
-    keep.append(flat)
+    hook('mlp', mlp, flat)
 
 
 def _flush_tn(dev) -> None:
@@ -931,9 +934,11 @@ class _FusedFine(torch.autograd.Function):
         # One GPU: the weight-gradient launch is forked off here and everything below runs beside it (_MARCH_FIRST: the two
         # vector-bound kernels of the sdf path first, see there).
         march_first = wgrad is not None and hook is None and _MARCH_FIRST
-        if wgrad is not None and hook is None and not march_first:
-            wgrad(True)                          # on a side stream, beside everything below
-            wgrad = None
+        forked = False
+        if wgrad is not None and not march_first and (hook is None or (_WGRAD_FORK and _WGRAD_FORK_DIST)):
+            wgrad(True)                          # on a side stream, beside everything below (with an exchange attached too:
+            wgrad = None                         # the MLP gradients' exchange is then issued from that stream, see below)
+            forked = hook is not None
 
         # 5. features -> grids
         if run.pre is not None:
@@ -986,8 +991,8 @@ class _FusedFine(torch.autograd.Function):
             # the long one (tens of MB at 8 ranks) and starts first, under the weight-gradient launch and the sdf scatter
             # kernels; the MLP gradients -- views of `flat`, final after that launch -- follow
             hook('k0', [k0_grid], grad_k0)
-            _wgrad_then_exchange(dev, wgrad, hook, mlp, flat)
-        elif opt_hook is not None:
+            _exchange_mlp(dev, wgrad, forked, hook, mlp, flat)
+        elif opt_hook is not None and not _K0_ADAM_LATE:
             opt_hook(k0_grid, grad_k0)           # MaskedAdam.early_update: k0's Adam pass runs beside them too
         # 6. march backward
         if not march_first:
@@ -1001,6 +1006,8 @@ class _FusedFine(torch.autograd.Function):
         finally:
             if compact:
                 call("fgs_set_dx0_compact", 0)
+        if hook is None and opt_hook is not None and _K0_ADAM_LATE:
+            opt_hook(k0_grid, grad_k0)           # ... as the LAST kernel of this branch (see _K0_ADAM_LATE)
 
         _join_side(dev)
         if hook is not None:
@@ -1274,9 +1281,11 @@ class _FusedCoarse(torch.autograd.Function):
         grp.__exit__()
         _flush_tn(dev)
         hook, opt_hook = _early_hooks(run)
-        if wgrad is not None and hook is None:
+        forked = False
+        if wgrad is not None and (hook is None or (_WGRAD_FORK and _WGRAD_FORK_DIST)):
             wgrad(True)
             wgrad = None
+            forked = hook is not None
         if run.pre is not None:
             d4, pre_k0 = run.pre
             run.pre = None
@@ -1297,7 +1306,7 @@ class _FusedCoarse(torch.autograd.Function):
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:                     # (k0, mlp, join: the order of every path, see _FusedFine)
             hook('k0', [k0_grid], grad_k0)
-            _wgrad_then_exchange(dev, wgrad, hook, mlp, flat)
+            _exchange_mlp(dev, wgrad, forked, hook, mlp, flat)
         elif opt_hook is not None:
             opt_hook(k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of

@@ -403,11 +403,12 @@ def test_captured_step_with_exchange_matches_eager_exchange(dev):
         avg.attach(model)
         avg.attach_optimizer(opt)
         fused.enable_early_update(model, opt, avg)
-        before = [p.detach().clone() for p in model.parameters()]
+        trained = [p for g in opt.param_groups for p in g['params']]      # (model.s_val follows the schedule regardless)
+        before = [p.detach().clone() for p in trained]
         (overflow, _), cap = _train(model, opt, avg, batches, 3, N, captured_capacity=32768, exchange_capacity=16)
         caps.append(cap)
         assert overflow and cap.exchange_overflowed()
-        assert all(torch.equal(p.detach(), b) for p, b in zip(model.parameters(), before))     # every update was skipped
+        assert all(torch.equal(p.detach(), b) for p, b in zip(trained, before))     # every update was skipped
     finally:
         for c in caps:            # graphs holding RCCL nodes go before the communicator does (CapturedFineStep.release)
             if c is not None:
