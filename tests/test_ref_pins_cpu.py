@@ -1,0 +1,95 @@
+"""The oracle against golden vectors produced by the REFERENCE'S OWN pure-torch functions (tests/golden/ref_fns.npz, written by
+oracle/make_golden_ref_fns.py: single function definitions taken out of model/nerf.py, model/dvgo.py and model/grid.py with
+`ast` and executed on fixed inputs -- the modules themselves cannot be imported).  Every comparison here pins a
+piece of oracle/oracle.py (or the C restatement behind it) to reference-executed arithmetic; tests/test_ref_pins_gpu.py
+pins the HIP kernels to the same vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+
+@pytest.fixture(scope="module")
+def ref(golden):
+    g = golden("ref_fns.npz")
+    return {k: (torch.from_numpy(g[k]) if g[k].dtype.kind in "fbiu" else g[k]) for k in g.files}
+
+
+def test_fixture_names_the_reference_lines_it_executed(ref):
+    names = {s.split(":")[0] for s in ref["source_lines"].tolist()}
+    assert {"tv_nerf", "tv_dvgo", "cumprod_exclusive", "get_ray_marching_ray", "neus_sdf_gradient", "_gaussian_3dconv",
+            "grid_sampler", "DenseGrid.forward", "MaskCache.forward", "sample_ray_ori", "l2_normalize", "orientation_loss",
+            "density_total_variation", "k0_total_variation", "init_gradient_conv"} <= names
+
+
+@pytest.mark.parametrize("variant", ["nerf", "dvgo"])
+def test_total_variation_matches_the_reference(oracle, ref, variant):
+    """model/nerf.py:1212-1221 and model/dvgo.py:420-428, with and without mask, 1 and 12 channels."""
+    for v, m, tag in ((ref["tv_v1"], ref["tv_m1"], "v1"), (ref["tv_v12"], ref["tv_m12"], "v12")):
+        assert torch.equal(oracle.total_variation(v, None, variant), ref[f"tv_{variant}_{tag}"])
+        assert torch.equal(oracle.total_variation(v, m.bool(), variant), ref[f"tv_{variant}_{tag}_m"])
+
+
+def test_alpha2weight_matches_cumprod_compositing_without_early_stop(oracle, ref):
+    """model/dvgo.py:409-417 (cumprod_exclusive / get_ray_marching_ray): on rays that never reach T < 1e-3 the C restatement of
+    alpha2weight (render_utils_kernel.cu:576-605: the sequential product, early stop never taken) must give the same weights and
+    the same final transmittance.  Tolerance 1e-6 relative: torch's CPU cumprod accumulates a float32 row in DOUBLE
+    (at::acc_type), the kernel's running product T *= (1 - alpha) is float32 -- 23 factors differ by up to 3 ulp (3.6e-7 seen)."""
+    alpha = ref["crm_alpha"]
+    n_rays, n_s = alpha.shape
+    ray_id = torch.arange(n_rays).repeat_interleave(n_s)
+    w, last, i_end = oracle.alphas2weights(alpha.reshape(-1).contiguous(), ray_id, n_rays)
+    assert float(ref["crm_alphainv_cum"].min()) > 1e-3                       # the premise: no early termination
+    assert np.array_equal(np.asarray(i_end), (np.arange(n_rays) + 1) * n_s)   # every ray ran to its end
+    np.testing.assert_allclose(w.reshape(n_rays, n_s).numpy(), ref["crm_weights"].numpy(), rtol=1e-6, atol=0)
+    np.testing.assert_allclose(last.numpy(), ref["crm_alphainv_cum"][:, -1].numpy(), rtol=1e-6, atol=0)
+
+
+def test_gradient_volume_matches_the_reference(oracle, ref):
+    """model/nerf.py:485-494 ('interpolate')."""
+    assert torch.equal(oracle.neus_sdf_gradient(ref["gv_sdf"], ref["gv_voxel_size"]), ref["gv_interpolate"])
+
+
+@pytest.mark.parametrize("ks,sigma", [(3, 1.0), (5, 0.8)])
+def test_gaussian_smoothing_matches_the_reference(oracle, ref, ks, sigma):
+    """model/nerf.py:260-272: the taps, and the replicate-padded convolution with them."""
+    k = oracle.gaussian_kernel3d(ks, sigma)
+    assert torch.equal(k, ref[f"smooth_w_{ks}"][0, 0])
+    assert rel_l2(oracle.smooth_conv(ref["gv_sdf"], k), ref[f"smooth_out_{ks}"]) < 1e-7
+
+
+def test_tv_smoothing_taps_match_the_reference(oracle, ref):
+    """model/nerf.py:226-236,250-252 (tv_smooth_conv of init_gradient_conv), sigma 0 and 0.5."""
+    assert torch.equal(oracle.tv_smooth_kernel(0), ref["tvsmooth_w_0"][0, 0])
+    assert torch.equal(oracle.tv_smooth_kernel(0.5), ref["tvsmooth_w_05"][0, 0])
+
+
+def test_l2_normalize_and_orientation_loss_match_the_reference(oracle, ref):
+    """model/nerf.py:480-483 and :469-478."""
+    assert torch.equal(oracle.l2_normalize(ref["l2n_x"]), ref["l2n_out"])
+    res = dict(rgb_marched=torch.zeros(1, 3), weights=ref["ori_weights"], normal=ref["ori_normal"], viewdirs=ref["ori_viewdirs"])
+    loss = oracle.fine_losses(res, torch.zeros(1, 3), dict(weight_main=0.0, weight_orientation=1.0))
+    assert torch.equal(loss, ref["ori_loss"])
+
+
+@pytest.mark.parametrize("C", [1, 3, 12])
+def test_trilinear_lookup_matches_the_reference(oracle, ref, C):
+    """model/grid.py:49-68 (DenseGrid.forward) and model/nerf.py:639-672 (grid_sampler, sample_ret): points inside, on the
+    faces, and outside the box (zero padding)."""
+    out = oracle.dense_grid_forward(ref[f"tri_grid_{C}"], ref["tri_pts"], ref["tri_lo"], ref["tri_hi"])
+    assert torch.equal(out, ref[f"tri_dense_{C}"])
+    assert torch.equal(out, ref[f"tri_sampler_{C}"])
+
+
+def test_padded_sampler_matches_the_reference(oracle, ref):
+    """model/nerf.py:734-758 (sample_ray_ori, is_train=False)."""
+    P = dict(xyz_min=torch.tensor([-1.0] * 3), xyz_max=torch.tensor([1.0] * 3), voxel_size=torch.tensor(2.0 / 15))
+    pts, mask, step = oracle.sample_ray_ori(P, (16, 16, 16), ref["sro_rays_o"], ref["sro_rays_d"], 2.0, 6.0, 0.5)
+    assert torch.equal(pts, ref["sro_pts"]) and torch.equal(mask, ref["sro_mask_outbbox"].bool()) and torch.equal(step, ref["sro_step"])
+
+
+def test_mask_cache_matches_the_reference(oracle, ref):
+    """model/nerf.py:1193-1209 (max-pooled mask, trilinear sample >= thres)."""
+    mc = oracle.make_mask_cache(ref["mc_raw"], ref["tri_lo"], ref["tri_hi"], 1e-3)
+    assert torch.equal(oracle.mask_cache_forward(mc, ref["mc_pts"]), ref["mc_keep"].bool())
