@@ -863,11 +863,14 @@ class _FusedFine(torch.autograd.Function):
 
         if M == 0:
             return _FusedFine._backward_empty(run, sdf_grid, k0_grid, mlp, rgb_w, ref_w, rw, fw, ldx0, ldz)
+        _seam(run, 'inputs', g_rgb_marched=g_rgb_marched, g_sigmoid_rgb=g_sigmoid_rgb, g_last=g_last, g_weights=g_weights,
+              g_raw_rgb=g_raw_rgb, g_normal=g_normal)
         # 1. compositing
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
         call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
              ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
+        _seam(run, 'composite', d_out=d_out, d_w=d_w)
 
         # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised): one zero fill for all of
         # them, views of a flat buffer, each 16-byte aligned.  The layout is cached; only the three views the head kernel
@@ -887,6 +890,7 @@ class _FusedFine(torch.autograd.Function):
         gw_last, gb_last, gb_prev = view(i_gw_ref + n_ref - 1), view(i_gb_ref + n_ref - 1), view(i_gb_ref + n_ref - 2)
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_last),
              ptr(gb_last), ptr(gb_prev), ptr(_head_scratch(fw, dev)), st)
+        _seam(run, 'head', dY=dY)
         views = [view(i) for i in range(len(items))]
         gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
         gb_rgb = views[i_gb_rgb:i_gb_rgb + n_rgb]
@@ -930,6 +934,7 @@ class _FusedFine(torch.autograd.Function):
             gw_rgb[0] = gW0p[:, :rgb_w[0].shape[1]]
         grp.__exit__()
         _flush_tn(dev)
+        _seam(run, 'mlp', dX0=dX0, dZ=dZ, compact=bool(getattr(run, 'dx0_compact', False)), saved=S)
         hook, opt_hook = _early_hooks(run)
         # One GPU: the weight-gradient launch is forked off here and everything below runs beside it (_MARCH_FIRST: the two
         # vector-bound kernels of the sdf path first, see there).
@@ -985,6 +990,7 @@ class _FusedFine(torch.autograd.Function):
             feat_bwd(True, False)
         else:
             feat_bwd(True, True)
+        _seam(run, 'features', g_sdf_s=g_sdf_s, g_grad_s=g_grad_s, grad_k0=grad_k0)
         _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
         if hook is not None:
             # the exchanges, in the order EVERY path of every rank issues them (k0, mlp, join: _backward_empty too): k0's is
@@ -997,6 +1003,7 @@ class _FusedFine(torch.autograd.Function):
         # 6. march backward
         if not march_first:
             march_bwd()
+        _seam(run, 'march', tot_sdf=tot_sdf, tot_grad=tot_grad)
         # 7. every sdf.grad contribution of the survivors (24 taps + centre + six +/-1 taps), combined on chip
         if compact:
             call("fgs_set_dx0_compact", 1)
@@ -1018,6 +1025,16 @@ class _FusedFine(torch.autograd.Function):
         for i in range(n_ref):
             grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
         return tuple(grads)
+
+
+def _seam(run, name, **tensors) -> None:
+    """Stage seam of the fine-stage backward pass.  A test may install `model._fused_cache['bwd_probe'] = f(name, tensors)`: it is
+    called with the tensors that cross the seam, right after the launches that produced them were issued, and may read them
+    (clone) or overwrite them in place (copy_) -- e.g. with the CPU oracle's gradient at the same seam, so that the NEXT stage
+    runs on exactly the oracle's upstream gradient (tests/test_stagewise_bwd_gpu.py).  No probe: nothing happens."""
+    probe = run.cache.get('bwd_probe')
+    if probe is not None:
+        probe(name, tensors)
 
 
 def _fine_grad_layout(run, rgb_w, ref_w, rw, fw, ldx0, ldz):

@@ -445,12 +445,23 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return x / torch.sqrt(torch.maximum(torch.sum(x ** 2, dim=-1, keepdims=True), eps))
 
 
-def mlp_apply(layers: List[Tuple[torch.Tensor, torch.Tensor]], x: torch.Tensor) -> torch.Tensor:
-    """model/nerf.py:125-142: Linear(+ReLU) stack, no activation after the last Linear."""
+def mlp_apply(layers: List[Tuple[torch.Tensor, torch.Tensor]], x: torch.Tensor, relu_masks=None, stats=None) -> torch.Tensor:
+    """model/nerf.py:125-142: Linear(+ReLU) stack, no activation after the last Linear.
+    `relu_masks` (one bool tensor per hidden layer, from ANOTHER float32 evaluation of the same network on the same inputs):
+    the sign decisions of the ReLUs are replayed instead of re-taken -- like forward_fine's `decisions` -- so that the two
+    evaluations differentiate the same piecewise-linear function; `stats['relu_flips']` counts the units whose own sign
+    differs from the replayed one (pre-activations within rounding of zero)."""
     for i, (W, b) in enumerate(layers):
         x = F.linear(x, W, b)
         if i + 1 < len(layers):
-            x = F.relu(x)
+            if relu_masks is not None:
+                m = relu_masks[i].to(x.device)
+                if stats is not None:
+                    stats['relu_flips'] = stats.get('relu_flips', 0) + int(((x > 0) != m).sum())
+                    stats['relu_units'] = stats.get('relu_units', 0) + m.numel()
+                x = x * m.to(x.dtype)
+            else:
+                x = F.relu(x)
     return x
 
 
@@ -509,20 +520,90 @@ def sample_ray_ori(P: Dict, grid_shape, rays_o, rays_d, near, far, stepsize):
     return rays_pts, mask_outbbox, step
 
 
+class _Seams:
+    """Stage seams of a `forward_fine(..., staged=True)` run: between the four segments of the path -- A march (sampling, SDF
+    lookups, NeuS alpha, Alphas2Weights, the two threshold compactions), B per-survivor features (k0 lookup, hierarchical taps,
+    encodings, normal, reflection), C the two MLPs, D sigmoid + compositing -- every tensor that crosses over is cut
+    (`detach().requires_grad_()`), so that the backward pass can be run ONE SEGMENT AT A TIME with a chosen upstream gradient.
+    `backward(loss)` does that with the oracle's own gradients and returns, per seam, exactly what the corresponding HIP
+    backward stage receives and must produce (tests/test_stagewise_bwd_gpu.py: k_composite_bwd, k_head_bwd + the data-gradient
+    chain + k_gemm + k_mlp_wgrad, k_feat_*_bwd, k_march_fine_bwd + the sdf scatter)."""
+
+    def __init__(self):
+        self.cuts = {}        # name -> (output of the producing segment, the leaf the consuming segment reads)
+
+    def cut(self, name, t):
+        leaf = t.detach().requires_grad_(True)
+        self.cuts[name] = (t, leaf)
+        return leaf
+
+    def backward(self, loss, P):
+        """Segment-wise backward pass.  Returns {seam name: gradient} for every cut, plus 'sdf_march' / 'sdf_taps' (the two
+        parts of sdf.grad: segment A and the hierarchical taps of segment B), 'k0', 'rgbnet' / 'refnet' ([(dW, db), ...])."""
+        c = self.cuts
+        g = {}
+
+        def up(name):
+            return c[name][1].grad
+
+        def out(name):
+            return c[name][0]
+
+        # E: the loss reads leaves of D / B / A outputs
+        loss.backward()
+        for k in ('rgb_marched', 'sigmoid_rgb', 'alphainv_last_loss', 'raw_rgb', 'normal_loss'):
+            g[k] = up(k)
+        zero = torch.zeros_like
+
+        def bw(outs, grads):
+            pairs = [(o, gr) for o, gr in zip(outs, grads) if gr is not None and o.requires_grad]
+            if pairs:
+                torch.autograd.backward([o for o, _ in pairs], [gr for _, gr in pairs])
+
+        # D: sigmoid + compositing
+        bw([out('rgb_marched'), out('sigmoid_rgb'), out('raw_rgb')], [g['rgb_marched'], g['sigmoid_rgb'], g['raw_rgb']])
+        g['logit'], g['weights'] = up('logit'), up('weights')
+        # C: the MLPs
+        bw([out('logit')], [g['logit']])
+        g['X0'], g['reflect_emb'] = up('X0'), up('reflect_emb')
+        g['rgbnet'] = [(W.grad.clone(), b.grad.clone()) for W, b in P['rgbnet']]
+        g['refnet'] = [(W.grad.clone(), b.grad.clone()) for W, b in P['refnet']]
+        # B: features
+        bw([out('X0'), out('reflect_emb'), out('normal_loss')], [g['X0'], g['reflect_emb'], g['normal_loss']])
+        g['sdf_s'], g['gradient_s'] = up('sdf_s'), up('gradient_s')
+        g['k0'] = P['k0'].grad.clone()
+        g['sdf_taps'] = up('sdf_grid_B') if up('sdf_grid_B') is not None else zero(P['sdf'])
+        # A: march
+        if P['sdf'].grad is not None:
+            P['sdf'].grad = None
+        bw([out('weights'), out('alphainv_last_loss'), out('sdf_s'), out('gradient_s')],
+           [g['weights'], g['alphainv_last_loss'], g['sdf_s'], g['gradient_s']])
+        g['sdf_march'] = P['sdf'].grad.clone() if P['sdf'].grad is not None else zero(P['sdf'])
+        return g
+
+
 def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize, bg,
-                 render_depth=False, render_grad=False, decisions: Optional[Dict] = None) -> Dict:
+                 render_depth=False, render_grad=False, decisions: Optional[Dict] = None, staged: bool = False,
+                 relu_masks: Optional[Dict] = None) -> Dict:
     """model/nerf.py:776-941.  P holds: xyz_min, xyz_max, voxel_size (0-d fp32 tensor), sdf [1,1,X,Y,Z],
     k0 [1,C,X,Y,Z], rgbnet / refnet (lists of (W,b)), posfreq, viewfreq, reffreq, fast_color_thres,
     s_ratio, s_start, grad_feat_displace (sorted tuple), use_grad_norm, center_sdf, optional
-    mask_cache, optional smooth_kernel."""
+    mask_cache, optional smooth_kernel.
+    `staged`: the same statements in the same order, with every tensor that crosses a stage seam cut into a fresh leaf
+    (class _Seams; the result dict then carries 'seams'); values are identical, gradients are taken segment by segment.
+    `relu_masks` = {'rgbnet': [...], 'refnet': [...]}: ReLU sign decisions replayed from another evaluation (mlp_apply); the
+    result dict's 'relu_stats' then says how many units that concerned."""
     # `decisions` (the 'decisions' entry of an earlier float32 run on the same inputs): every discrete choice of the
     # path -- mask-cache skip, alpha > thres, the T < 1e-3 stopping point, weights > thres -- is replayed instead of
     # re-taken, so that a float64 run (P from params_f64) differentiates the SAME sample set: the error yardstick of
     # the full-size parity tests.  Without it the function is the reference path, decisions included.
     dec, rec = decisions, {}
+    seams = _Seams() if staged else None
+    cut = seams.cut if staged else (lambda name, t: t)
     N = len(rays_o)
     dt = P['sdf'].dtype
     xyz_min, xyz_max, voxel_size = P['xyz_min'], P['xyz_max'], P['voxel_size']
+    # ---------------------------------------------------------------------------------------------------- A: march
     ray_pts, ray_id, step_id, mask_outbbox, m_total = sample_ray(P, rays_o, rays_d, near, stepsize)
     ray_pts, viewdirs = ray_pts.to(dt), viewdirs.to(dt)
     n_inbbox = int(ray_pts.shape[0])
@@ -550,6 +631,10 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
         rec['weight_mask'] = mask
         weights, alpha, ray_pts, viewdirs_pts = weights[mask], alpha[mask], ray_pts[mask], viewdirs_pts[mask]
         ray_id, step_id, gradient, sdf = ray_id[mask], step_id[mask], gradient[mask], sdf[mask]
+    weights, alphainv_last = cut('weights', weights), cut('alphainv_last_loss', alphainv_last)
+    sdf, gradient = cut('sdf_s', sdf), cut('gradient_s', gradient)
+    sdf_grid_taps = cut('sdf_grid_B', sdf_grid)
+    # ---------------------------------------------------------------------------------------------------- B: features
     normal = l2_normalize(gradient / (gradient.norm(dim=-1, keepdim=True) + 1e-7))
     rays_xyz = (ray_pts - xyz_min) / (xyz_max - xyz_min)
     xyz_emb = posenc(rays_xyz, P['posfreq'])
@@ -559,16 +644,22 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
         hier.append(sdf[:, None])
     disp = P.get('grad_feat_displace', ())
     if len(disp) > 0:
-        all_feat, all_grad = sample_sdfs(ray_pts, sdf_grid, xyz_min, xyz_max, voxel_size, sorted(disp),
+        all_feat, all_grad = sample_sdfs(ray_pts, sdf_grid_taps, xyz_min, xyz_max, voxel_size, sorted(disp),
                                          use_grad_norm=P.get('use_grad_norm', True))
         hier += [all_feat, all_grad]
     viewdirs_emb = posenc(viewdirs, P['viewfreq'])[ray_id]
     rgb_feat = torch.cat([k0, xyz_emb, viewdirs_emb, *hier, gradient], dim=-1)
-    rgb_feat = mlp_apply(P['rgbnet'], rgb_feat)
     reflect_r = viewdirs_pts - 2. * torch.sum(viewdirs_pts * normal, dim=-1, keepdim=True) * normal
     reflect_emb = posenc(reflect_r, P['reffreq'])
+    rgb_feat, reflect_emb = cut('X0', rgb_feat), cut('reflect_emb', reflect_emb)
+    normal = cut('normal_loss', normal)
+    # ---------------------------------------------------------------------------------------------------- C: the MLPs
+    relu_stats = {}
+    rgb_feat = mlp_apply(P['rgbnet'], rgb_feat, relu_masks['rgbnet'] if relu_masks else None, relu_stats)
     ref_feat = torch.cat([rgb_feat, reflect_emb], dim=-1)
-    rgb = torch.sigmoid(mlp_apply(P['refnet'], ref_feat))
+    logit = cut('logit', mlp_apply(P['refnet'], ref_feat, relu_masks['refnet'] if relu_masks else None, relu_stats))
+    # ---------------------------------------------------------------------------------------------------- D: compositing
+    rgb = torch.sigmoid(logit)
     sig_rgb = torch.sigmoid(rgb)
     rgb_marched = segment_sum(weights.unsqueeze(-1) * rgb, ray_id, N)
     cum_weights = segment_sum(weights.unsqueeze(-1), ray_id, N)
@@ -576,6 +667,7 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
     rgb_marched = (rgb_marched + (1 - cum_weights) * bg).clamp(0, 1)
     sigmoid_rgb = (sigmoid_rgb + (1 - cum_weights) * bg).clamp(0, 1)
     normal_marched = segment_sum(weights.unsqueeze(-1) * normal, ray_id, N) if render_grad else None
+    rgb_marched, sigmoid_rgb, rgb = cut('rgb_marched', rgb_marched), cut('sigmoid_rgb', sigmoid_rgb), cut('raw_rgb', rgb)
     depth = disp_map = None
     if render_depth:
         with torch.no_grad():
@@ -587,7 +679,8 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
         'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': disp_map, 'mask': mask,
         'mask_outbbox': mask_outbbox, 'gradient': gradient, 's_val': s_val,
         # bookkeeping for the bench/tests (not in the reference dict)
-        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'sdf': sdf, 'decisions': rec,
+        'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'sdf': sdf, 'decisions': rec, 'seams': seams,
+        'relu_stats': relu_stats,
     }
 
 

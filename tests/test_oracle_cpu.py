@@ -206,3 +206,34 @@ def test_e2e_golden(oracle, golden):
         loss.backward()
         assert abs(float(loss) - float(g["loss"])) < 1e-6
         assert rel_l2(P["sdf"].grad, g["grad_sdf"]) < 1e-5 and rel_l2(P["k0"].grad, g["grad_k0"]) < 1e-5
+
+
+def test_staged_backward_adds_up_to_the_plain_backward(oracle):
+    """oracle.forward_fine(staged=True): the same values, and the segment-by-segment backward pass (A march, B features, C MLPs,
+    D compositing: the seams the HIP backward stages are checked at, tests/test_stagewise_bwd_gpu.py) gives the gradients of the
+    plain backward pass."""
+    import torch
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import render_losses
+    torch.manual_seed(0)
+    model = synth.build_model(16, synth.FINE_MODEL, fused=False)
+    ro, rd, vd = synth.random_rays(96, n_views=4, H=64, W=64, seed=5)
+    target = torch.rand(96, 3, generator=torch.Generator().manual_seed(2))
+    outs = []
+    for staged in (False, True):
+        P = synth.oracle_params(model)
+        leaves = [P['sdf'], P['k0']] + [t for net in (P['rgbnet'], P['refnet']) for wb in net for t in wb]
+        for t in leaves:
+            t.requires_grad_(True)
+        res = oracle.forward_fine(P, ro, rd, vd, global_step=1000, near=2.0, stepsize=0.5, bg=1, staged=staged)
+        loss = render_losses(res, target, synth.FINE_LOSS)
+        if staged:
+            g = res['seams'].backward(loss, P)
+            grads = [g['sdf_march'] + g['sdf_taps'], g['k0']] + [t for net in (g['rgbnet'], g['refnet']) for wb in net for t in wb]
+        else:
+            loss.backward()
+            grads = [t.grad.clone() for t in leaves]
+        outs.append((res['rgb_marched'].detach().clone(), float(loss), grads))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert float((a - b).norm() / a.norm().clamp_min(1e-30)) < 2e-6
