@@ -685,9 +685,10 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
 
 
 def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize, bg, stage='coarse',
-                   render_depth=True, render_grad=False, decisions: Optional[Dict] = None) -> Dict:
-    """model/nerf.py:943-1075.  Extra keys in P: inc_mask (dict(mask, scale, shift) or None).  `decisions`: see
-    forward_fine."""
+                   render_depth=True, render_grad=False, decisions: Optional[Dict] = None,
+                   relu_masks: Optional[Dict] = None) -> Dict:
+    """model/nerf.py:943-1075.  Extra keys in P: inc_mask (dict(mask, scale, shift) or None).  `decisions`, `relu_masks`
+    ({'refnet': [...]}): see forward_fine."""
     dec, rec = decisions, {}
     N = len(rays_o)
     dt = P['sdf'].dtype
@@ -737,7 +738,8 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
     reflect_emb = posenc(reflect_r, P['reffreq'])
     viewdirs_emb = posenc(viewdirs, P['viewfreq'])[ray_id]
     ref_feat = torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb], dim=-1)
-    rgb = torch.sigmoid(mlp_apply(P['refnet'], ref_feat))
+    relu_stats = {}
+    rgb = torch.sigmoid(mlp_apply(P['refnet'], ref_feat, relu_masks['refnet'] if relu_masks else None, relu_stats))
     sig_rgb = torch.sigmoid(rgb)
     rgb_marched = segment_sum(weights.unsqueeze(-1) * rgb, ray_id, N)
     sigmoid_rgb = segment_sum(weights.unsqueeze(-1) * sig_rgb, ray_id, N)
@@ -756,6 +758,7 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
         'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth, 'disp': disp_map, 'mask': mask,
         'mask_outbbox': mask_outbbox, 'gradient': gradient, 's_val': s_val,
         'step_id': step_id, 'n_total': m_total, 'n_inbbox': n_inbbox, 'decisions': rec, 'pass1': pass1,
+        'relu_stats': relu_stats,
     }
 
 

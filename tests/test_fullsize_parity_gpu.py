@@ -7,11 +7,17 @@ For every compared tensor
 
     e_hip = rel-L2(HIP, oracle-f64)        e_ref = rel-L2(oracle-f32, oracle-f64)
 
-and the bar is  e_hip <= 2 * e_ref + FLOOR, plus a direct bar HIP-vs-oracle-f32 (outputs 1e-5; gradients 0.5 x e_ref, see check()).  e_ref is what float32 itself costs on this computation (accumulation
-order, expf/sigmoid ulps, ReLU pre-activations that change sign between two correct float32 evaluations -- each such
-flip moves a gradient by a whole term, which is why gradients sit at 1e-5..1e-4 and not at 1e-7 at these sizes); a kernel
-bug shows as e_hip >> e_ref.  FLOOR = 2e-6 covers tensors whose e_ref happens to be ~0 (a float32 evaluation that is
-exact by luck).  Both numbers are printed for every tensor.
+and the bar is  e_hip <= 2 * e_ref + FLOOR, plus a FLAT direct bar HIP-vs-oracle-f32: outputs 1e-5, gradients DIRECT_GRAD = 2e-5.
+e_ref is what float32 itself costs on this computation (accumulation order, expf/sigmoid ulps); a kernel bug shows as
+e_hip >> e_ref.  FLOOR = 2e-6 covers tensors whose e_ref happens to be ~0.  Both numbers are printed for every tensor.
+
+Round 2 had to accept 0.5 x e_ref (~3.5e-3 on sdf.grad) as the direct gradient bar: HIP and the float32 oracle sat 1.4e-3 / 2.4e-3
+apart on sdf.grad / k0.grad.  tests/test_stagewise_bwd_gpu.py located that difference: a few dozen of the 24 M hidden ReLU units have
+a pre-activation within float32 rounding of zero and come out on different sides in the two forward passes; each flips a whole
+term of its sample's gradient.  Both oracle runs here therefore replay the HIP forward's ReLU sign decisions (oracle.mlp_apply
+relu_masks) the same way the float64 run replays the float32 run's threshold decisions -- all three evaluations then
+differentiate the same piecewise-linear network -- and the direct bar is flat again.  The number of replayed units that
+differ from the oracle's own decision is printed and bounded (< 1e-5 of all units).
 
 Cases: configs[1] (160^3 fine, 1024 rays of bench batch 0), the coarse stage at 160^3 (configs[2]'s path at the bench
 size), a 320^3 fine shard (configs[4]'s per-GPU shape).  All through the fused HIP path and the C ABI.
@@ -25,10 +31,7 @@ pytestmark = pytest.mark.gpu
 
 FLOOR = 2e-6
 DIRECT_OUT = 1e-5      # rendered pixels, weights, normals ... HIP vs the float32 reference arithmetic (north_star: <= 1e-5)
-# gradients, HIP vs the float32 reference arithmetic: at most HALF of what float32 itself is away from float64 on that tensor
-# (measured 0.2-0.26 x e_ref at 160^3: two float32 evaluations of the cancelling NeuS-alpha derivative differ from each other
-# by a fraction of their common distance to float64; a kernel bug would have to hide inside that fraction, and the 16^3-48^3
-# tests bound those at 2e-4 .. 1e-3 flat)
+DIRECT_GRAD = 2e-5     # every parameter gradient, HIP vs the float32 reference arithmetic on the same ReLU decisions (flat)
 
 
 def _leaves(P):
@@ -67,9 +70,15 @@ def _case(dev, oracle, G, stage, n_rays, ray_seed, label):
 
     # HIP
     res = model(ro.to(dev), rd.to(dev), vd.to(dev), global_step=1000, **synth.RENDER_KWARGS)
+    saved = res['rgb_marched'].grad_fn.run.saved          # the forward chain's post-ReLU activations -> its sign decisions
+    if stage == 'fine':
+        masks = dict(rgbnet=[(a > 0).cpu() for a in saved['acts_rgb'][1:]], refnet=[(a > 0).cpu() for a in saved['acts_ref'][1:]])
+    else:
+        masks = dict(refnet=[(a > 0).cpu() for a in saved['acts'][1:]])
     loss = render_losses(res, target.to(dev), lossw, model)
     loss.backward()
     hip = {k: v.detach().cpu() for k, v in _hip_grads(model).items()}
+    okw['relu_masks'] = masks
     # oracle, float32 (the reference arithmetic)
     P = synth.oracle_params(model)
     L32 = _leaves(P)
@@ -92,7 +101,7 @@ def _case(dev, oracle, G, stage, n_rays, ray_seed, label):
         # sigmoids, so d alpha / d sdf cancels badly in float32 and BOTH float32 evaluations sit 1e-3..1e-2 from float64):
         # there a wrong kernel could hide under e_ref, so HIP must also sit within DIRECT of the float32 reference
         # arithmetic itself (same formulas, only summation order / ReLU-flip noise apart)
-        ok = e_hip <= 2.0 * e_ref + FLOOR and e_dir <= (0.5 * e_ref + FLOOR if name.startswith('grad') else DIRECT_OUT)
+        ok = e_hip <= 2.0 * e_ref + FLOOR and e_dir <= (DIRECT_GRAD if name.startswith('grad') else DIRECT_OUT)
         rows.append((name, e_hip, e_ref, e_dir, ok))
         if not ok:
             bad.append(name)
@@ -103,8 +112,11 @@ def _case(dev, oracle, G, stage, n_rays, ray_seed, label):
     check('loss', loss.detach(), l32.detach(), l64.detach())
     for k in hip:
         check('grad ' + k, hip[k], L32[k].grad, L64[k].grad)
+    rs = r32['relu_stats']
     print(f"\n[{label}] rays {n_rays}, in-bbox samples {r32['n_inbbox']}, survivors {r32['weights'].shape[0]}, "
-          f"kept-sample differences {n_flips}")
+          f"kept-sample differences {n_flips}, ReLU decisions replayed against the oracle's own sign: {rs['relu_flips']} of "
+          f"{rs['relu_units']}")
+    assert rs['relu_flips'] < 1e-5 * rs['relu_units']
     print("    %-24s %-12s %-18s %-12s" % ("tensor", "e_hip", "e_ref(f32 vs f64)", "HIP vs f32"))
     for name, e_hip, e_ref, e_dir, ok in rows:
         print("    %-24s %-12.3e %-18.3e %-12.3e %s" % (name, e_hip, e_ref, e_dir, "" if ok else "  <-- out of tolerance"))
