@@ -48,6 +48,7 @@ _SIGNATURES = {
     "fgs_transpose_multi": [I32, P, P, P, P, P, P, P],
     "fgs_pad_cols_multi": [I32, P, P, P, P, P, P, P],
     "fgs_copy_cols_multi": [I32, P, P, P, P, P, P, P, P],
+    "fgs_debug_pad_cols_old_indexing": [P, I32, I32, I64, P, I64, P],
     "fgs_set_row_count_ptr": [P],
     "fgs_set_inv_s_ptr": [P],
     "fgs_set_dx0_compact": [I32],

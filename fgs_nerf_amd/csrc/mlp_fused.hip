@@ -418,6 +418,30 @@ FGS_API int fgs_copy_cols_multi(int n, const float *const *src, const int *rows,
   return 0;
 }
 
+// Diagnostics (tests/test_mlp_rc_gpu.py, DESIGN.md section 4, "The round-2 abort"): ONE matrix copied with the index expression
+// this kernel had up to commit a5aee36 -- dst[e] for e < rows * ld_dst, which takes the destination for a whole [rows, ld_dst]
+// matrix -- so that the canary test can be shown to catch it when the destination is a column slice of a wider tensor.  The
+// caller guarantees rows * ld_dst floats behind `dst` are its own memory.
+namespace {
+__global__ __launch_bounds__(FGS_BLOCK) void k_pad_cols_old_indexing(const float *__restrict__ src, float *__restrict__ dst, int rows,
+                                                                     int cols, int64_t ld_src, int64_t ld_dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)rows * ld_dst) return;
+  const int64_t r = e / ld_dst, c = e - r * ld_dst;
+  dst[e] = c < cols ? src[r * ld_src + c] : 0.f;
+}
+}  // namespace
+
+FGS_API int fgs_debug_pad_cols_old_indexing(const float *src, int rows, int cols, int64_t ld_src, float *dst, int64_t ld_dst,
+                                            fgs_stream_t stream) {
+  FGS_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, FGS_E_INVALID,
+              "fgs_debug_pad_cols_old_indexing: bad argument");
+  hipLaunchKernelGGL(k_pad_cols_old_indexing, dim3(fgs_blocks((int64_t)rows * ld_dst)), dim3(FGS_BLOCK), 0, fgs_s(stream), src, dst,
+                     rows, cols, ld_src, ld_dst);
+  FGS_LAUNCH_OK("fgs_debug_pad_cols_old_indexing");
+  return 0;
+}
+
 FGS_API int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
                                float *const *dst, const int64_t *ld_dst, fgs_stream_t stream) {
   return fgs_copy_cols_multi(n, src, rows, cols, ld_src, dst, ld_dst, nullptr, stream);

@@ -376,6 +376,11 @@ int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const in
  * first rgbnet layer's weights without the columns of the xyz / view-direction encodings, see fgs_set_dx0_compact). */
 int fgs_copy_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
                         float *const *dst, const int64_t *ld_dst, const int *width, fgs_stream_t stream);
+/* Diagnostics: one matrix copied with the index expression fgs_pad_cols_multi's kernel had before fgs_copy_cols_multi existed
+ * (dst[e], e < rows * ld_dst: the destination taken for a whole [rows, ld_dst] matrix).  Only for the canary test that shows this
+ * expression overruns a column-slice destination; the caller owns rows * ld_dst floats behind dst. */
+int fgs_debug_pad_cols_old_indexing(const float *src, int rows, int cols, int64_t ld_src, float *dst, int64_t ld_dst,
+                                    fgs_stream_t stream);
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,

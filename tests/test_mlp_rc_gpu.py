@@ -221,3 +221,29 @@ def test_pad_cols_multi_matches_torch_pad(dev):
     assert bool((canvas == 7.0).all())
     with pytest.raises(RuntimeError):                          # a destination whose shape is not [rows, width] is refused
         fo.pad_cols_multi([W[:, :12]], [12], outs=[dst[:, :13]])
+
+
+def test_canary_catches_the_old_pad_cols_index_expression(dev):
+    """Up to commit a5aee36 the kernel wrote dst[e] for e < rows * ld_dst -- right for a destination that IS a [rows, ld_dst]
+    matrix, the only kind it was given.  The compact-dX0 change (b4fb5c1) began to pass column slices of a wider tensor
+    (W0c[:, :12], W0c[:, 12:52]); on its first development snapshot the old expression was still in place, and the full GPU
+    suite of that snapshot died with SIGABRT in the first fused forward pass (gpurun_out/abort.log).  This
+    test runs the old expression (kept as fgs_debug_pad_cols_old_indexing) on the canary layout of
+    test_pad_cols_multi_matches_torch_pad and shows that the canary check fails on it: the run of rows * ld_dst floats covers
+    the canary columns of every row and ends 4 floats + one row behind the slice."""
+    from fgs_nerf_amd._lib import call, ptr, stream
+    torch.manual_seed(3)
+    W = torch.randn(256, 106, device=dev)
+    canvas = torch.full((258, 60), 7.0, device=dev)
+    dst = canvas[1:257, 4:56]                                  # [256, 52] inside the canvas, pitch 60
+    src = W[:, 66:]                                            # 40 columns -> dst[:, 12:]
+    call("fgs_debug_pad_cols_old_indexing", ptr(src), 256, 40, src.stride(0), ptr(dst[:, 12:]), dst.stride(0), stream())
+    inside = torch.zeros_like(canvas, dtype=torch.bool)
+    inside[1:257, 16:56] = True
+    overwritten = int(((canvas != 7.0) & ~inside).sum())
+    assert overwritten > 256 * 10                               # canary columns of every row: what the canary test asserts against
+    # and the current entry point leaves every canary cell alone on the same destination
+    canvas.fill_(7.0)
+    from fgs_nerf_amd import fused_ops as fo
+    fo.pad_cols_multi([src], [40], outs=[dst[:, 12:]])
+    assert int(((canvas != 7.0) & ~inside).sum()) == 0 and torch.equal(dst[:, 12:], src)
