@@ -76,6 +76,27 @@ def train_step(model, opt, averager, batch, n_rays_global):
     return loss
 
 
+def touched_voxels(model, batches) -> float:
+    """k0 voxels holding a trilinear corner of a survivor point, mean over the resident batches (what MaskedAdam's voxel update
+    visits): a render without gradients per batch, fgs_brick_masks_pts into a scratch byte-per-voxel buffer, one sum."""
+    import ctypes
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd._lib import call, ptr, stream
+    _, _, X, Y, Z = model.k0.grid.shape
+    flags = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4) * 64, dtype=torch.uint8, device=model.k0.grid.device)
+    lo = (ctypes.c_float * 3)(*[float(v) for v in model.xyz_min.flatten().tolist()])
+    hi = (ctypes.c_float * 3)(*[float(v) for v in model.xyz_max.flatten().tolist()])
+    total = 0
+    with torch.no_grad():
+        for b in batches:
+            res = model(b[0], b[1], b[2], global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
+            pts = res['survivor_pts'][:res['weights'].shape[0]].contiguous()
+            flags.zero_()
+            call("fgs_brick_masks_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(flags), stream())
+            total += int(flags.sum())
+    return total / max(len(batches), 1)
+
+
 def cpu_baseline(n_rays=4096, iters=10, warm=3):
     """The oracle (CPU port of the reference path: packed sampling -> F.grid_sample -> NeuS alpha -> early-stop scan ->
     nn.Linear MLPs -> index_add_ -> backward) on a bounded sample of the same workload, host cores of this box."""
@@ -143,7 +164,7 @@ def pmc_traffic_live(args, timeout_s=180):
             d = os.path.join(root, counter)
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, here,
                    "--pmc-child", "--no-cpu-baseline", "--mode", "eager", "--steps", "4", "--warmup", "2",
-                   "--stage", args.stage, "--grid", str(args.grid)]
+                   "--stage", args.stage, "--grid", str(args.grid), "--rays", str(args.rays)]
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
@@ -233,10 +254,14 @@ def main():
                          "the host; eager: Python enqueues every launch and reads the survivor count back once per step")
     ap.add_argument("--grid", type=int, default=GRID,
                     help="grid side (default 160 = the headline config; 320 = the per-GPU shape of configs[4], 128 = configs[0])")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU,
+                    help="rays per GPU per step (default 4096 = the headline config; 8192 = the reference's own fine-stage batch, "
+                         "config/shiny_blender.py:182 -- a secondary line, never the headline)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     globals()["GRID"] = args.grid
+    globals()["RAYS_PER_GPU"] = args.rays
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child processes, BEFORE anything
     # in this process touches the GPU (the parent never initialises HIP and never replaces itself with another program).
@@ -448,16 +473,16 @@ def main():
         elapsed, samples = float(tmax.item()), float(ssum.item())
     if rank == 0:
         line = {
-            "metric": f"M ray-samples/sec (fwd+bwd), {GRID}^3 grid, 4096-ray batch",
+            "metric": f"M ray-samples/sec (fwd+bwd), {GRID}^3 grid, {RAYS_PER_GPU}-ray batch",
             "value": round(samples / elapsed / 1e6, 3), "unit": "M ray-samples/s",
             "n_gpus": (dist.get_world_size() if dist.is_initialized() else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"configs[1]: {GRID}^3 sdf(1ch)+k0(12ch) fine-stage training step "
-                                    "(forward_fine + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step")
+                                    f"(forward_fine + losses + backward + sdf TV + MaskedAdam), {RAYS_PER_GPU} rays/GPU/step")
                        if args.stage == "fine" else
                        ("configs[2] path at the bench size: 160^3 coarse-stage training step (5^3 smoothing + gradient "
-                        "volume + forward_coarse + losses + backward + sdf TV + MaskedAdam), 4096 rays/GPU/step"),
+                        f"volume + forward_coarse + losses + backward + sdf TV + MaskedAdam), {RAYS_PER_GPU} rays/GPU/step"),
                        "grid": GRID, "rays_per_gpu": RAYS_PER_GPU, "inbbox_samples_per_step_per_gpu": int(sum(n_inbbox) / len(n_inbbox)),
                        "emitted_samples_per_step_per_gpu": int(sum(n_total) / len(n_total)),
                        "mlp_survivors_per_step_per_gpu": int(STEP_STATS["survivors"] / max(args.steps, 1)),
@@ -484,18 +509,33 @@ def main():
         if line["roofline"] is not None:
             line["roofline"]["timing"] = roofline_note
         if line["roofline"] is not None and args.stage == "fine":
-            # the path is NOT HBM-bound -- both HBM fractions, for the record (the claimed bound is "mfma" above).
-            # sampled path: 688 + 3456 rho algorithmic bytes per in-bbox sample; whole step adds the dense per-step streams
-            # (sdf TV 3*4*G^3, dense Adam on sdf 7*4*G^3, masked Adam on k0 <= 7*4*12*G^3, zero fill of both gradients)
+            # The path is MFMA-bound, not HBM-bound: both HBM fractions for the record, from the
+            # bytes a step MUST move.  sampled path: 688 + 3456 rho algorithmic bytes per in-bbox sample (SURVEY 8d's table);
+            # dense per-step streams that remain: sdf TV 3*4*G^3, dense Adam on sdf 7*4*G^3, one zero fill of sdf.grad 4*G^3;
+            # k0: 7*4*12 B per TOUCHED voxel (the voxel-granular masked update; counted below from the survivors' trilinear
+            # corners) -- no dense k0 Adam pass and no k0.grad fill exist any more.  The survey's dense figure (k0 Adam over
+            # all of 12*G^3 and both gradient fills) is kept under its own key.
             n_in = sum(n_inbbox) / len(n_inbbox)
             rho = STEP_STATS["survivors"] / max(args.steps, 1) / n_in
             step_s = elapsed / args.steps
             sampled = (688.0 + 3456.0 * rho) * n_in
-            dense = (3 * 4 + 7 * 4 + 7 * 4 * 12 + 4 * 13) * float(GRID) ** 3
+            g3 = float(GRID) ** 3
+            touched = touched_voxels(model, batches)
+            must = sampled + (3 * 4 + 7 * 4 + 4) * g3 + 7 * 4 * 12 * touched
+            dense_survey = sampled + (3 * 4 + 7 * 4 + 7 * 4 * 12 + 4 * 13) * g3
+            mlp_flop = 3 * 2 * 434176.0 * STEP_STATS["survivors"] / max(args.steps, 1)      # fwd + data + weight gradients
             line["roofline"]["hbm_fraction_for_reference"] = {
                 "rho_survivors_per_inbbox_sample": round(rho, 4),
-                "sampled_path": round(sampled / step_s / 8e12, 4), "whole_step": round((sampled + dense) / step_s / 8e12, 4),
-                "note": "algorithmic bytes / step time / 8 TB/s; the step is bound by fp32 matrix throughput and atomics"}
+                "k0_voxels_touched_per_step": int(touched),
+                "sampled_path": round(sampled / step_s / 8e12, 4),
+                "whole_step": round(must / step_s / 8e12, 4),
+                "whole_step_bytes": int(must),
+                "whole_step_if_k0_were_updated_densely_(survey_8d)": round(dense_survey / step_s / 8e12, 4),
+                "note": "bytes the step must move / step time / 8 TB/s.  The step is bound by fp32 matrix throughput: "
+                        "the north_star's >= 40 % HBM-roofline target does not apply to this design (0.9 GB per step)"}
+            line["roofline"]["mfma_floor_ms_per_step"] = round(mlp_flop / 157.3e12 * 1e3, 4)
+            line["roofline"]["mfma_floor_note"] = ("MLP FLOP of a step (3 x 2 x 434 176 per survivor) at the fp32 MFMA peak: no "
+                                                   "schedule of exact-fp32 products can run the step faster")
         # (the CPU baseline is timed at N = 1 only: the other ranks of a multi-GPU run would sit in the final barrier meanwhile)
         line["cpu_baseline"] = None if (args.no_cpu_baseline or args.stage != "fine" or world > 1) else cpu_baseline()
         stale = [g.get('name', str(i)) for i, (g, a, b) in enumerate(zip(opt.param_groups, digest_before, digest_after))

@@ -178,17 +178,25 @@ class TrainStepper:
             from . import fused
             fused.enable_early_update(self.model, self.optimizer, av)   # ... or applied right behind it (no TV on k0)
 
+    def _maybe_rescale(self, global_step: int) -> bool:
+        """Progressive growing (model/nerf_training.py:243-253), at the head of iteration `global_step`: new grids (and, on a
+        `reset_iter` entry, re-initialised voxels and MLPs), a new optimizer, the exchange re-bound to the new parameters."""
+        model, ct = self.model, self.cfg_train
+        if global_step not in ct.get('pg_scale', []):
+            return False
+        model.scale_volume_grid(model.num_voxels * ct.scale_ratio)
+        if global_step in ct.get('reset_iter', []):
+            model.reset_voxel_and_mlp()
+            if self.cfg_model.get('maskout_near_cam_vox', False) and self.poses_train is not None:
+                model.maskout_near_cam_vox(self.poses_train[:, :3, 3], self.near)
+        self.optimizer = create_optimizer_or_freeze_model(model, ct, global_step=0)
+        self._bind_averager()                            # new grids, new optimizer
+        return True
+
     def step(self, global_step: int) -> torch.Tensor:
-        model, ct, opt = self.model, self.cfg_train, self.optimizer
-        # progressive growing (:243-253)
-        if global_step in ct.get('pg_scale', []):
-            model.scale_volume_grid(model.num_voxels * ct.scale_ratio)
-            if global_step in ct.get('reset_iter', []):
-                model.reset_voxel_and_mlp()
-                if self.cfg_model.get('maskout_near_cam_vox', False) and self.poses_train is not None:
-                    model.maskout_near_cam_vox(self.poses_train[:, :3, 3], self.near)
-            opt = self.optimizer = create_optimizer_or_freeze_model(model, ct, global_step=0)
-            self._bind_averager()                            # new grids, new optimizer
+        model, ct = self.model, self.cfg_train
+        self._maybe_rescale(global_step)
+        opt = self.optimizer
         target, rays_o, rays_d, viewdirs = self._select_rays()
         # voxel increment (:288-295)
         if ct.get('voxel_inc', False):
@@ -285,6 +293,25 @@ class TrainStepper:
         become rows of the device-resident table.  Returns (losses [n_steps] device tensor, overflowed: bool); on overflow
         (more survivors than `capacity` in some iteration: that iteration's update was skipped) the caller re-runs with a
         larger capacity or falls back to `step()`.  Per-iteration statistics are not collected in a captured window."""
+        # A progressive-growing iteration (pg_scale) changes every shape behind the captured graphs: the window is cut there, the
+        # grids are rescaled and the optimizer re-created exactly as step() does at the head of that iteration, and the rest of
+        # the window is captured anew (one warm-up pass + one capture per cut: ~1 s, against thousands of iterations between
+        # two cuts in the shipped configs: model/nerf_training.py:244-253, config/shiny_blender.py:203-204).
+        ct = self.cfg_train
+        end = first_step + n_steps
+        cuts = [first_step] + [g for g in range(first_step + 1, end) if g in ct.get('pg_scale', [])] + [end]
+        if len(cuts) > 2 or first_step in ct.get('pg_scale', []):
+            losses, overflow = [], False
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                rescaled = self._maybe_rescale(a)
+                l, o = self._run_captured_window(a, b - a, None if (rescaled or a != first_step) else capacity)
+                losses.append(l)
+                overflow = overflow or o
+            return torch.cat(losses), overflow
+        return self._run_captured_window(first_step, n_steps, capacity)
+
+    def _run_captured_window(self, first_step: int, n_steps: int, capacity: Optional[int] = None):
+        """One capture, n_steps replays (see run_captured); no shape-changing iteration inside."""
         from . import fused
         from .graph_step import CapturedFineStep
         model, ct, opt = self.model, self.cfg_train, self.optimizer
@@ -293,9 +320,8 @@ class TrainStepper:
             raise RuntimeError("run_captured covers the fused fine stage on one GPU")
         if ct.get('voxel_inc', False) or ct.get('ori_tv', False):
             raise RuntimeError("run_captured: voxel_inc / ori_tv iterations change shape from step to step; use step()")
-        for key, cfg in (('pg_scale', ct), ('reset_iter', ct)):
-            if any(g in cfg.get(key, []) for g in steps):
-                raise RuntimeError(f"run_captured: {key} inside the window")
+        if any(g in ct.get('pg_scale', []) for g in list(steps)[1:]):
+            raise RuntimeError("_run_captured_window: pg_scale inside the window (run_captured cuts windows there)")
         for key, cfg in (('decay_step_module', ct), ('tv_updates', ct), ('s_updates', self.cfg_model),
                          ('smooth_updates', self.cfg_model)):
             if any((g - 1) in cfg.get(key, {}) for g in steps):

@@ -20,7 +20,7 @@ differentiate the same piecewise-linear network -- and the direct bar is flat ag
 differ from the oracle's own decision is printed and bounded (< 1e-5 of all units).
 
 Cases: configs[1] (160^3 fine, 1024 rays of bench batch 0), the coarse stage at 160^3 (configs[2]'s path at the bench
-size), a 320^3 fine shard (configs[4]'s per-GPU shape).  All through the fused HIP path and the C ABI.
+size), 256^3 fine (the reference's own grid after its rescale), a 320^3 fine shard (configs[4]'s per-GPU shape).  All through the fused HIP path and the C ABI.
 """
 import pytest
 import torch
@@ -134,6 +134,11 @@ def test_fine_160_fwd_bwd_vs_oracle(dev, oracle):
 def test_coarse_160_fwd_bwd_vs_oracle(dev, oracle):
     from fgs_nerf_amd import synth
     _case(dev, oracle, 160, 'coarse', 1024, synth.SEED, "160^3 coarse stage, 1024 rays of bench batch 0")
+
+
+def test_fine_256_fwd_bwd_vs_oracle(dev, oracle):
+    """The reference's own late fine-stage grid: 256^3 after the rescale at iteration 15 000 (config/shiny_blender.py:203-204,222)."""
+    _case(dev, oracle, 256, 'fine', 1024, 9, "reference fine stage after its rescale: 256^3, 1024 rays")
 
 
 def test_fine_320_shard_fwd_bwd_vs_oracle(dev, oracle):

@@ -135,13 +135,47 @@ def test_stepper_captured_window_matches_step_by_step(dev):
     assert not overflow and bool(torch.isfinite(losses).all())
     # windows the captured form does not cover are refused, not silently mis-run
     model = synth.build_model(32, synth.FINE_MODEL, device=dev)
-    st = nt.TrainStepper(model, dict(cfg, pg_scale=[3], scale_ratio=2.0), {}, synth.RENDER_KWARGS, target, *rays, stage='fine',
-                         seed=1)
-    with pytest.raises(RuntimeError):
-        st.run_captured(1, 6)
     st = nt.TrainStepper(model, dict(cfg, ori_tv=True), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
     with pytest.raises(RuntimeError):
         st.run_captured(1, 6)
+
+
+def test_captured_window_across_a_pg_scale_boundary_matches_step_by_step(dev):
+    """A progressive-growing iteration inside the window (model/nerf_training.py:244-253: new grids, new optimizer): run_captured
+    cuts the window there, rescales exactly as step() does at the head of that iteration and captures the rest anew -- same
+    losses and parameters as step() iteration by iteration, the grid grown, the optimizer restarted."""
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    cfg = dict(N_iters=20000, N_rand=512, lrate_k0=0.1, lrate_sdf=0.005, lrate_rgbnet=1e-3, lrate_refnet=1e-3, lrate_decay=20,
+               ray_sampler='flatten', weight_main=1.0, weight_entropy_last=0.001, weight_rgbper=0.0, weight_tv_density=0.01,
+               weight_tv_k0=0.0, sigmoid_rgb_loss=0.02, weight_orientation=1e-4, tv_every=1, tv_from=0, tv_end=30000,
+               voxel_inc=False, pg_scale=[903], scale_ratio=2.0, reset_iter=[], tv_terms=dict(sdf_tv=0.1, smooth_grad_tv=0.0),
+               tv_dense_before=20000, cosine_lr=True,
+               cosine_lr_cfg=dict(warm_up_iters=0, const_warm_up=True, warm_up_min_ratio=1.0), decay_step_module={},
+               skip_zero_grad_fields=['density', 'k0', 'k1'])
+    R, FIRST, N = 2048, 900, 6
+    rays = tuple(r.to(dev) for r in synth.random_rays(R, seed=31))
+    target = torch.rand(R, 3, generator=torch.Generator().manual_seed(7)).to(dev)
+    runs = {}
+    for mode in ("steps", "captured"):
+        model = synth.build_model(32, synth.FINE_MODEL, device=dev)
+        st = nt.TrainStepper(model, cfg, {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=13)
+        if mode == "steps":
+            losses = torch.stack([st.step(g).detach() for g in range(FIRST, FIRST + N)])
+        else:
+            losses, overflow = st.run_captured(FIRST, N)
+            assert not overflow
+        torch.cuda.synchronize()
+        runs[mode] = (losses.cpu(), [p.detach().clone() for p in model.parameters()], tuple(model.sdf.grid.shape),
+                      sorted({s['step'] for s in st.optimizer.state.values()}))
+    assert runs["steps"][2] == runs["captured"][2] and runs["captured"][2][2] > 32            # the grid grew, identically
+    assert runs["steps"][3] == runs["captured"][3] == [N - 3]                                # optimizer restarted at the cut
+    la, lb = runs["steps"][0], runs["captured"][0]
+    assert la.shape == lb.shape == (N,)
+    assert float(((la - lb) / la).abs().max()) < 1e-3, (la, lb)
+    for pa, pb in zip(runs["steps"][1], runs["captured"][1]):
+        assert pa.shape == pb.shape
+        assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 5e-3
 
 
 def test_stepper_captured_window_with_the_shipped_tv_schedule(dev):
