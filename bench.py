@@ -532,7 +532,7 @@ def main():
                 "whole_step_bytes": int(must),
                 "whole_step_if_k0_were_updated_densely_(survey_8d)": round(dense_survey / step_s / 8e12, 4),
                 "note": "bytes the step must move / step time / 8 TB/s.  The step is bound by fp32 matrix throughput: "
-                        "the north_star's >= 40 % HBM-roofline target does not apply to this design (0.9 GB per step)"}
+                        f"the north_star's >= 40 % HBM-roofline target does not apply to this design ({must / 1e9:.2f} GB per step)"}
             line["roofline"]["mfma_floor_ms_per_step"] = round(mlp_flop / 157.3e12 * 1e3, 4)
             line["roofline"]["mfma_floor_note"] = ("MLP FLOP of a step (3 x 2 x 434 176 per survivor) at the fp32 MFMA peak: no "
                                                    "schedule of exact-fp32 products can run the step faster")

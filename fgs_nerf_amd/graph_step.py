@@ -185,6 +185,9 @@ class CapturedFineStep:
         """Warm up (one eager forward + backward in the sync-free form on `batch`, no update: allocator pools, cached host
         copies of the geometry) and capture the step."""
         self.load(batch)
+        if hasattr(self.model, '_world_max'):
+            self.model._world_max()       # host copy of world_size.max() (the TV weight): read now, not inside the capture -- the
+                                          # warm-up pass runs no TV pass, and a grid rescale has just invalidated the cached value
         self._enter()
         try:
             # A leaf's AccumulateGrad node lives as long as any autograd graph that reaches it, and it remembers the stream it
