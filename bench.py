@@ -357,6 +357,49 @@ def main():
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
     torch.cuda.synchronize()
+    captured = None
+    if use_graph:
+        from fgs_nerf_amd.graph_step import CapturedFineStep
+        # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
+        seen = max(STEP_STATS["max_survivors"], 16384)
+        if world > 1:     # (buffers are rank-local, but one number for all keeps the ranks' graphs alike)
+            seen_t = torch.tensor([seen], dtype=torch.int64, device=dev)
+            dist.all_reduce(seen_t, op=dist.ReduceOp.MAX)
+            seen = int(seen_t.item())
+        capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
+        captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
+                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
+                                    global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
+                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity,
+                                    averager=averager if (world > 1 or force_dist) else None)
+        # Several ranks: a capture that fails on ANY rank (the capture pass itself issues no collective, so a failure is local
+        # and leaves the others unharmed) sends ALL ranks to the eager form below -- decided by one MIN all-reduce, so that
+        # no rank replays a graph whose collectives the others never launch.
+        capture_ok = 1
+        try:
+            captured.capture(batches[0])
+        except Exception as e:        # noqa: BLE001
+            if world == 1 and not force_dist:
+                raise
+            capture_ok = 0
+            print(f"[bench] rank {rank}: capturing the step failed ({type(e).__name__}: {e}); falling back to eager launches",
+                  file=sys.stderr, flush=True)
+        if world > 1:
+            ok_t = torch.tensor([capture_ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            capture_ok = int(ok_t.item())
+        if capture_ok:
+            packed = [torch.stack(b).contiguous() for b in batches]     # rays_o / rays_d / viewdirs / target as one [4, N, 3] block
+            for i in range(2):                       # two untimed replays (the first launch of a graph uploads it)
+                captured.replay(packed[i % N_BATCHES])
+            torch.cuda.synchronize()
+            captured.clear_counters()
+        else:
+            captured.release()
+            captured, use_graph = None, False
+            from fgs_nerf_amd import fused as _f
+            _f.reset_grid_grad(model, force=True)
+            opt.zero_grad(set_to_none=True)
     # Eager runs (several GPUs, --mode eager on request): the same launches, but with the survivor count left on the device
     # (fused.set_sync_free: fixed-capacity buffers, kernels clamp to the device-side count), so that the host never waits
     # for the GPU inside a step and its ~2 ms of Python per step overlap the previous step's kernels.  --mode eager-sync
@@ -373,27 +416,6 @@ def main():
         torch.cuda.synchronize()
         st_ = model._fused_cache['sync_free_buffers']
         st_['flags'].zero_(); st_['total'].zero_()
-    captured = None
-    if use_graph:
-        from fgs_nerf_amd.graph_step import CapturedFineStep
-        # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
-        seen = max(STEP_STATS["max_survivors"], 16384)
-        if world > 1:     # (buffers are rank-local, but one number for all keeps the ranks' graphs alike)
-            seen_t = torch.tensor([seen], dtype=torch.int64, device=dev)
-            dist.all_reduce(seen_t, op=dist.ReduceOp.MAX)
-            seen = int(seen_t.item())
-        capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
-        captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
-                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
-                                    global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
-                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity,
-                                    averager=averager if (world > 1 or force_dist) else None)
-        captured.capture(batches[0])
-        packed = [torch.stack(b).contiguous() for b in batches]     # rays_o / rays_d / viewdirs / target as one [4, N, 3] block
-        for i in range(2):                       # two untimed replays (the first launch of a graph uploads it)
-            captured.replay(packed[i % N_BATCHES])
-        torch.cuda.synchronize()
-        captured.clear_counters()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -494,6 +516,11 @@ def main():
             line["config"]["k0_exchange"] = {"form": "brick-sparse, device-counted, inside the captured step",
                                              "capacity_bricks": captured.exchange_capacity,
                                              "bytes_per_step": captured.exchange_capacity * 64 * 12 * 4}
+            if captured.sdf_exchange_capacity is not None:
+                line["config"]["sdf_exchange"] = {"form": "brick-sparse, device-counted (occupancy read from the gradient)",
+                                                  "capacity_bricks": captured.sdf_exchange_capacity,
+                                                  "bytes_per_step": captured.sdf_exchange_capacity * 64 * 4,
+                                                  "dense_bytes": 4 * GRID ** 3}
         line["config"]["step_mode"] = ("one hipGraph replay per step (gradient exchange included), no device->host read"
                                        if captured is not None and captured.averager is not None else
                                        "one hipGraph replay per step, no device->host read" if captured is not None

@@ -52,12 +52,20 @@ class GradAverager:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
                  big_numel: int = 1 << 20, sparse_min_numel: int = 1 << 24, sparse_max_fill: float = 0.5,
-                 force: bool = False):
+                 force: bool = False, sparse_1ch_min_numel: Optional[int] = 1 << 21, sparse_1ch_eager: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.big_numel = big_numel
         self.sparse_min_numel = sparse_min_numel
         self.sparse_max_fill = sparse_max_fill
+        # 1-channel grids (the sdf gradient: 16 MB at 160^3, 131 MB at 320^3, touched in a shell around the surface like k0's) go
+        # brick-sparse too from this size on (None: always dense); their occupancy is read from the gradient itself.  In the
+        # device-counted form (use_device_counts, the captured step) that costs one streaming pass; the host-counted form needs
+        # a blocking nonzero() at the very end of the backward pass, so eager steps keep the dense all-reduce unless
+        # `sparse_1ch_eager` asks otherwise (the gloo tests do).
+        self.sparse_1ch_min_numel = sparse_1ch_min_numel
+        self.sparse_1ch_eager = sparse_1ch_eager
+        self.last_sparse_fill_1ch = None
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()      # run the exchange even in a group of one (path rehearsal)
         # RCCL averages inside the collective (ncclAvg); gloo only sums, so the CPU tests scale afterwards
@@ -170,16 +178,35 @@ class GradAverager:
         if on_gpu and sc is not None:
             # device-counted form (use_device_counts): fixed-capacity buffer, fixed-size collective, nothing read by the host
             from ._lib import call, ptr, stream
-            if not (h is not None and h['armed'] and h['total'] == total):
-                raise RuntimeError("GradAverager: the device-counted exchange needs hint_touched() before every backward pass")
-            h['armed'] = False
-            torch.cuda.current_stream().wait_event(h['event'])
             cap, buf = sc['capacity'], sc['buf']
-            call("fgs_brick_gather_dev", ptr(g), *dims, ptr(h['idx']), ptr(h['count']), cap, ptr(buf), stream())
+            if h is not None and h['armed'] and h['total'] == total:
+                # occupancy hinted from the survivor points: union, brick list and guard were produced on the side stream
+                h['armed'] = False
+                torch.cuda.current_stream().wait_event(h['event'])
+                idx, count = h['idx'], h['count']
+            else:
+                # no hint (the 1-channel sdf gradient: every alive sample and every tap writes it): occupancy from the
+                # gradient itself, one streaming pass; then the same union / list / guard, all on this stream
+                u = sc.get('own')
+                if u is None or u['flags'].numel() != total + 1:
+                    u = sc['own'] = dict(flags=torch.zeros(total + 1, dtype=torch.int32, device=g.device),
+                                         idx=torch.empty(total, dtype=torch.int64, device=g.device),
+                                         count=torch.zeros(1, dtype=torch.int64, device=g.device))
+                call("fgs_brick_flags", ptr(g), *dims, ptr(u['flags']), stream())
+                if sc['guard_flags'] is not None:
+                    u['flags'][total:].copy_(sc['guard_flags'][1:2])
+                else:
+                    u['flags'][total:].zero_()
+                dist.all_reduce(u['flags'], op=dist.ReduceOp.MAX, group=group)
+                call("fgs_brick_compact", ptr(u['flags']), total, ptr(u['idx']), ptr(u['count']), stream())
+                call("fgs_brick_count_guard", ptr(u['count']), cap, ptr(sc['flags']), ptr(sc['sticky']), ptr(u['flags'][total:]),
+                     stream())
+                idx, count = u['idx'], u['count']
+            call("fgs_brick_gather_dev", ptr(g), *dims, ptr(idx), ptr(count), cap, ptr(buf), stream())
             dist.all_reduce(buf, op=self._op(), group=group)
-            call("fgs_brick_scatter_dev", ptr(g), *dims, ptr(h['idx']), ptr(h['count']), cap, ptr(buf),
+            call("fgs_brick_scatter_dev", ptr(g), *dims, ptr(idx), ptr(count), cap, ptr(buf),
                  1.0 if self.avg_in_collective else float(inv), stream())
-            self._note_union(param, g, h['idx'], cap, count_dev=h['count'])
+            self._note_union(param, g, idx, cap, count_dev=count)
             self.last_sparse_fill = None
             return True
         if on_gpu and h is not None and h['armed'] and h['total'] == total:
@@ -224,6 +251,8 @@ class GradAverager:
         dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)                              # union of occupancy
         idx = flags.nonzero(as_tuple=False).squeeze(1)                                          # identical on all ranks
         n = int(idx.numel())
+        if param is not None:
+            self.max_union_bricks[id(param)] = max(self.max_union_bricks.get(id(param), 0), n)
         self.last_sparse_fill = n / max(total, 1)
         if n > self.sparse_max_fill * total:
             return False
@@ -322,6 +351,15 @@ class GradAverager:
             return None
         return (int(n * margin) + granule - 1) // granule * granule
 
+    def last_device_count(self, param) -> Optional[int]:
+        """The union brick count of the most recent device-counted exchange of `param` whose occupancy came from the gradient
+        itself (one device->host read; None before the first one).  CapturedFineStep sizes the sdf exchange from it after its
+        eager warm-up pass."""
+        sc = self._static.get(id(param))
+        if sc is None or sc.get('own') is None:
+            return None
+        return int(sc['own']['count'].cpu()[0])
+
     def device_count_state(self, param, clear: bool = False):
         """(exchange overflowed: bool) of the device-counted exchange of `param` -- one device->host read; `clear` lowers
         the sticky flag again (after the caller has reset the gradient buffer: fused.reset_grid_grad)."""
@@ -332,6 +370,12 @@ class GradAverager:
         if clear:
             sc['sticky'].zero_()
         return over
+
+    def _sparse_1ch(self, g) -> bool:
+        """Shape-only predicate (identical on every rank) for the brick-sparse exchange of a 1-channel grid gradient."""
+        return (self.sparse_1ch_min_numel is not None and g.dim() == 5 and g.shape[0] == 1 and g.shape[1] == 1
+                and g.numel() >= self.sparse_1ch_min_numel and not (g.shape[2] % BRICK or g.shape[3] % BRICK or g.shape[4] % BRICK)
+                and g.is_contiguous())
 
     def _disarm(self, param) -> None:
         h = self._hints.get(id(param)) if param is not None else None
@@ -455,6 +499,9 @@ class GradAverager:
                 if g.numel() >= self.sparse_min_numel and g.dim() == 5 and g.shape[1] > 1:
                     sparse_later.append(g)
                     owner[id(g)] = p
+                elif self._sparse_1ch(g) and (self.sparse_1ch_eager or id(p) in self._static):
+                    sparse_later.append(g)
+                    owner[id(g)] = p
                 else:
                     handles.append(self._dense(g, async_op=True))
             else:
@@ -472,7 +519,11 @@ class GradAverager:
                 off += g.numel()
             torch._foreach_copy_(small, views)                                             # a few launches out
         for g in sparse_later:
-            if not self._sparse(g, inv, owner.get(id(g))):
+            one_ch, prev = g.shape[1] == 1, self.last_sparse_fill
+            ok = self._sparse(g, inv, owner.get(id(g)))
+            if one_ch:       # (`last_sparse_fill` keeps describing the multi-channel exchange)
+                self.last_sparse_fill_1ch, self.last_sparse_fill = self.last_sparse_fill, prev
+            if not ok:
                 self._disarm(owner.get(id(g)))
                 h, flat = self._dense(g, async_op=False)
                 self._post_scale(flat, inv)

@@ -19,6 +19,7 @@ step's data ever reaches the host:
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Dict, Optional, Sequence
 
 import numpy as np
@@ -102,6 +103,8 @@ class CapturedFineStep:
         self._updated = [[] for _ in self.variants]
         self._pinned = None
         self._exchange_state = None
+        self._sdf_exchange_state = None
+        self.sdf_exchange_capacity = None
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _enter(self):
@@ -113,12 +116,46 @@ class CapturedFineStep:
             self.averager.use_device_counts(self.model.k0.grid, self.exchange_capacity, guard_flags=st['flags'])
             # (the graphs will hold the addresses of the exchange buffer and of its sticky flag: this reference outlives _leave())
             self._exchange_state = self.averager._static[id(self.model.k0.grid)]
+        if self.averager is not None and self._sdf_exchange_is_sparse():
+            # the 1-channel sdf gradient, brick-sparse as well (occupancy from the gradient itself).  Its capacity is not known
+            # before a backward pass has run: the first warm-up pass of capture() runs with a provisional one (half the grid,
+            # the limit above which the exchange would rather be dense) and _size_sdf_exchange() then sets the real one.
+            sdf = self.model.sdf.grid
+            if self.sdf_exchange_capacity is None:
+                _, _, X, Y, Z = sdf.shape
+                self.sdf_exchange_capacity = max(1, (X // 4) * (Y // 4) * (Z // 4) // 2)
+                self._sdf_capacity_provisional = True
+            self.averager.use_device_counts(sdf, self.sdf_exchange_capacity, guard_flags=st['flags'])
+            self._sdf_exchange_state = self.averager._static[id(sdf)]
 
     def _leave(self):
         fused.set_sync_free(self.model, None)
         self.opt.use_device_schedule(None)
         if self.averager is not None:
             self.averager.use_device_counts(self.model.k0.grid, None)
+            self.averager.use_device_counts(self.model.sdf.grid, None)
+
+    def _sdf_exchange_is_sparse(self) -> bool:
+        sdf = self.model.sdf.grid
+        return self.averager._sparse_1ch(sdf) and os.environ.get("FGS_SDF_SPARSE", "1") == "1"
+
+    def _size_sdf_exchange(self) -> None:
+        """After the first (eager) warm-up pass: capacity of the sdf exchange = 1.5 x the union's brick count that pass saw,
+        rounded to 256 -- the same number on every rank (the count is the all-reduced union's)."""
+        if not getattr(self, '_sdf_capacity_provisional', False):
+            return
+        n = self.averager.last_device_count(self.model.sdf.grid)
+        self._sdf_capacity_provisional = False
+        if n is None:
+            return
+        sdf = self.model.sdf.grid
+        _, _, X, Y, Z = sdf.shape
+        total = (X // 4) * (Y // 4) * (Z // 4)
+        self.sdf_exchange_capacity = min(total, (int(1.5 * n) + 255) // 256 * 256)
+        st = self.model._fused_cache['sync_free']
+        self.averager.use_device_counts(sdf, self.sdf_exchange_capacity, guard_flags=st['flags'])
+        self._sdf_exchange_state = self.averager._static[id(sdf)]
+        st['flags'].zero_()
 
     def _exchange_is_sparse(self) -> bool:
         """dist.GradAverager's own (shape-only) predicate for the brick-sparse k0 exchange."""
@@ -204,6 +241,8 @@ class CapturedFineStep:
                     self._body(update=False, variant=k)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                if self.averager is not None and k == 0:
+                    self._size_sdf_exchange()
                 self.opt.zero_grad(set_to_none=True)
                 self._drop_autograd_leftovers()
                 fused.reset_grid_grad(self.model)  # the warm-up's k0.grad was not consumed: the captured step starts clean
@@ -297,8 +336,7 @@ class CapturedFineStep:
         """The union of touched k0 bricks exceeded `exchange_capacity` in some replay (one device->host read).  The replicas
         are still identical -- every rank skipped every update from that step on -- but the persistent gradient buffer holds
         leftovers: call fused.reset_grid_grad(model), then capture again with a larger capacity."""
-        st = self._exchange_state
-        return bool(int(st['sticky'].cpu()[0])) if st is not None else False
+        return any(bool(int(st['sticky'].cpu()[0])) for st in (self._exchange_state, self._sdf_exchange_state) if st is not None)
 
 
 CapturedStep = CapturedFineStep       # (the class serves both stages; the fine stage came first)

@@ -142,3 +142,44 @@ def test_device_counted_exchange_world2_overflow_protocol():
     assert by_step[2][1] > 6 and by_step[2][2:4] == (1, 1)         # the union did not fit: sticky + skip on both ranks
     assert by_step[3][1] <= 6 and by_step[3][2:4] == (1, 1)        # ... and it STAYS raised although this union fits
     assert all(r[4] for r in a if r[0] in (0, 1)) and all(r[4] for r in b if r[0] in (0, 1))
+
+
+def _sdf_sparse_worker(rank, world, port, out):
+    """The 1-channel sdf gradient through the brick-sparse exchange (host-counted and device-counted forms) == dense all-reduce."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fgs_nerf_amd.dist import GradAverager
+        ok = True
+        for counted in (False, True):
+            sdf = torch.nn.Parameter(torch.zeros(1, 1, 8, 12, 16))
+            gen = torch.Generator().manual_seed(7 + rank)
+            g = torch.zeros_like(sdf)
+            pick = torch.randperm(8 * 12 * 16, generator=gen)[:40]              # a sparse, rank-dependent set of voxels
+            g.view(-1)[pick] = torch.randn(40, generator=gen)
+            sdf.grad = g.clone()
+            avg = GradAverager([sdf], big_numel=256, sparse_1ch_min_numel=1024, sparse_1ch_eager=True)
+            if counted:
+                avg.use_device_counts(sdf, capacity=24)
+            avg.average()
+            ref = g.clone()
+            dist.all_reduce(ref)
+            ref /= world
+            ok = ok and torch.allclose(sdf.grad, ref, atol=1e-7) and bool(((sdf.grad != 0) == (ref != 0)).all())
+            if counted:
+                ok = ok and not avg.device_count_state(sdf)
+            else:
+                ok = ok and avg.last_sparse_fill_1ch is not None and 0 < avg.last_sparse_fill_1ch <= 1.0
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sdf_gradient_brick_sparse_exchange_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sdf_sparse_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] and out[1]

@@ -380,7 +380,9 @@ def test_captured_step_with_exchange_matches_eager_exchange(dev):
         for mode in ("eager", "captured"):
             model = synth.build_model(64, synth.FINE_MODEL, device=dev)
             opt = bench.make_optimizer(model)
-            avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16)
+            # (captured: the 1-channel sdf gradient goes brick-sparse too, device-counted, its capacity sized by capture())
+            avg = GradAverager(model.parameters(), force=True, sparse_min_numel=1 << 16,
+                               sparse_1ch_min_numel=(1 << 16) if mode == "captured" else None)
             avg.attach(model)
             avg.attach_optimizer(opt)
             fused.enable_early_update(model, opt, avg)
@@ -391,6 +393,7 @@ def test_captured_step_with_exchange_matches_eager_exchange(dev):
             assert not overflow and total > 0, mode
             if cap is not None:
                 assert not cap.exchange_overflowed()
+                assert cap.sdf_exchange_capacity is not None and 0 < cap.sdf_exchange_capacity < 16 ** 3 // 2
                 assert all(opt.state[p]['step'] == STEPS for g in opt.param_groups for p in g['params'])
             outs[mode] = (total, [p.detach().clone() for p in model.parameters()])
         assert abs(outs["eager"][0] - outs["captured"][0]) <= 8
