@@ -52,14 +52,16 @@ class GradAverager:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
                  big_numel: int = 1 << 20, sparse_min_numel: int = 1 << 24, sparse_max_fill: float = 0.5,
-                 force: bool = False, sparse_1ch_min_numel: Optional[int] = 1 << 21, sparse_1ch_eager: bool = False):
+                 force: bool = False, sparse_1ch_min_numel: Optional[int] = 1 << 24, sparse_1ch_eager: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.big_numel = big_numel
         self.sparse_min_numel = sparse_min_numel
         self.sparse_max_fill = sparse_max_fill
         # 1-channel grids (the sdf gradient: 16 MB at 160^3, 131 MB at 320^3, touched in a shell around the surface like k0's) go
-        # brick-sparse too from this size on (None: always dense); their occupancy is read from the gradient itself.  In the
+        # brick-sparse too from this size on (None: always dense; default 256^3 = 67 MB: below that the six extra launches of the
+        # sparse form -- flags, compact, guard, gather, scatter, the flags' own all-reduce -- cost about what the smaller
+        # collective saves; single-rank rehearsal at 160^3: +35 us per step); their occupancy is read from the gradient itself.  In the
         # device-counted form (use_device_counts, the captured step) that costs one streaming pass; the host-counted form needs
         # a blocking nonzero() at the very end of the backward pass, so eager steps keep the dense all-reduce unless
         # `sparse_1ch_eager` asks otherwise (the gloo tests do).

@@ -247,7 +247,17 @@ class CapturedFineStep:
                 self._drop_autograd_leftovers()
                 fused.reset_grid_grad(self.model)  # the warm-up's k0.grad was not consumed: the captured step starts clean
                 self.graphs[k] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graphs[k]):
+                gkw = {}
+                if self.averager is not None:
+                    # ProcessGroupNCCL's watchdog THREAD polls the events of earlier (eager) collectives with hipEventQuery; under
+                    # the default "global" capture mode that call is illegal from ANY thread while this one captures, and the
+                    # watchdog then takes the process down ("operation not permitted when stream is capturing" -> terminate:
+                    # seen when the warm-up pass's collectives were still on its list).  Two measures: thread-local capture mode
+                    # (only the capturing thread is policed), and the watchdog's list given time to drain (it wakes every 100 ms).
+                    gkw['capture_error_mode'] = 'thread_local'
+                    import time
+                    time.sleep(0.35)
+                with torch.cuda.graph(self.graphs[k], **gkw):
                     # (detached: the scalar lives in the graph's pool either way, and a loss that kept its autograd graph
                     # -- the leaves' AccumulateGrad nodes, bound to THIS capture's stream -- would reach into the next capture)
                     self.losses[k] = self._body(update=True, variant=k).detach()
