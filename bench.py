@@ -512,6 +512,15 @@ def main():
         }
         if STEP_STATS.get("overflow"):
             line["config"]["capacity_overflow_on_rank0"] = True
+        from fgs_nerf_amd import fused as _fz
+        if _fz._MLP_COLLAPSE and args.stage == "fine" and not args.composed:
+            # a labelled mode, not the headline: less arithmetic than the reference's operation order (roofline books the FLOP
+            # it executes, so `frac` cannot rise from doing less)
+            line["config"]["mlp_mode"] = ("FGS_MLP_COLLAPSE=1: rgbnet's last Linear and refnet's first as ONE 256x256 layer with a "
+                                          "per-step pre-multiplied weight (368 640 instead of 434 176 MAC per survivor and pass); "
+                                          "NOT the reference's operation order -- secondary line")
+        else:
+            line["config"]["mlp_mode"] = "reference operation order"
         if captured is not None and captured.exchange_capacity is not None:
             line["config"]["k0_exchange"] = {"form": "brick-sparse, device-counted, inside the captured step",
                                              "capacity_bricks": captured.exchange_capacity,

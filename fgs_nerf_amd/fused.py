@@ -147,6 +147,25 @@ class _DeviceScalars:
         return False
 
 
+class _HostRows:
+    """Launches on PARAMETER-sized operands (the pre-multiplied weight of _MLP_COLLAPSE and its gradient products) issued from
+    inside a sync-free forward / backward pass: their row counts are host numbers, whatever device-side survivor count the
+    surrounding code runs under (fgs_set_row_count_ptr is per host thread)."""
+
+    def __init__(self, run):
+        self.ptr = run.count_ptr if run.sync_free else None
+
+    def __enter__(self):
+        if self.ptr is not None:
+            call("fgs_set_row_count_ptr", None)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ptr is not None:
+            call("fgs_set_row_count_ptr", self.ptr)
+        return False
+
+
 def set_sync_free(model, capacity=None, inv_s_dev=None) -> None:
     """Switch the fused path of `model` (fine or coarse stage) to the sync-free form (or back, with capacity=None): the survivor count
     is never read by the host; result tensors, activations and gradients of the survivors are allocated for `capacity` rows
@@ -346,15 +365,20 @@ def _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
 
 
 def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs):
+                 gw_rgb, gb_rgb, gw_ref, gb_ref, cs, gV0p=None, rgb_b=None):
     """FGS_MLP=rc: every 256-wide data gradient of the two MLPs in ONE register-resident launch (fgs_mlp_rc_chain on the
     transposed weight images, ReLU masks from the 16-byte-per-lane sign bits the forward chain saved), the two narrow
     products (the reflection-encoding columns of dZ, dX0) as plain NN GEMMs on the dY tensors the chain wrote out.  Returns
     (dZ, dX0, wgrad): `wgrad(fork)` issues every weight and bias gradient in ONE fgs_mlp_wgrad launch, written straight into
-    the views of the flat gradient buffer -- the caller decides where in the backward pass (see _wgrad)."""
+    the views of the flat gradient buffer -- the caller decides where in the backward pass (see _wgrad).
+    With S['Wc_full'] (FGS_MLP_COLLAPSE): rgbnet's last layer and refnet's first are one layer here too (see _MLP_COLLAPSE);
+    `gV0p` (a zero-filled [fw, ldz] slot of the flat buffer the rc path does not otherwise use) receives the collapsed weight's
+    gradient, from which three small products behind the weight-gradient launch make dW3, dV0a and db3."""
     S = run.saved
     dev = dY.device
     bits = S['relu_bits']
+    Wc_full = S.get('Wc_full')
+    collapse = Wc_full is not None
     layers = []
     dY_ref = [None] * (n_ref - 1)            # dY_ref[i]: gradient w.r.t. the pre-activation output of refnet layer i
     dY_ref[n_ref - 2] = dY
@@ -363,14 +387,25 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         layers.append(dict(W=ref_w[i], mask_bits=bits[n_rgb + i - 1], out=out, n_store=fw))
         dY_ref[i - 1] = out
     dZ = torch.empty(M, ldz, dtype=F32, device=dev)
-    layers.append(dict(W=ref_w[0][:, :rw], out=dZ, n_store=rw))      # no activation under refnet layer 0: no mask
     dY_rgb = [None] * n_rgb                  # dY_rgb[i]: gradient w.r.t. the output of rgbnet layer i
-    dY_rgb[n_rgb - 1] = dZ[:, :rw]
-    for i in range(n_rgb - 1, 0, -1):
+    if collapse:
+        # dY_ref[0] . (V0a W3), masked by the ReLU of rgbnet layer n_rgb - 2: straight to that layer's output gradient
+        out = torch.empty(M, rw, dtype=F32, device=dev)
+        layers.append(dict(W=Wc_full[:, :rw], mask_bits=bits[n_rgb - 2], out=out, n_store=rw))
+        dY_rgb[n_rgb - 2] = out
+        first_rgb = n_rgb - 2
+    else:
+        layers.append(dict(W=ref_w[0][:, :rw], out=dZ, n_store=rw))      # no activation under refnet layer 0: no mask
+        dY_rgb[n_rgb - 1] = dZ[:, :rw]
+        first_rgb = n_rgb - 1
+    for i in range(first_rgb, 0, -1):
         out = torch.empty(M, rw, dtype=F32, device=dev)
         layers.append(dict(W=rgb_w[i], mask_bits=bits[i - 1], out=out, n_store=rw))
         dY_rgb[i - 1] = out
-    fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1)))
+    flop_chain = 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
+    if collapse:
+        flop_chain -= 2.0 * M * rw * rw
+    fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain)
     # narrow products: the reflection-encoding columns of dZ (dY_ref[0] . V0[:, rw:]) and dX0 (dY_rgb[0] . W0).  (As one-layer
     # register-resident chains of 4 row tiles they measured 63 us each against 47 for the tiled GEMM: with 64 MFMAs per chunk
     # the chain's per-chunk barrier / DMA and its uncoalesced input load dominate.)
@@ -388,12 +423,32 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         run.dx0_compact = False
     # all weight / bias gradients (the bias gradient of the top refnet layer came out of the head kernel)
     items = []
+    post = None
     for i in range(n_ref - 1):
+        if collapse and i == 0:
+            # dWc = dY_ref0^T h (h = the input of rgbnet's last layer) into the spare zero-filled slot, dbc straight into dc0's
+            # slot (dc0 = dbc), and the reflection-encoding columns of dV0 where they belong
+            items.append((dY_ref[0], acts_rgb[n_rgb - 1], gV0p[:, :rw], gb_ref[0], fw, rw))
+            items.append((dY_ref[0], S['Z'][:, rw:], gw_ref[0][:, rw:], None, fw, z_cols - rw))
+            continue
         items.append((dY_ref[i], acts_ref[i], gw_ref[i], None if i == n_ref - 2 else gb_ref[i], fw, ref_w[i].shape[1]))
-    for i in range(n_rgb):
+    for i in range(n_rgb - 1 if collapse else n_rgb):
         items.append((dY_rgb[i], acts_rgb[i], gw_rgb[i], gb_rgb[i], rw, rgb_w[i].shape[1]))
     flop = 2.0 * M * (fw * sum(w.shape[1] for w in ref_w[:-1]) + rw * sum(w.shape[1] for w in rgb_w))
-    return dZ, dX0, lambda fork: _wgrad(dev, M, items, flop, fork)
+    if collapse:
+        flop -= 2.0 * M * rw * rw
+        V0a, W3, b3 = S['V0p'][:, :rw], rgb_w[n_rgb - 1], rgb_b[n_rgb - 1]
+        dWc, dbc = gV0p[:, :rw], gb_ref[0]
+
+        def post():
+            # (on the stream of the weight-gradient launch, right behind it: three 256^3 products and three small vector ops)
+            tmp = torch.empty(fw, rw, dtype=F32, device=dev)
+            with _HostRows(run):
+                fo.gemm(fo.GEMM_TN, V0a, dWc, gw_rgb[n_rgb - 1], rw, rw, fw)                 # dW3 = V0a^T dWc
+                fo.gemm(fo.GEMM_NT, dWc, W3.detach(), tmp, fw, rw, rw)                        # dWc W3^T
+            gw_ref[0][:, :rw].copy_(torch.addcmul(tmp, dbc[:, None], b3.detach()[None, :]))   # dV0a = dWc W3^T + dbc b3^T
+            gb_rgb[n_rgb - 1].copy_((V0a * dbc[:, None]).sum(0))                              # db3 = V0a^T dbc
+    return dZ, dX0, lambda fork: _wgrad(dev, M, items, flop, fork, post)
 
 
 # The weight-gradient launch (k_mlp_wgrad: 57 + 256 registers per lane, one 256-thread workgroup per CU, 132 KB of LDS, matrix
@@ -414,12 +469,21 @@ _DX0_COMPACT = os.environ.get("FGS_DX0_COMPACT", "1") == "1"
 # registers and LDS leave its waves two slots per SIMD) is issued: right behind the feature-grid scatter (0), or as the branch's
 # last kernel (1), where it mostly runs after the weight-gradient launch has drained.
 _K0_ADAM_LATE = os.environ.get("FGS_K0_ADAM_LATE", "0") == "1"
+# FGS_MLP_COLLAPSE=1 (a LABELLED mode, never the default: bench.py marks its line): rgbnet's last Linear has no activation and feeds
+# refnet's first Linear (model/nerf.py:135-142,877-884), so  V0[:, :256] (W3 h + b3) + V0[:, 256:] e + c0  =  (V0a W3) h + V0b e +
+# (V0a b3 + c0): ONE 256 x 256 layer with a per-step pre-multiplied weight instead of two -- 65 536 of 434 176 MAC per survivor in
+# each of the forward, data-gradient and weight-gradient passes.  The gradients of the original parameters follow from the
+# collapsed layer's by three 256^3 products per step (dW3 = V0a^T dWc, dV0a = dWc W3^T + dbc b3^T, db3 = V0a^T dbc, dc0 = dbc).
+# Values differ from the reference order by float32 re-association only (tests/test_fullsize_parity_gpu.py passes unchanged).
+_MLP_COLLAPSE = os.environ.get("FGS_MLP_COLLAPSE", "0") == "1"
 _SIDE_PENDING = set()
 
 
-def _wgrad(dev, M, items, flop, fork: bool) -> None:
+def _wgrad(dev, M, items, flop, fork: bool, post=None) -> None:
     if not (fork and _WGRAD_FORK):
         fo.mlp_wgrad(M, items, flop=flop)
+        if post is not None:
+            post()
         return
     side, keep = _side(dev)
     ready = torch.cuda.Event()
@@ -427,6 +491,8 @@ def _wgrad(dev, M, items, flop, fork: bool) -> None:
     with torch.cuda.stream(side):
         side.wait_event(ready)
         fo.mlp_wgrad(M, items, flop=flop)
+        if post is not None:
+            post()                      # (_MLP_COLLAPSE: the original parameters' gradients from the collapsed layer's)
     keep.append(items)                  # (allocated on the main stream: alive until the join)
     _SIDE_PENDING.add(dev.index)
 
@@ -713,7 +779,15 @@ class _FusedFine(torch.autograd.Function):
             per = fo.rc_mask_bits(M, dev).numel()
             relu_bits = torch.empty(n_rgb + n_ref - 1, per, dtype=torch.int32, device=dev)
             layers = []
-            for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
+            collapse = _MLP_COLLAPSE and n_rgb >= 2 and n_ref >= 2
+            Wc_full = bias_c = None
+            if collapse:
+                # Wc_full = [V0a W3 | V0b] (K-padded like V0p), bias_c = V0a b3 + c0: two small launches per step
+                Wc_full = V0p.clone()
+                with _HostRows(run):
+                    fo.gemm(fo.GEMM_NN, V0p[:, :rw], rgb_w[-1].detach(), Wc_full[:, :rw], fw, rw, rw)
+                bias_c = (V0p[:, :rw] * rgb_b[-1].detach()).sum(1) + ref_b[0].detach()
+            for i in range(n_rgb - 1 if collapse else n_rgb):   # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
                 last = i == n_rgb - 1
                 layers.append(dict(W=rgb_w[i].detach(), bias=rgb_b[i].detach(), relu=not last,
                                    mask_bits=None if last else relu_bits[i], out=Z if last else acts_rgb[i + 1], n_store=rw))
@@ -722,9 +796,13 @@ class _FusedFine(torch.autograd.Function):
                          out=acts_ref[i + 1], n_store=fw)
                 if i == 0:
                     L.update(ext=Z[:, rw:], ext_cols=ldz - rw)
+                    if collapse:     # the carried input is rgbnet's last HIDDEN activation, the weight the pre-multiplied one
+                        L.update(W=Wc_full[:, :ref_w[0].shape[1]], bias=bias_c)
                 layers.append(L)
-            fo.rc_chain(False, M, X0, ldx0, layers,
-                        flop=2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1])))
+            flop_fwd = 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
+            if collapse:
+                flop_fwd -= 2.0 * M * rw * rgb_w[-1].shape[1]
+            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd)
         elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
@@ -786,6 +864,7 @@ class _FusedFine(torch.autograd.Function):
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
                                    acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, WT=WT, relu_bits=relu_bits,
+                                   Wc_full=(Wc_full if use_rc else None),
                                    pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
@@ -901,7 +980,8 @@ class _FusedFine(torch.autograd.Function):
         wgrad = None
         if S.get('relu_bits') is not None:
             dZ, dX0, wgrad = _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
-                                          gw_rgb, gb_rgb, gw_ref, gb_ref, cs)
+                                          gw_rgb, gb_rgb, gw_ref, gb_ref, cs, gV0p=gV0p,
+                                          rgb_b=[mlp[2 * i + 1] for i in range(n_rgb)])
         elif S.get('WT') is not None and ldx0 <= 256:
             dZ, dX0 = _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
                                       gw_rgb, gb_rgb, gw_ref, gb_ref, gW0p, gV0p, cs)
