@@ -54,13 +54,8 @@ def train_step(model, opt, averager, batch, n_rays_global):
     loss = fused_render_losses(res, target, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model)
     pts = res.get('survivor_pts') if hasattr(res, 'get') else None
     if pts is not None:   # every k0 gradient of this step comes from trilinear lookups at the survivors
-        count_ptr = res.get('survivor_count_ptr')
-        if count_ptr is None:
-            averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
-        else:             # sync-free: `pts` has CAPACITY rows, the rows that count are behind a device-side counter
-            from fgs_nerf_amd.fused import _DeviceScalars
-            with _DeviceScalars(count=count_ptr):
-                averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max)
+        # (sync-free: `pts` has CAPACITY rows, the rows that count are behind a device-side counter)
+        averager.hint_touched(model.k0.grid, pts, model.xyz_min, model.xyz_max, count_ptr=res.get('survivor_count_ptr'))
     opt.zero_grad(set_to_none=True)
     seed = STEP_STATS.get("seed")
     if seed is None or seed.device != loss.device:
@@ -92,7 +87,7 @@ def touched_voxels(model, batches) -> float:
             res = model(b[0], b[1], b[2], global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
             pts = res['survivor_pts'][:res['weights'].shape[0]].contiguous()
             flags.zero_()
-            call("fgs_brick_masks_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(flags), stream())
+            call("fgs_brick_masks_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(flags), None, stream())
             total += int(flags.sum())
     return total / max(len(batches), 1)
 

@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -41,7 +41,7 @@ _SIGNATURES = {
     "fgs_trilerp_bwd": [P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I64, P, P],
     "fgs_sdf_taps_fwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P, P],
     "fgs_sdf_taps_bwd": [P, I64, I64, I64, P, P, P, I64, P, I32, P, P],
-    "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P, I64, P],
+    "fgs_gemm_f32": [I32, I64, I64, I64, P, I64, P, I64, P, I64, P, I32, P, I64, P, P, I64, P, P],
     "fgs_linear_bwd_f32": [I64, I64, I64, P, I64, P, I64, P, I64, P, I64, P, I64, P, P, I64, P],
     "fgs_mlp_fwd_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P],
     "fgs_mlp_chain_f32": [I64, I32, P, I64, I32, P, I64, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -49,51 +49,48 @@ _SIGNATURES = {
     "fgs_pad_cols_multi": [I32, P, P, P, P, P, P, P],
     "fgs_copy_cols_multi": [I32, P, P, P, P, P, P, P, P],
     "fgs_debug_pad_cols_old_indexing": [P, I32, I32, I64, P, I64, P],
-    "fgs_set_row_count_ptr": [P],
-    "fgs_set_inv_s_ptr": [P],
-    "fgs_set_dx0_compact": [I32],
     "fgs_step_scalars_tick": [P, I32, I32, P, P, I32, P, P],
     "fgs_count_guard": [P, I64, I64, P, P, P],
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, I32, F32, F32, F32, F32, I32, P, P],
     "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, P, P, F32, F32, F32, P, P],
-    "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P],
+    "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P, P],
     "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
-    "fgs_mlp_wgrad": [I64, I32, P, P],
+    "fgs_mlp_wgrad": [I64, I32, P, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_exclusive_scan_guard_i64": [P, I64, P, I64, P, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
-                           P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P],
+                           P, P, P, I32, I32, I32, F32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_march_count": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
-                        P, P, P, I32, I32, I32, F32, I32, P, P, P],
+                        P, P, P, I32, I32, I32, F32, I32, P, P, P, P],
     "fgs_surv_compact": [I64, I64, P, I32, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32,
-                         P, P, P, P, P, P, P, P, P],
+                         P, P, P, P, P, P, P, P, P, P],
     "fgs_march_fine_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, I32,
-                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "fgs_sdf_scatter_surv": [I64, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P],
+                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_sdf_scatter_surv": [I64, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P],
     "fgs_brick_flags": [P, I32, I32, I32, I32, P, P],
     "fgs_brick_gather": [P, I32, I32, I32, I32, P, I64, P, P],
     "fgs_brick_scatter": [P, I32, I32, I32, I32, P, I64, P, F32, P],
-    "fgs_brick_flags_pts": [P, I64, P, P, I32, I32, I32, P, P],
+    "fgs_brick_flags_pts": [P, I64, P, P, I32, I32, I32, P, P, P],
     "fgs_brick_compact": [P, I64, P, P, P],
     "fgs_brick_gather_dev": [P, I32, I32, I32, I32, P, P, I64, P, P],
     "fgs_brick_scatter_dev": [P, I32, I32, I32, I32, P, P, I64, P, F32, P],
     "fgs_brick_count_guard": [P, I64, P, P, P, P],
     "fgs_tv_loss_value": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P],
     "fgs_tv_loss_grad": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I32, P],
-    "fgs_brick_masks_pts": [P, I64, P, P, I32, I32, I32, P, P],
+    "fgs_brick_masks_pts": [P, I64, P, P, I32, I32, I32, P, P, P],
     "fgs_adam_upd_voxels": [P, P, P, P, I32, I32, I32, I32, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_bricks": [P, P, P, P, I32, I32, I32, I32, P, P, I64, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_multi": [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P],
-    "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P],
-    "fgs_fine_loss_bwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "fgs_feat_fine_fwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, I64, I64, I64, P, P, P, P],
+    "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_fine_loss_bwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_feat_fine_fwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P],
     "fgs_feat_fine_bwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64,
-                          P, P, P],
-    "fgs_head_fwd": [P, I64, I32, I64, P, P, P, P],
-    "fgs_head_bwd": [P, I64, I32, I64, P, P, P, P, P, P, P, P],
+                          P, P, P, P],
+    "fgs_head_fwd": [P, I64, I32, I64, P, P, P, P, P],
+    "fgs_head_bwd": [P, I64, I32, I64, P, P, P, P, P, P, P, P, P],
     "fgs_composite_fwd": [I64, P, P, P, P, P, F32, F32, P, P, P, P, P, P, P],
-    "fgs_composite_bwd": [I64, P, P, P, P, P, P, P, P, P, F32, P, P, P],
+    "fgs_composite_bwd": [I64, P, P, P, P, P, P, P, P, P, F32, P, P, P, P],
     "fgs_smooth3d_fwd": [P, I32, I32, I32, I32, P, P, P],
     "fgs_smooth3d_bwd": [P, I64, I32, I32, I32, I32, P, P, P, P],
     "fgs_smooth_tv_loss": [P, I32, I32, I32, P, P, P, F32, P, P, P],
@@ -101,11 +98,11 @@ _SIGNATURES = {
     "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, P, I32, P],
     "fgs_march_coarse_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, P, P, P, F32, F32, F32,
                              P, P, P, I32, I32, I32, F32, P, I32, I32, I32, P, P, I32,
-                             P, P, P, P, P, P, P, P, P, P, P, P, P],
+                             P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_march_coarse_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, I32,
-                             P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
-    "fgs_feat_coarse_fwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, I64, I64, I64, I64, P, P, P],
-    "fgs_feat_coarse_bwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I64, I64, I64, I64, P, P],
+                             P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_feat_coarse_fwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, I64, I64, I64, I64, P, P, P, P],
+    "fgs_feat_coarse_bwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I64, I64, I64, I64, P, P, P],
     "fgs_ide_fwd": [P, P, P, P, I32, I32, I64, P, P],
     "fgs_ide_bwd": [P, P, P, P, I32, I32, I64, P, P, P, P],
     "fgs_mc_count": [P, I32, I32, I32, F32, P, P, P, P, P],
@@ -130,6 +127,20 @@ class WgradItem(ctypes.Structure):
                 ("X", c_void_p), ("ld_x", c_int64), ("n_in", c_int),
                 ("dW", c_void_p), ("ld_dw", c_int64),
                 ("dbias", c_void_p)]
+
+
+class Dyn(ctypes.Structure):
+    """fgs_dyn_t (include/fgs_hip.h): the device-resident values a launch may read instead of its host arguments."""
+    _fields_ = [("row_count", c_void_p), ("inv_s", c_void_p), ("dx0_compact", c_int)]
+
+
+def dyn(row_count=None, inv_s=None, compact: bool = False):
+    """`const fgs_dyn_t *` argument for the entry points that take one: None (NULL) when nothing is device-resident, else a
+    pointer to a struct holding the raw device addresses (ints) of the survivor count / NeuS 1/s and the compact-dX0 flag.
+    The C side copies the members into its kernel arguments before it returns: the struct need not outlive the call."""
+    if row_count is None and inv_s is None and not compact:
+        return None
+    return ctypes.byref(Dyn(row_count, inv_s, int(bool(compact))))
 
 
 class FgsError(RuntimeError):

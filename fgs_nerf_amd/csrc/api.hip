@@ -6,28 +6,6 @@
 
 namespace {
 thread_local char g_last_error[512] = "";
-thread_local const int64_t *g_row_ptr = nullptr;
-thread_local const float *g_inv_s_ptr = nullptr;
-thread_local int g_dx0_compact = 0;
-}
-
-const int64_t *fgs_row_ptr() { return g_row_ptr; }
-const float *fgs_inv_s_ptr() { return g_inv_s_ptr; }
-int fgs_dx0_compact() { return g_dx0_compact; }
-
-FGS_API int fgs_set_dx0_compact(int on) {
-  g_dx0_compact = on ? 1 : 0;
-  return 0;
-}
-
-FGS_API int fgs_set_inv_s_ptr(const float *inv_s_dev) {
-  g_inv_s_ptr = inv_s_dev;
-  return 0;
-}
-
-FGS_API int fgs_set_row_count_ptr(const int64_t *count_dev) {
-  g_row_ptr = count_dev;
-  return 0;
 }
 
 int fgs_set_error(int code, const char *fmt, ...) {

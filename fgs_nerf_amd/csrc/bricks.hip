@@ -262,7 +262,7 @@ FGS_API int fgs_brick_count_guard(int64_t *count_dev, int64_t capacity, int *fla
 // Brick occupancy from sample points instead of from the gradient (see k_brick_flags_pts).  ORs into `flags`
 // (caller zeroes it once per step); xyz_min/max on the host, grid [X,Y,Z] as for the trilinear kernels.
 FGS_API int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X,
-                                int Y, int Z, int *flags, fgs_stream_t stream) {
+                                int Y, int Z, int *flags, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   BrickGrid g;      // sides that are not multiples of 4 are fine here: the last brick of an axis is then partial
   if (int e = make_grid_any("fgs_brick_flags_pts", 1, X, Y, Z, &g)) return e;
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_brick_flags_pts: M=%lld", (long long)M);
@@ -272,7 +272,7 @@ FGS_API int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_mi
   SceneGeom sg;
   for (int c = 0; c < 3; ++c) { sg.lo[c] = xyz_min_host[c]; sg.hi[c] = xyz_max_host[c]; }
   sg.X = X; sg.Y = Y; sg.Z = Z; sg.voxel_size = 0.f;
-  hipLaunchKernelGGL(k_brick_flags_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, fgs_row_ptr(), sg, g,
+  hipLaunchKernelGGL(k_brick_flags_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, fgs_dyn_rows(dyn), sg, g,
                      flags);
   FGS_LAUNCH_OK("fgs_brick_flags_pts");
   return 0;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_voxels(float *__restrict__ p
 // voxels that hold a trilinear corner of the points (the caller zeroes the buffer once; fgs_adam_upd_voxels leaves it zero).  Index mapping and
 // row-count handling as fgs_brick_flags_pts.
 FGS_API int fgs_brick_masks_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
-                                int Z, unsigned char *masks, fgs_stream_t stream) {
+                                int Z, unsigned char *masks, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   BrickGrid g;
   if (int e = make_grid_any("fgs_brick_masks_pts", 1, X, Y, Z, &g)) return e;
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_brick_masks_pts: M=%lld", (long long)M);
@@ -498,7 +498,7 @@ FGS_API int fgs_brick_masks_pts(const float *pts, int64_t M, const float *xyz_mi
   SceneGeom sg;
   for (int c = 0; c < 3; ++c) { sg.lo[c] = xyz_min_host[c]; sg.hi[c] = xyz_max_host[c]; }
   sg.X = X; sg.Y = Y; sg.Z = Z; sg.voxel_size = 0.f;
-  hipLaunchKernelGGL(k_brick_masks_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, fgs_row_ptr(), sg, g,
+  hipLaunchKernelGGL(k_brick_masks_pts, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), pts, M, fgs_dyn_rows(dyn), sg, g,
                      masks);
   FGS_LAUNCH_OK("fgs_brick_masks_pts");
   return 0;

@@ -698,7 +698,7 @@ SceneGeom geom_of(const float *lo, const float *hi, int X, int Y, int Z, float v
   return g;
 }
 
-int fill_layout(const int *li, const float *disp, FeatLayout *L) {
+int fill_layout(const int *li, const float *disp, FeatLayout *L, int compact = 0) {
   // li: k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, center_sdf, use_grad_norm, K, ldx0, off_ref, ldz
   L->k0_dim = li[0]; L->n_posfreq = li[1]; L->n_viewfreq = li[2]; L->n_reffreq = li[3];
   L->use_viewdir = li[4]; L->center_sdf = li[5]; L->use_grad_norm = li[6]; L->K = li[7];
@@ -716,8 +716,8 @@ int fill_layout(const int *li, const float *disp, FeatLayout *L) {
   L->off_hgrad = c; c += 3 * L->K;
   L->off_grad = c; c += 3;
   L->x0_cols = c;
-  L->dx_gap = fgs_dx0_compact() ? L->off_sdf - L->off_xyz : 0;
-  L->dx_ld = fgs_dx0_compact() ? (L->x0_cols - L->dx_gap + 3) / 4 * 4 : L->ldx0;
+  L->dx_gap = compact ? L->off_sdf - L->off_xyz : 0;
+  L->dx_ld = compact ? (L->x0_cols - L->dx_gap + 3) / 4 * 4 : L->ldx0;
   L->z_cols = L->off_ref + 3 + 6 * L->n_reffreq;
   if (L->ldx0 < L->x0_cols || L->ldz < L->z_cols || (L->ldx0 & 3) || (L->ldz & 3))
     return fgs_set_error(FGS_E_INVALID, "feature layout: ldx0=%d (need >= %d), ldz=%d (need >= %d), multiples of 4",
@@ -725,7 +725,7 @@ int fill_layout(const int *li, const float *disp, FeatLayout *L) {
   return 0;
 }
 
-int fill_layout_coarse(const int *li, FeatLayout *L) {
+int fill_layout_coarse(const int *li, FeatLayout *L, int compact = 0) {
   // li: k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, ldx0
   L->k0_dim = li[0]; L->n_posfreq = li[1]; L->n_viewfreq = li[2]; L->n_reffreq = li[3]; L->use_viewdir = li[4];
   L->center_sdf = 0; L->use_grad_norm = 0; L->K = 0; L->ldx0 = li[5]; L->coarse = 1;
@@ -741,8 +741,8 @@ int fill_layout_coarse(const int *li, FeatLayout *L) {
   L->x0_cols = c;
   // compact dX0 (fgs_set_dx0_compact): [k0 | reflect_emb | normal] -- the xyz encoding between k0 and the reflection block and
   // the view-direction encoding at the end are functions of the fixed ray inputs
-  L->dx_gap = fgs_dx0_compact() ? L->off_ref - L->off_xyz : 0;
-  L->dx_ld = fgs_dx0_compact() ? (L->off_view - L->dx_gap + 3) / 4 * 4 : L->ldx0;
+  L->dx_gap = compact ? L->off_ref - L->off_xyz : 0;
+  L->dx_ld = compact ? (L->off_view - L->dx_gap + 3) / 4 * 4 : L->ldx0;
   L->ldz = L->ldx0; L->z_cols = L->ldx0;
   if (L->ldx0 < L->x0_cols || (L->ldx0 & 3))
     return fgs_set_error(FGS_E_INVALID, "coarse feature layout: ldx0=%d (need >= %d, multiple of 4)", L->ldx0, L->x0_cols);
@@ -756,13 +756,13 @@ int fill_layout_coarse(const int *li, FeatLayout *L) {
 FGS_API int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient,
                                 const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
                                 int Z, const int *layout_i, const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY,
-                                int64_t ksZ, float *X0, float *normal_out, fgs_stream_t stream) {
+                                int64_t ksZ, float *X0, float *normal_out, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_coarse_fwd: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && k0_grid && X0 && normal_out,
               FGS_E_INVALID, "fgs_feat_coarse_fwd: null pointer");
   SurvArgs S;
-  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_dyn_rows(dyn); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
   if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -778,15 +778,15 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
                                 const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
                                 int Z, const int *layout_i, const float *X0, const float *dX0, const float *g_normal,
                                 float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient,
-                                fgs_stream_t stream) {
+                                const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_coarse_bwd: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(ray_id && pts && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && k0_grad_grid &&
                   g_gradient, FGS_E_INVALID, "fgs_feat_coarse_bwd: null pointer");
   SurvArgs S;
-  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_dyn_rows(dyn); S.ray_id = ray_id; S.pts = pts; S.sdf = nullptr; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
-  if (int e = fill_layout_coarse(layout_i, &S.L)) return e;
+  if (int e = fill_layout_coarse(layout_i, &S.L, fgs_dyn_compact(dyn))) return e;
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
@@ -808,13 +808,13 @@ FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts
                               const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
                               int Z, float voxel_size, const int *layout_i, const float *displace_host,
                               const float *sdf_grid, const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY,
-                              int64_t ksZ, float *X0, float *Zbuf, float *normal_out, fgs_stream_t stream) {
+                              int64_t ksZ, float *X0, float *Zbuf, float *normal_out, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_fine_fwd: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(ray_id && pts && sdf && gradient && viewdirs && xyz_min_host && xyz_max_host && layout_i && sdf_grid &&
                   k0_grid && X0 && Zbuf && normal_out, FGS_E_INVALID, "fgs_feat_fine_fwd: null pointer");
   SurvArgs S;
-  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_dyn_rows(dyn); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
   if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
   hipStream_t st = fgs_s(stream);
@@ -835,7 +835,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
                               int Z, float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
                               const float *Zbuf, const float *dX0, const float *dZ, const float *g_normal,
                               float *sdf_grad_grid, float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ,
-                              float *g_sdf, float *g_gradient, fgs_stream_t stream) {
+                              float *g_sdf, float *g_gradient, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_feat_fine_bwd: M=%lld", (long long)M);
   if (M == 0) return 0;
   // k0_grad_grid == NULL: only the encoding part (g_sdf / g_gradient);  g_sdf == g_gradient == NULL: only the k0 scatter -- the two
@@ -844,9 +844,9 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
                   dZ && (k0_grad_grid || (g_sdf && g_gradient)) && (!g_sdf == !g_gradient), FGS_E_INVALID,
               "fgs_feat_fine_bwd: null pointer");
   SurvArgs S;
-  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
+  S.M = M; S.m_dev = fgs_dyn_rows(dyn); S.ray_id = ray_id; S.pts = pts; S.sdf = sdf; S.gradient = gradient; S.viewdirs = viewdirs;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  if (int e = fill_layout(layout_i, displace_host, &S.L, fgs_dyn_compact(dyn))) return e;
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   if (k0_grad_grid) {
@@ -870,15 +870,15 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
 FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_min_host, const float *xyz_max_host, int X,
                                  int Y, int Z, float voxel_size, const int *layout_i, const float *displace_host,
                                  const float *X0, const float *dX0, const float *tot_sdf, const float *tot_grad,
-                                 float *sdf_grad_grid, fgs_stream_t stream) {
+                                 float *sdf_grad_grid, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_sdf_scatter_surv: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(pts && xyz_min_host && xyz_max_host && layout_i && X0 && dX0 && sdf_grad_grid && (!tot_sdf == !tot_grad),
               FGS_E_INVALID, "fgs_sdf_scatter_surv: null pointer");
   SurvArgs S;
-  S.M = M; S.m_dev = fgs_row_ptr(); S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
+  S.M = M; S.m_dev = fgs_dyn_rows(dyn); S.ray_id = nullptr; S.pts = pts; S.sdf = nullptr; S.gradient = nullptr; S.viewdirs = nullptr;
   S.geom = geom_of(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  if (int e = fill_layout(layout_i, displace_host, &S.L)) return e;
+  if (int e = fill_layout(layout_i, displace_host, &S.L, fgs_dyn_compact(dyn))) return e;
   static const int prio = fgs_env_int("FGS_PRIO_TAPS_BWD", 0);
   hipLaunchKernelGGL(k_feat_taps_bwd, dim3(fgs_blocks((M + TAPS_GROUP - 1) / TAPS_GROUP * 32)), dim3(FGS_BLOCK), 0, fgs_s(stream), S, X0, dX0, tot_sdf,
                      tot_grad, sdf_grad_grid, prio);
@@ -887,14 +887,14 @@ FGS_API int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_m
 }
 
 FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *bias, float *rgb,
-                         fgs_stream_t stream) {
+                         const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && W > 0 && W <= 256 && (W & 3) == 0 && (ldr & 3) == 0, FGS_E_RANGE,
               "fgs_head_fwd: M=%lld W=%d ldr=%lld (W <= 256, multiples of 4)", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
   FGS_REQUIRE(R && V && bias && rgb, FGS_E_INVALID, "fgs_head_fwd: null pointer");
   const int64_t want = (M + 3) / 4;
   const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb, fgs_row_ptr());
+  hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb, fgs_dyn_rows(dyn));
   FGS_LAUNCH_OK("fgs_head_fwd");
   return 0;
 }
@@ -902,7 +902,7 @@ FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const fl
 FGS_API int64_t fgs_head_bwd_scratch_floats(int W) { return (int64_t)1024 * (4 * (int64_t)W + 4); }
 
 FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR,
-                         float *dV, float *dbias, float *dR_colsum, float *scratch, fgs_stream_t stream) {
+                         float *dV, float *dbias, float *dR_colsum, float *scratch, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && W > 0 && W <= 256 && (W & 3) == 0 && (ldr & 3) == 0, FGS_E_RANGE,
               "fgs_head_bwd: M=%lld W=%d ldr=%lld", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
@@ -913,7 +913,7 @@ FGS_API int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const fl
   unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (scratch && blocks > 1024) blocks = 1024;      // fgs_head_bwd_scratch_floats() sizes the scratch for 1024 blocks
   hipLaunchKernelGGL(k_head_bwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, d_out, dR, dV, dbias,
-                     dR_colsum, scratch, fgs_row_ptr());
+                     dR_colsum, scratch, fgs_dyn_rows(dyn));
   FGS_LAUNCH_OK("fgs_head_bwd");
   if (scratch) {
     hipLaunchKernelGGL(k_head_bwd_reduce, dim3((4 * W + 3 + 63) / 64, 8), dim3(FGS_BLOCK), 0, fgs_s(stream), scratch,
@@ -942,12 +942,12 @@ FGS_API int fgs_composite_fwd(int64_t n_rays, const int64_t *surv_off, const flo
 FGS_API int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, const float *rgb, const float *pre_rgb,
                               const float *pre_sig, const float *g_rgb_marched, const float *g_sigmoid_rgb,
                               const float *g_raw_rgb, const float *g_weights_direct, float bg, float *d_out, float *d_w,
-                              fgs_stream_t stream) {
+                              const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_composite_bwd: M=%lld", (long long)M);
   if (M == 0) return 0;
   FGS_REQUIRE(ray_id && weights && rgb && pre_rgb && pre_sig && d_out && d_w, FGS_E_INVALID, "fgs_composite_bwd: null pointer");
   CompositeBwdArgs C;
-  C.M = M; C.m_dev = fgs_row_ptr(); C.ray_id = ray_id; C.weights = weights; C.rgb = rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
+  C.M = M; C.m_dev = fgs_dyn_rows(dyn); C.ray_id = ray_id; C.weights = weights; C.rgb = rgb; C.pre_rgb = pre_rgb; C.pre_sig = pre_sig;
   C.g_rgb_marched = g_rgb_marched; C.g_sigmoid_rgb = g_sigmoid_rgb; C.g_raw_rgb = g_raw_rgb;
   C.g_weights_direct = g_weights_direct; C.bg = bg; C.d_out = d_out; C.d_w = d_w;
   hipLaunchKernelGGL(k_composite_bwd, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, fgs_s(stream), C);

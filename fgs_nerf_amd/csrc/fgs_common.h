@@ -29,12 +29,11 @@ int fgs_set_error(int code, const char *fmt, ...);
 
 static inline hipStream_t fgs_s(fgs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Dynamic row count (fgs_set_row_count_ptr): the device pointer launches are currently issued under, or NULL.
-const int64_t *fgs_row_ptr();
-// Device-side NeuS 1/s (fgs_set_inv_s_ptr): when set, the march kernels read inv_s from there instead of their argument.
-const float *fgs_inv_s_ptr();
-// fgs_set_dx0_compact: the fine-stage backward entries read dX0 in its compact form (see include/fgs_hip.h).
-int fgs_dx0_compact();
+// Device-resident values of a sync-free / captured step, passed EXPLICITLY to the entry points that can read them (fgs_dyn_t,
+// include/fgs_hip.h): the survivor row count, NeuS 1/s, the compact-dX0 operand form.  NULL = host arguments only.
+static inline const int64_t *fgs_dyn_rows(const fgs_dyn_t *d) { return d ? d->row_count : nullptr; }
+static inline const float *fgs_dyn_inv_s(const fgs_dyn_t *d) { return d ? d->inv_s : nullptr; }
+static inline int fgs_dyn_compact(const fgs_dyn_t *d) { return d ? d->dx0_compact : 0; }
 
 constexpr int FGS_WAVE = 64;      // gfx950 wavefront
 constexpr int FGS_BLOCK = 256;    // 4 waves: one per SIMD of a CU

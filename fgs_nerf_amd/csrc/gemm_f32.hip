@@ -557,7 +557,7 @@ FGS_API int64_t fgs_gemm_workspace_bytes(void) { return (int64_t)resident_slots(
 
 FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
                          int64_t ldb, float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm,
-                         float *colsum, void *workspace, int64_t workspace_bytes, fgs_stream_t stream) {
+                         float *colsum, void *workspace, int64_t workspace_bytes, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(op >= 0 && op <= 2, FGS_E_INVALID, "fgs_gemm_f32: op=%d", op);
   FGS_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < ((int64_t)1 << 31) && N < ((int64_t)1 << 31) && K < ((int64_t)1 << 31),
               FGS_E_RANGE, "fgs_gemm_f32: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -578,11 +578,11 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
   hipStream_t st = fgs_s(stream);
   // device-side row count (fgs_set_row_count_ptr): supported by the one-tile-per-workgroup NT / NN form (rows = M); the
   // split-K reduction over the rows (TN) and the stream-K grid take their partition from the host count
-  if (fgs_row_ptr()) {
+  if (fgs_dyn_rows(dyn)) {
     FGS_REQUIRE(op != FGS_GEMM_TN && !workspace, FGS_E_INVALID,
                 "fgs_gemm_f32: TN / stream-K are not available under fgs_set_row_count_ptr (use fgs_mlp_wgrad)");
     FGS_REQUIRE(!colsum, FGS_E_INVALID, "fgs_gemm_f32: colsum is not available under fgs_set_row_count_ptr");
-    g.m_dev = fgs_row_ptr();
+    g.m_dev = fgs_dyn_rows(dyn);
   }
   if (op != FGS_GEMM_TN && workspace) {
     // the caller asked for stream-K (by passing a workspace); used when it can balance: more than a handful of tiles,

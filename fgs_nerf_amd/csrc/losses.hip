@@ -144,13 +144,13 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_bwd(LossArgs L, const float 
 
 int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
          const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
-         const int64_t *ray_id, const float *viewdirs, const float *w5) {
+         const int64_t *ray_id, const float *viewdirs, const float *w5, const fgs_dyn_t *dyn) {
   if (N <= 0 || N >= ((int64_t)1 << 31) || M < 0 || M >= ((int64_t)1 << 31))
     return fgs_set_error(FGS_E_RANGE, "fine loss: N=%lld M=%lld", (long long)N, (long long)M);
   if (!(rgb_marched && sigmoid_rgb && target && alphainv_cum && viewdirs && w5) ||
       (M > 0 && !(weights && normal && raw_rgb && ray_id)))
     return fgs_set_error(FGS_E_INVALID, "fine loss: null pointer");
-  L->N = N; L->M = M; L->m_dev = fgs_row_ptr(); L->rgb_marched = rgb_marched; L->sigmoid_rgb = sigmoid_rgb; L->target = target;
+  L->N = N; L->M = M; L->m_dev = fgs_dyn_rows(dyn); L->rgb_marched = rgb_marched; L->sigmoid_rgb = sigmoid_rgb; L->target = target;
   L->alphainv_cum = alphainv_cum; L->weights = weights; L->normal = normal; L->raw_rgb = raw_rgb; L->ray_id = ray_id;
   L->viewdirs = viewdirs;
   L->w_main = w5[0]; L->w_rgbper = w5[1]; L->w_ent = w5[2]; L->w_ori = w5[3]; L->w_sig = w5[4];
@@ -164,10 +164,10 @@ int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const floa
 FGS_API int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                               const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                               const int64_t *ray_id, const float *viewdirs, const float *weights5_host, float *loss_out,
-                              fgs_stream_t stream) {
+                              const fgs_dyn_t *dyn, fgs_stream_t stream) {
   LossArgs L;
   if (int e = fill(&L, N, M, rgb_marched, sigmoid_rgb, target, alphainv_cum, weights, normal, raw_rgb, ray_id, viewdirs,
-                   weights5_host)) return e;
+                   weights5_host, dyn)) return e;
   FGS_REQUIRE(loss_out, FGS_E_INVALID, "fgs_fine_loss_fwd: null loss_out");
   hipStream_t st = fgs_s(stream);
   hipError_t he = hipMemsetAsync(loss_out, 0, sizeof(float), st);
@@ -184,10 +184,10 @@ FGS_API int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, co
                               const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                               const int64_t *ray_id, const float *viewdirs, const float *weights5_host,
                               const float *grad_out, float *g_rgb_marched, float *g_sigmoid_rgb, float *g_last,
-                              float *g_normal, float *g_raw_rgb, fgs_stream_t stream) {
+                              float *g_normal, float *g_raw_rgb, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   LossArgs L;
   if (int e = fill(&L, N, M, rgb_marched, sigmoid_rgb, target, alphainv_cum, weights, normal, raw_rgb, ray_id, viewdirs,
-                   weights5_host)) return e;
+                   weights5_host, dyn)) return e;
   FGS_REQUIRE(grad_out && g_rgb_marched && g_sigmoid_rgb && g_last && (M == 0 || g_normal), FGS_E_INVALID,
               "fgs_fine_loss_bwd: null pointer");
   hipStream_t st = fgs_s(stream);

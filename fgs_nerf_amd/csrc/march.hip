@@ -322,7 +322,7 @@ FGS_API int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const f
                                const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
                                int mZ, float mask_thres, int max_steps, int *a_step, float *a_alpha, float *a_T,
                                float *a_weight, float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive,
-                               int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream) {
+                               int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_fine_fwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && sdf && a_step && a_alpha && a_T && a_weight &&
@@ -333,7 +333,7 @@ FGS_API int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const f
   MarchArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_dyn_inv_s(dyn); A.thres = thres;
   A.mask_grid = mask_grid;
   A.mask_geom = A.geom;
   A.mask_thres = mask_thres;
@@ -358,7 +358,7 @@ FGS_API int fgs_march_count(const float *rays_o, const float *rays_d, const floa
                             float near, float far, float stepdist, const float *sdf, float dist, float inv_s, float thres,
                             const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
                             int mZ, float mask_thres, int max_steps, int64_t *n_m1, int64_t *n_inbbox,
-                            fgs_stream_t stream) {
+                            const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_count: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && sdf && n_m1 && n_inbbox, FGS_E_INVALID,
@@ -367,7 +367,7 @@ FGS_API int fgs_march_count(const float *rays_o, const float *rays_d, const floa
   MarchArgs A = {};
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.sdf = sdf; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_dyn_inv_s(dyn); A.thres = thres;
   A.mask_grid = mask_grid;
   A.mask_geom = A.geom;
   A.mask_thres = mask_thres;
@@ -387,14 +387,14 @@ FGS_API int fgs_surv_compact(int64_t n_rays, int64_t n_surv_total, const int64_t
                              const float *a_sdf, const float *a_grad, const float *rays_o, const float *rays_d,
                              const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float near, float far,
                              float stepdist, int64_t *ray_id, int64_t *step_id, int *rec_idx, float *weights, float *alpha,
-                             float *sdf, float *gradient, float *pts, fgs_stream_t stream) {
+                             float *sdf, float *gradient, float *pts, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays > 0 && n_surv_total >= 0 && n_surv_total < ((int64_t)1 << 40), FGS_E_RANGE, "fgs_surv_compact: sizes");
   if (n_surv_total == 0) return 0;
   FGS_REQUIRE(surv_off && surv_slot && a_step && a_alpha && a_weight && a_sdf && a_grad && rays_o && rays_d && xyz_min_host &&
                   xyz_max_host && ray_id && step_id && rec_idx && weights && alpha && sdf && gradient && pts,
               FGS_E_INVALID, "fgs_surv_compact: null pointer");
   CompactArgs C;
-  C.n_rays = n_rays; C.n_surv_total = n_surv_total; C.m_dev = fgs_row_ptr(); C.surv_off = surv_off; C.max_steps = max_steps;
+  C.n_rays = n_rays; C.n_surv_total = n_surv_total; C.m_dev = fgs_dyn_rows(dyn); C.surv_off = surv_off; C.max_steps = max_steps;
   C.surv_slot = surv_slot; C.a_step = a_step; C.a_alpha = a_alpha; C.a_weight = a_weight; C.a_sdf = a_sdf; C.a_grad = a_grad;
   C.rays_o = rays_o; C.rays_d = rays_d;
   C.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
@@ -413,7 +413,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
                                const float *a_weight, const float *a_sdf, const float *a_grad, const int64_t *n_alive,
                                const int64_t *surv_off, const float *alphainv_last, const float *g_weights,
                                const float *g_last, const float *g_sdf, const float *g_gradient, float *grad_sdf_grid,
-                               float *tot_sdf, float *tot_grad, fgs_stream_t stream) {
+                               float *tot_sdf, float *tot_grad, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_fine_bwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_surv && a_alpha && a_T && a_weight &&
@@ -422,7 +422,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
   MarchBwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = make_geom(xyz_min_host, xyz_max_host, X, Y, Z, voxel_size);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.max_steps = max_steps;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_dyn_inv_s(dyn); A.max_steps = max_steps;
   A.a_step = a_step; A.a_surv = a_surv; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf;
   A.a_grad = a_grad; A.n_alive = n_alive; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_sdf = g_sdf; A.g_gradient = g_gradient; A.grad_sdf_grid = grad_sdf_grid;

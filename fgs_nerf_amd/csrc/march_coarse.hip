@@ -308,7 +308,7 @@ FGS_API int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const
                                  const uint8_t *inc_world, int iX, int iY, int iZ, const float *inc_scale_host,
                                  const float *inc_shift_host, int max_steps, int *a_step, float *a_alpha, float *a_T,
                                  float *a_weight, float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive,
-                                 int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream) {
+                                 int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_coarse_fwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && sdf_smooth && gradvol && a_step && a_alpha &&
@@ -322,7 +322,7 @@ FGS_API int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const
   A.near = near; A.far = far; A.stepdist = stepdist; A.sdf_smooth = sdf_smooth; A.gradvol = gradvol;
   FGS_REQUIRE((reinterpret_cast<uintptr_t>(vol4) & 15) == 0, FGS_E_INVALID, "fgs_march_coarse_fwd: vol4 must be 16-byte aligned");
   A.vol4 = reinterpret_cast<const float4 *>(vol4);
-  A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.thres = thres;
+  A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_dyn_inv_s(dyn); A.thres = thres;
   A.mask_grid = mask_grid; A.mask_geom = A.geom; A.mask_thres = mask_thres;
   if (mask_grid) {
     FGS_REQUIRE(mask_min_host && mask_max_host && mX > 1 && mY > 1 && mZ > 1, FGS_E_INVALID, "fgs_march_coarse_fwd: bad mask cache");
@@ -349,7 +349,7 @@ FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const
                                  const float *a_alpha, const float *a_T, const float *a_weight, const float *a_sdf,
                                  const float *a_grad, const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off,
                                  const float *alphainv_last, const float *g_weights, const float *g_last,
-                                 const float *g_gradient, float *d_grid4, fgs_stream_t stream) {
+                                 const float *g_gradient, float *d_grid4, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_coarse_bwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_alpha && a_T && a_weight && a_sdf &&
@@ -358,7 +358,7 @@ FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const
   CoarseBwdArgs A;
   A.rays_o = rays_o; A.rays_d = rays_d; A.viewdirs = viewdirs; A.n_rays = n_rays;
   A.geom = geom_make(xyz_min_host, xyz_max_host, X, Y, Z, 0.f);
-  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_inv_s_ptr(); A.max_steps = max_steps;
+  A.near = near; A.far = far; A.stepdist = stepdist; A.dist = dist; A.inv_s = inv_s; A.inv_s_dev = fgs_dyn_inv_s(dyn); A.max_steps = max_steps;
   A.a_step = a_step; A.a_alpha = a_alpha; A.a_T = a_T; A.a_weight = a_weight; A.a_sdf = a_sdf; A.a_grad = a_grad;
   A.n_alive = n_alive; A.n_surv = n_surv; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_gradient = g_gradient;

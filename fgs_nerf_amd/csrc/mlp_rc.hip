@@ -556,7 +556,7 @@ FGS_API int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc
 }
 
 FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0,
-                             int64_t ld_in0, int in0_cols, float *image_ws, int64_t image_ws_floats, fgs_stream_t stream) {
+                             int64_t ld_in0, int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_layers >= 1 && n_layers <= RC_MAXL, FGS_E_RANGE,
               "fgs_mlp_rc_chain: M=%lld n_layers=%d (1..%d)", (long long)M, n_layers, RC_MAXL);
   if (M == 0) return 0;
@@ -569,7 +569,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
               (long long)image_ws_floats, (long long)need);
   RcArgs a;
   PackArgs p;
-  a.M = M; a.m_dev = fgs_row_ptr(); a.n_layers = n_layers; a.img = image_ws; a.stamps = g_rc_stamps;
+  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.n_layers = n_layers; a.img = image_ws; a.stamps = g_rc_stamps;
   p.n_layers = n_layers; p.transpose = backward ? 1 : 0; p.img = image_ws;
   int carried = in0_cols;            // columns of the input carried in registers
   int64_t base = 0, f4 = 0;

@@ -365,13 +365,13 @@ FGS_API int fgs_mlp_wgrad_debug_stamps(unsigned long long *stamps) {
   return 0;
 }
 
-FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, fgs_stream_t stream) {
+FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_items >= 1 && n_items <= WG_MAXBLK, FGS_E_RANGE,
               "fgs_mlp_wgrad: M=%lld n_items=%d (1..%d)", (long long)M, n_items, WG_MAXBLK);
   if (M == 0) return 0;
   FGS_REQUIRE(items, FGS_E_INVALID, "fgs_mlp_wgrad: null pointer");
   WgArgs a;
-  a.M = M; a.m_dev = fgs_row_ptr(); a.stamps = g_wg_stamps;
+  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.stamps = g_wg_stamps;
   int nb = 0, cost_total = 0;
   int cost[WG_MAXBLK];
   for (int i = 0; i < n_items; ++i) {

@@ -94,13 +94,14 @@ class GradAverager:
         self.last_hint_wait_us = 0.0      # host time spent waiting for the hinted brick count (diagnostics)
 
     # ------------------------------------------------------------------------------------------------ early occupancy
-    def hint_touched(self, param: torch.nn.Parameter, pts: torch.Tensor, xyz_min, xyz_max) -> None:
+    def hint_touched(self, param: torch.nn.Parameter, pts: torch.Tensor, xyz_min, xyz_max, count_ptr=None) -> None:
         """Tell the averager, right after the forward, which sample points the backward of the DenseGrid `param` will
         scatter into (`pts` [M,3], the survivor list).  The brick occupancy (a superset of the non-zero bricks), its union
         over ranks and the compacted brick list are then produced on a side stream while the MLP forward/backward runs,
         and `average()` sizes the exchange from a count that is already on the host: no blocking nonzero(), no pass over
         the 197 MB gradient.  Only valid when every gradient of `param` in this step comes from trilinear lookups at
-        `pts`; without a hint the occupancy is read from the gradient itself."""
+        `pts`; without a hint the occupancy is read from the gradient itself.  `count_ptr`: device address of the survivor count
+        when `pts` has CAPACITY rows (the result dict's 'survivor_count_ptr' of a sync-free forward)."""
         if (self.world_size == 1 and not self.force) or not (pts.is_cuda and param.dim() == 5):
             return
         _, C, X, Y, Z = param.shape
@@ -113,7 +114,7 @@ class GradAverager:
         if self.dense_sources.get(id(param), False):
             return        # something else (a TV loss on this grid) adds a dense gradient: occupancy comes from the gradient
         import ctypes
-        from ._lib import call, ptr, stream
+        from ._lib import call, dyn, ptr, stream
         total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
         h = self._hints.get(id(param))
         if h is None or h['total'] != total:
@@ -139,7 +140,7 @@ class GradAverager:
             h['stream'].wait_event(ready)
             sc = self._static.get(id(param))
             h['flags'].zero_()
-            call("fgs_brick_flags_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(h['flags']), stream())
+            call("fgs_brick_flags_pts", ptr(pts), pts.shape[0], lo, hi, X, Y, Z, ptr(h['flags']), dyn(row_count=count_ptr), stream())
             if sc is not None and sc['guard_flags'] is not None:
                 h['flags'][total:].copy_(sc['guard_flags'][1:2])                               # this rank's skip flag rides along
             dist.all_reduce(h['flags'], op=dist.ReduceOp.MAX, group=self.group)               # union over ranks

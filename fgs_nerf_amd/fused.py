@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import fused_ops as fo
-from ._lib import call, ptr, stream
+from ._lib import call, dyn, ptr, stream
 from .ops import grid_strides
 
 F32, I64, I32 = torch.float32, torch.int64, torch.int32
@@ -124,46 +124,16 @@ class _Run:
     """Everything one forward produced that the backward needs (plain attribute bag)."""
 
 
-class _DeviceScalars:
-    """Sync-free mode: while active on this host thread, the kernels behind the C ABI take the survivor
-    count from device memory (fgs_set_row_count_ptr: the host value is the capacity of the buffers) and the NeuS 1/s from a
-    device float (fgs_set_inv_s_ptr).  No-op when both are None."""
-
-    def __init__(self, count=None, inv_s=None):
-        self.count, self.inv_s = count, inv_s
-
-    def __enter__(self):
-        if self.count is not None:
-            call("fgs_set_row_count_ptr", self.count)
-        if self.inv_s is not None:
-            call("fgs_set_inv_s_ptr", self.inv_s)
-        return self
-
-    def __exit__(self, *exc):
-        if self.count is not None:
-            call("fgs_set_row_count_ptr", None)
-        if self.inv_s is not None:
-            call("fgs_set_inv_s_ptr", None)
-        return False
+def _rows(run):
+    """Device address of the survivor count of a sync-free run (fgs_dyn_t.row_count), or None: the per-survivor entry points then
+    take their host row count as the CAPACITY of the buffers and read the actual count from the device."""
+    return run.count_ptr if run.sync_free else None
 
 
-class _HostRows:
-    """Launches on PARAMETER-sized operands (the pre-multiplied weight of _MLP_COLLAPSE and its gradient products) issued from
-    inside a sync-free forward / backward pass: their row counts are host numbers, whatever device-side survivor count the
-    surrounding code runs under (fgs_set_row_count_ptr is per host thread)."""
-
-    def __init__(self, run):
-        self.ptr = run.count_ptr if run.sync_free else None
-
-    def __enter__(self):
-        if self.ptr is not None:
-            call("fgs_set_row_count_ptr", None)
-        return self
-
-    def __exit__(self, *exc):
-        if self.ptr is not None:
-            call("fgs_set_row_count_ptr", self.ptr)
-        return False
+def _inv_s(run):
+    """Device address of NeuS 1/s of a sync-free run whose schedule lives on the device (a captured step), or None."""
+    sf = run.sync_free
+    return ptr(sf['inv_s_dev']) if (sf and sf.get('inv_s_dev') is not None) else None
 
 
 def set_sync_free(model, capacity=None, inv_s_dev=None) -> None:
@@ -405,21 +375,21 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     flop_chain = 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
     if collapse:
         flop_chain -= 2.0 * M * rw * rw
-    fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain)
+    fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain, rows_dev=_rows(run))
     # narrow products: the reflection-encoding columns of dZ (dY_ref[0] . V0[:, rw:]) and dX0 (dY_rgb[0] . W0).  (As one-layer
     # register-resident chains of 4 row tiles they measured 63 us each against 47 for the tiled GEMM: with 64 MFMAs per chunk
     # the chain's per-chunk barrier / DMA and its uncoalesced input load dominate.)
     z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
-    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw))
+    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw), rows_dev=_rows(run))
     if S.get('W0c') is not None:
-        # dX0 in compact form (fgs_set_dx0_compact): only the columns somebody differentiates through
+        # dX0 in compact form (fgs_dyn_t.dx0_compact): only the columns somebody differentiates through
         W0c = S['W0c']
         dX0 = torch.empty(M, W0c.shape[1], dtype=F32, device=dev)
-        _gemm(fo.GEMM_NN, dY_rgb[0], W0c, dX0, M, W0c.shape[1], rw, logical=(M, run.dx0_cols[2], rw))
+        _gemm(fo.GEMM_NN, dY_rgb[0], W0c, dX0, M, W0c.shape[1], rw, logical=(M, run.dx0_cols[2], rw), rows_dev=_rows(run))
         run.dx0_compact = True
     else:
         dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-        _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw))
+        _gemm(fo.GEMM_NN, dY_rgb[0], S['W0p'], dX0, M, ldx0, rw, logical=(M, x_cols, rw), rows_dev=_rows(run))
         run.dx0_compact = False
     # all weight / bias gradients (the bias gradient of the top refnet layer came out of the head kernel)
     items = []
@@ -443,12 +413,11 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         def post():
             # (on the stream of the weight-gradient launch, right behind it: three 256^3 products and three small vector ops)
             tmp = torch.empty(fw, rw, dtype=F32, device=dev)
-            with _HostRows(run):
-                fo.gemm(fo.GEMM_TN, V0a, dWc, gw_rgb[n_rgb - 1], rw, rw, fw)                 # dW3 = V0a^T dWc
-                fo.gemm(fo.GEMM_NT, dWc, W3.detach(), tmp, fw, rw, rw)                        # dWc W3^T
+            fo.gemm(fo.GEMM_TN, V0a, dWc, gw_rgb[n_rgb - 1], rw, rw, fw)                     # dW3 = V0a^T dWc
+            fo.gemm(fo.GEMM_NT, dWc, W3.detach(), tmp, fw, rw, rw)                            # dWc W3^T
             gw_ref[0][:, :rw].copy_(torch.addcmul(tmp, dbc[:, None], b3.detach()[None, :]))   # dV0a = dWc W3^T + dbc b3^T
             gb_rgb[n_rgb - 1].copy_((V0a * dbc[:, None]).sum(0))                              # db3 = V0a^T dbc
-    return dZ, dX0, lambda fork: _wgrad(dev, M, items, flop, fork, post)
+    return dZ, dX0, lambda fork: _wgrad(dev, M, items, flop, fork, post, rows_dev=_rows(run))
 
 
 # The weight-gradient launch (k_mlp_wgrad: 57 + 256 registers per lane, one 256-thread workgroup per CU, 132 KB of LDS, matrix
@@ -479,9 +448,9 @@ _MLP_COLLAPSE = os.environ.get("FGS_MLP_COLLAPSE", "0") == "1"
 _SIDE_PENDING = set()
 
 
-def _wgrad(dev, M, items, flop, fork: bool, post=None) -> None:
+def _wgrad(dev, M, items, flop, fork: bool, post=None, rows_dev=None) -> None:
     if not (fork and _WGRAD_FORK):
-        fo.mlp_wgrad(M, items, flop=flop)
+        fo.mlp_wgrad(M, items, flop=flop, rows_dev=rows_dev)
         if post is not None:
             post()
         return
@@ -490,7 +459,7 @@ def _wgrad(dev, M, items, flop, fork: bool, post=None) -> None:
     ready.record()                      # dY tensors, layer inputs and the zero-filled gradient buffer exist from here on
     with torch.cuda.stream(side):
         side.wait_event(ready)
-        fo.mlp_wgrad(M, items, flop=flop)
+        fo.mlp_wgrad(M, items, flop=flop, rows_dev=rows_dev)
         if post is not None:
             post()                      # (_MLP_COLLAPSE: the original parameters' gradients from the collapsed layer's)
     keep.append(items)                  # (allocated on the main stream: alive until the join)
@@ -637,7 +606,7 @@ def _take_grid_grad(cache, k0_grid):
     return gb['buf'].detach(), gb
 
 
-def _publish_touched(gb, k0_grid, grad_k0, pts, M, g, st, exchange: bool):
+def _publish_touched(gb, k0_grid, grad_k0, pts, M, g, st, exchange: bool, rows_dev=None):
     """Record which bricks `grad_k0` can be non-zero in and attach the record to the parameter for MaskedAdam
     (adam.MaskedAdam._bricks).  `exchange`: a gradient exchange follows (dist.GradAverager): the union over ranks then
     replaces the local occupancy, or invalidates the record if the exchange goes dense."""
@@ -645,7 +614,7 @@ def _publish_touched(gb, k0_grid, grad_k0, pts, M, g, st, exchange: bool):
         k0_grid._fgs_touched = None
         return
     C, X, Y, Z = gb['dims']
-    call("fgs_brick_masks_pts", ptr(pts), M, g.lo_c, g.hi_c, X, Y, Z, ptr(gb['flags']), st)
+    call("fgs_brick_masks_pts", ptr(pts), M, g.lo_c, g.hi_c, X, Y, Z, ptr(gb['flags']), dyn(row_count=rows_dev), st)
     k0_grid._fgs_touched = dict(state=gb, grad_ptr=grad_k0.data_ptr(), version=gb['buf']._version, dims=gb['dims'],
                                 flags=gb['flags'], idx=None, n=None, valid=True, exchange=exchange)
 
@@ -695,14 +664,12 @@ class _FusedFine(torch.autograd.Function):
         _own_workspace(run, any(ctx.needs_input_grad))
         # 1. march (alphainv_last is an output of this call: a fresh tensor per step, the other records live in `ws`)
         alphainv_last = torch.empty(N, dtype=F32, device=dev)
-        if run.sync_free and run.sync_free.get('inv_s_dev') is not None:
-            call("fgs_set_inv_s_ptr", ptr(run.sync_free['inv_s_dev']))    # reset by forward_fine()
         call("fgs_march_fine_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, ptr(sdf_grid), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
              g.mask[3] if g.mask else 0.0, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']),
              ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']), ptr(ws['n_alive']),
-             ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
+             ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), dyn(inv_s=_inv_s(run)), st)
         sf = run.sync_free
         if sf:      # sync-free: offsets cut at the capacity and the overflow flags set by the scan launch itself
             call("fgs_exclusive_scan_guard_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), sf['capacity'], ptr(sf['flags']),
@@ -737,8 +704,7 @@ class _FusedFine(torch.autograd.Function):
         if sf:
             # sync-free: the count stays on the device (last entry of the survivor offsets); M is the CAPACITY from here on
             M = sf['capacity']
-            run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
-            call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_fine() when this forward returns
+            run.count_ptr = ws['surv_off'].data_ptr() + 8 * N     # (handed to every per-survivor launch: fgs_dyn_t.row_count)
         else:
             M = _count_end(token)                  # the one host read of the step
         run.M = M
@@ -754,7 +720,7 @@ class _FusedFine(torch.autograd.Function):
         call("fgs_surv_compact", N, M, ptr(ws['surv_off']), ms, ptr(ws['surv_slot']), ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(run.rays_o), ptr(run.rays_d), g.lo_c, g.hi_c,
              g.X, g.Y, g.Z, run.near, 1e9, run.stepdist, ptr(ray_id), ptr(step_id), ptr(rec_idx), ptr(weights), ptr(alpha),
-             ptr(sdf), ptr(gradient), ptr(pts), st)
+             ptr(sdf), ptr(gradient), ptr(pts), dyn(row_count=_rows(run)), st)
         # 3. features
         ldx0, ldz = run.ldx0, run.ldz
         X0 = torch.empty(M, ldx0, dtype=F32, device=dev)
@@ -763,7 +729,7 @@ class _FusedFine(torch.autograd.Function):
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         call("fgs_feat_fine_fwd", M, ptr(ray_id), ptr(pts), ptr(sdf), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c,
              g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
-             ptr(X0), ptr(Z), ptr(normal), st)
+             ptr(X0), ptr(Z), ptr(normal), dyn(row_count=_rows(run)), st)
         # 4. MLPs
         use_rc = _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and M > 0
         one_launch = (not use_rc and _MLP_FWD_ONE_LAUNCH and rw == 256 and fw == 256 and ldx0 <= 128 and 0 < ldz - rw <= 64 and
@@ -784,8 +750,7 @@ class _FusedFine(torch.autograd.Function):
             if collapse:
                 # Wc_full = [V0a W3 | V0b] (K-padded like V0p), bias_c = V0a b3 + c0: two small launches per step
                 Wc_full = V0p.clone()
-                with _HostRows(run):
-                    fo.gemm(fo.GEMM_NN, V0p[:, :rw], rgb_w[-1].detach(), Wc_full[:, :rw], fw, rw, rw)
+                fo.gemm(fo.GEMM_NN, V0p[:, :rw], rgb_w[-1].detach(), Wc_full[:, :rw], fw, rw, rw)
                 bias_c = (V0p[:, :rw] * rgb_b[-1].detach()).sum(1) + ref_b[0].detach()
             for i in range(n_rgb - 1 if collapse else n_rgb):   # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
                 last = i == n_rgb - 1
@@ -802,7 +767,7 @@ class _FusedFine(torch.autograd.Function):
             flop_fwd = 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
             if collapse:
                 flop_fwd -= 2.0 * M * rw * rgb_w[-1].shape[1]
-            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd)
+            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run))
         elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
@@ -834,7 +799,8 @@ class _FusedFine(torch.autograd.Function):
         a = acts_ref[n_ref - 1]
         grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
-        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
+        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb),
+             dyn(row_count=_rows(run)), st)
         # 5. compositing
         rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
         sigmoid_rgb = torch.empty(N, 3, dtype=F32, device=dev)
@@ -912,11 +878,7 @@ class _FusedFine(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        run = ctx.run
-        sf = run.sync_free
-        inv = ptr(sf['inv_s_dev']) if (sf and sf.get('inv_s_dev') is not None) else None
-        with _DeviceScalars(count=run.count_ptr if sf else None, inv_s=inv):    # (the autograd thread has its own setting)
-            return _FusedFine._backward_impl(ctx, *grads)
+        return _FusedFine._backward_impl(ctx, *grads)
 
     @staticmethod
     def _backward_impl(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
@@ -948,7 +910,8 @@ class _FusedFine(torch.autograd.Function):
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
         call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
-             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
+             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
+             dyn(row_count=_rows(run)), st)
         _seam(run, 'composite', d_out=d_out, d_w=d_w)
 
         # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised): one zero fill for all of
@@ -968,7 +931,7 @@ class _FusedFine(torch.autograd.Function):
         dY = torch.empty(M, fw, dtype=F32, device=dev)
         gw_last, gb_last, gb_prev = view(i_gw_ref + n_ref - 1), view(i_gb_ref + n_ref - 1), view(i_gb_ref + n_ref - 2)
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw_last),
-             ptr(gb_last), ptr(gb_prev), ptr(_head_scratch(fw, dev)), st)
+             ptr(gb_last), ptr(gb_prev), ptr(_head_scratch(fw, dev)), dyn(row_count=_rows(run)), st)
         _seam(run, 'head', dY=dY)
         views = [view(i) for i in range(len(items))]
         gw_rgb, gw_ref = views[:n_rgb], views[n_rgb:n_rgb + n_ref]
@@ -1041,26 +1004,18 @@ class _FusedFine(torch.autograd.Function):
         compact = bool(getattr(run, 'dx0_compact', False))
 
         def feat_bwd(k0_part: bool, enc_part: bool):
-            if compact:
-                call("fgs_set_dx0_compact", 1)
-            try:
-                _feat_bwd(k0_part, enc_part)
-            finally:
-                if compact:
-                    call("fgs_set_dx0_compact", 0)
-
-        def _feat_bwd(k0_part: bool, enc_part: bool):
             call("fgs_feat_fine_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['sdf']), ptr(S['gradient']), ptr(run.viewdirs),
                  g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(S['X0']), ptr(S['Z']), ptr(dX0),
                  ptr(dZ), ptr(g_normal), ptr(grad_sdf), ptr(grad_k0) if k0_part else None, ksC, ksX, ksY, ksZ,
-                 ptr(g_sdf_s) if enc_part else None, ptr(g_grad_s) if enc_part else None, st)
+                 ptr(g_sdf_s) if enc_part else None, ptr(g_grad_s) if enc_part else None,
+                 dyn(row_count=_rows(run), compact=compact), st)
 
         def march_bwd():
             call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
                  g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
                  ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
                  ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
-                 ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), st)
+                 ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), dyn(inv_s=_inv_s(run)), st)
 
         if march_first:
             feat_bwd(False, True)
@@ -1071,7 +1026,7 @@ class _FusedFine(torch.autograd.Function):
         else:
             feat_bwd(True, True)
         _seam(run, 'features', g_sdf_s=g_sdf_s, g_grad_s=g_grad_s, grad_k0=grad_k0)
-        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
+        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None, rows_dev=_rows(run))
         if hook is not None:
             # the exchanges, in the order EVERY path of every rank issues them (k0, mlp, join: _backward_empty too): k0's is
             # the long one (tens of MB at 8 ranks) and starts first, under the weight-gradient launch and the sdf scatter
@@ -1085,14 +1040,9 @@ class _FusedFine(torch.autograd.Function):
             march_bwd()
         _seam(run, 'march', tot_sdf=tot_sdf, tot_grad=tot_grad)
         # 7. every sdf.grad contribution of the survivors (24 taps + centre + six +/-1 taps), combined on chip
-        if compact:
-            call("fgs_set_dx0_compact", 1)
-        try:
-            call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
-                 run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf), st)
-        finally:
-            if compact:
-                call("fgs_set_dx0_compact", 0)
+        call("fgs_sdf_scatter_surv", M, ptr(S['pts']), g.lo_c, g.hi_c, g.X, g.Y, g.Z, g.voxel_size, run.layout_i,
+             run.displace, ptr(S['X0']), ptr(dX0), ptr(tot_sdf), ptr(tot_grad), ptr(grad_sdf),
+             dyn(row_count=_rows(run), compact=compact), st)
         if hook is None and opt_hook is not None and _K0_ADAM_LATE:
             opt_hook(k0_grid, grad_k0)           # ... as the LAST kernel of this branch (see _K0_ADAM_LATE)
 
@@ -1173,15 +1123,13 @@ class _FusedCoarse(torch.autograd.Function):
         inc = run.inc
         alphainv_last = torch.empty(N, dtype=F32, device=dev)   # an output of the march: a fresh tensor per step
         sf = run.sync_free
-        if sf and sf.get('inv_s_dev') is not None:
-            call("fgs_set_inv_s_ptr", ptr(sf['inv_s_dev']))       # reset by forward_coarse()
         call("fgs_march_coarse_fwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, ptr(sdf_smooth), ptr(gradvol), ptr(getattr(run, 'vol4', None)), run.dist, run.inv_s,
              run.thres, ptr(run.mask_grid), *(g.mask[:2] if use_mc else (None, None)), *(g.mask[2] if use_mc else (0, 0, 0)),
              g.mask[3] if use_mc else 0.0, ptr(inc[0]) if inc else None, *(inc[1] if inc else (0, 0, 0)),
              inc[2] if inc else None, inc[3] if inc else None, ms, ptr(ws['a_step']), ptr(ws['a_alpha']), ptr(ws['a_T']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['a_surv']), ptr(ws['surv_slot']),
-             ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), st)
+             ptr(ws['n_alive']), ptr(ws['n_surv']), ptr(ws['n_inbbox']), ptr(alphainv_last), dyn(inv_s=_inv_s(run)), st)
         if sf:
             call("fgs_exclusive_scan_guard_i64", ptr(ws['n_surv']), N, ptr(ws['surv_off']), sf['capacity'], ptr(sf['flags']),
                  ptr(sf['total']), st)
@@ -1209,7 +1157,6 @@ class _FusedCoarse(torch.autograd.Function):
         if sf:       # sync-free (see _FusedFine.forward): the count stays on the device, M is the CAPACITY from here on
             M = sf['capacity']
             run.count_ptr = ws['surv_off'].data_ptr() + 8 * N
-            call("fgs_set_row_count_ptr", run.count_ptr)       # reset by forward_coarse() when this forward returns
         else:
             M = _count_end(token)                  # the one host read of the step
         run.M = M
@@ -1224,13 +1171,13 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_surv_compact", N, M, ptr(ws['surv_off']), ms, ptr(ws['surv_slot']), ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(run.rays_o), ptr(run.rays_d), g.lo_c, g.hi_c,
              g.X, g.Y, g.Z, run.near, 1e9, run.stepdist, ptr(ray_id), ptr(step_id), ptr(rec_idx), ptr(weights), ptr(alpha),
-             ptr(sdf), ptr(gradient), ptr(pts), st)
+             ptr(sdf), ptr(gradient), ptr(pts), dyn(row_count=_rows(run)), st)
         ldx0 = run.ldx0
         X0 = torch.empty(M, ldx0, dtype=F32, device=dev)
         normal = torch.empty(M, 3, dtype=F32, device=dev)
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
         call("fgs_feat_coarse_fwd", M, ptr(ray_id), ptr(pts), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c, g.X, g.Y,
-             g.Z, run.layout_i, ptr(k0_grid), ksC, ksX, ksY, ksZ, ptr(X0), ptr(normal), st)
+             g.Z, run.layout_i, ptr(k0_grid), ksC, ksX, ksY, ksZ, ptr(X0), ptr(normal), dyn(row_count=_rows(run)), st)
         use_rc = _MLP_IMPL == "rc" and fw % 32 == 0 and fw <= 256 and ldx0 <= 256 and n_ref - 1 <= 8 and M > 0
         grp = _gemm_group("forward chain (" + ("k_mlp_rc: register-resident, all layers in one launch" if use_rc
                                                else "NT: k_gemm<true,true,0>") + ")").__enter__()
@@ -1242,7 +1189,7 @@ class _FusedCoarse(torch.autograd.Function):
             acts += [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]
             fo.rc_chain(False, M, X0, ldx0, [dict(W=ref_w[i].detach(), bias=ref_b[i].detach(), relu=True, mask_bits=relu_bits[i],
                                                    out=acts[i + 1], n_store=fw) for i in range(n_ref - 1)],
-                        flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]))
+                        flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), rows_dev=_rows(run))
             a = acts[-1]
         else:
             for i in range(n_ref - 1):
@@ -1253,7 +1200,8 @@ class _FusedCoarse(torch.autograd.Function):
                 acts.append(out)
         grp.__exit__()
         rgb = torch.empty(M, 3, dtype=F32, device=dev)
-        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb), st)
+        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb),
+             dyn(row_count=_rows(run)), st)
         rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
         sigmoid_rgb = torch.empty(N, 3, dtype=F32, device=dev)
         pre_rgb = torch.empty(N, 3, dtype=F32, device=dev)
@@ -1278,11 +1226,7 @@ class _FusedCoarse(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        run = ctx.run
-        sf = run.sync_free
-        inv = ptr(sf['inv_s_dev']) if (sf and sf.get('inv_s_dev') is not None) else None
-        with _DeviceScalars(count=run.count_ptr if sf else None, inv_s=inv):    # (the autograd thread has its own setting)
-            return _FusedCoarse._backward_impl(ctx, *grads)
+        return _FusedCoarse._backward_impl(ctx, *grads)
 
     @staticmethod
     def _backward_impl(ctx, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal, *_unused):
@@ -1330,12 +1274,13 @@ class _FusedCoarse(torch.autograd.Function):
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
         call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
-             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w), st)
+             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
+             dyn(row_count=_rows(run)), st)
         acts = S['acts']
         a_last = acts[n_ref - 1]
         dY = torch.empty(M, fw, dtype=F32, device=dev)
         call("fgs_head_bwd", ptr(a_last), a_last.stride(0), fw, M, ptr(ref_w[-1]), ptr(d_out), ptr(dY), ptr(gw[-1]),
-             ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), st)
+             ptr(gb[-1]), ptr(gb[n_ref - 2]), ptr(_head_scratch(fw, dev)), dyn(row_count=_rows(run)), st)
         dX0 = None
         wgrad = None
         dx0_compact = False
@@ -1352,18 +1297,19 @@ class _FusedCoarse(torch.autograd.Function):
                 layers.append(dict(W=ref_w[i], mask_bits=bits[i - 1], out=out, n_store=fw))
                 dYs[i - 1] = out
             if layers:
-                fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers))
-            if S.get('V0c') is not None:     # compact dX0 (fgs_set_dx0_compact)
+                fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers), rows_dev=_rows(run))
+            if S.get('V0c') is not None:     # compact dX0 (fgs_dyn_t.dx0_compact)
                 V0c = S['V0c']
                 dX0 = torch.empty(M, V0c.shape[1], dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dYs[0], V0c, dX0, M, V0c.shape[1], fw, logical=(M, run.dx0_cols[2], fw))
+                _gemm(fo.GEMM_NN, dYs[0], V0c, dX0, M, V0c.shape[1], fw, logical=(M, run.dx0_cols[2], fw), rows_dev=_rows(run))
                 dx0_compact = True
             else:
                 dX0 = torch.empty(M, ldx0, dtype=F32, device=dev)
-                _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw))
+                _gemm(fo.GEMM_NN, dYs[0], S['V0p'], dX0, M, ldx0, fw, logical=(M, ref_w[0].shape[1], fw), rows_dev=_rows(run))
             wg_items = [(dYs[i], acts[i], gw[i], None if i == n_ref - 2 else gb[i], fw, ref_w[i].shape[1])
                         for i in range(n_ref - 1)]
-            wgrad = lambda fork: _wgrad(dev, M, wg_items, 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), fork)
+            wgrad = lambda fork: _wgrad(dev, M, wg_items, 2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), fork,
+                                        rows_dev=_rows(run))
         else:
             for i in range(n_ref - 2, -1, -1):
                 a_in = acts[i]
@@ -1391,16 +1337,10 @@ class _FusedCoarse(torch.autograd.Function):
         grad_k0, k0_state = pre_k0 if pre_k0 is not None else _take_grid_grad(run.cache, k0_grid)
         g_grad_s = torch.empty(M, 3, dtype=F32, device=dev)
         ksC, ksX, ksY, ksZ = S['k0_strides']
-        if dx0_compact:
-            call("fgs_set_dx0_compact", 1)
-        try:
-            call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
-                 g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
-                 ptr(g_grad_s), st)
-        finally:
-            if dx0_compact:
-                call("fgs_set_dx0_compact", 0)
-        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None)
+        call("fgs_feat_coarse_bwd", M, ptr(S['ray_id']), ptr(S['pts']), ptr(S['gradient']), ptr(run.viewdirs), g.lo_c,
+             g.hi_c, g.X, g.Y, g.Z, run.layout_i, ptr(S['X0']), ptr(dX0), ptr(g_normal), ptr(grad_k0), ksC, ksX, ksY, ksZ,
+             ptr(g_grad_s), dyn(row_count=_rows(run), compact=dx0_compact), st)
+        _publish_touched(k0_state, k0_grid, grad_k0, S['pts'], M, g, st, exchange=hook is not None, rows_dev=_rows(run))
         if hook is not None:                     # (k0, mlp, join: the order of every path, see _FusedFine)
             hook('k0', [k0_grid], grad_k0)
             _exchange_mlp(dev, wgrad, forked, hook, mlp, flat)
@@ -1411,7 +1351,8 @@ class _FusedCoarse(torch.autograd.Function):
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['n_alive']), ptr(ws['n_surv']),
-             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), st)
+             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), dyn(inv_s=_inv_s(run)),
+             st)
         d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
         d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
         _join_side(dev)
@@ -1587,13 +1528,8 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     if run.sync_free and not (_MLP_IMPL == "rc" and fw_ % 32 == 0 and fw_ <= 256 and run.ldx0 <= 256 and len(fl) - 1 <= 8):
         raise RuntimeError("the sync-free coarse-stage path needs the register-resident MLP kernels (FGS_MLP=rc, refnet width "
                            "a multiple of 32, <= 256)")
-    try:
-        (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
-            run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
-    finally:
-        if run.sync_free:
-            call("fgs_set_row_count_ptr", None)
-            call("fgs_set_inv_s_ptr", None)
+    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
+        run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
     ex = run.extras
     depth = ex['depth']
 
@@ -1653,13 +1589,8 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
             model._fused_taps = taps
         sdf_in = dense.smooth3d(model.sdf.grid, model.smooth_conv.weight, taps[1])
     run.sdf_in = sdf_in.detach()
-    try:
-        (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
-            run, sdf_in, model.k0.grid, *mlp)
-    finally:
-        if run.sync_free:
-            call("fgs_set_row_count_ptr", None)
-            call("fgs_set_inv_s_ptr", None)
+    (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
+        run, sdf_in, model.k0.grid, *mlp)
     ex = run.extras
     depth = ex['depth']
 
@@ -1689,7 +1620,7 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
         call("fgs_march_count", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              g.voxel_size, run.near, 1e9, run.stepdist, ptr(_current_sdf_in()), run.dist, run.inv_s, run.thres,
              ptr(run.mask_grid), *(g.mask[:2] if g.mask else (None, None)), *(g.mask[2] if g.mask else (0, 0, 0)),
-             g.mask[3] if g.mask else 0.0, run.max_steps, ptr(n_m1), ptr(n_in), stream())
+             g.mask[3] if g.mask else 0.0, run.max_steps, ptr(n_m1), ptr(n_in), None, stream())
         # the training loop reads 'mask' after optimizer.step() (nerf_training.py:373-381), i.e. on an updated sdf grid:
         # never let a ray's list be shorter than its alive segment of this forward (valid until the next forward)
         n_m1 = torch.maximum(n_m1, ws['n_alive'])
@@ -1705,7 +1636,7 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
              'survivor_pts': run.saved['pts'],
              # sync-free mode: the per-survivor entries above have CAPACITY rows; the rows that count are the first
-             # *survivor_count_ptr (a device int64), which consumers pass on through fgs_set_row_count_ptr
+             # *survivor_count_ptr (a device int64), which consumers pass on as fgs_dyn_t.row_count
              'survivor_count_ptr': run.count_ptr}
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_masks, 'viewdirs': lambda: run.viewdirs[ray_id]})
 

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import call, lib, ptr, stream
+from ._lib import call, lib, ptr, stream, dyn
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 
@@ -26,17 +26,18 @@ def gemm_workspace(device: torch.device) -> torch.Tensor:
 
 
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, bias=None, relu=False,
-         mask=None, colsum=None, stream_k: bool = False) -> torch.Tensor:
+         mask=None, colsum=None, stream_k: bool = False, rows_dev=None) -> torch.Tensor:
     """C = op(A, B) with the epilogues of include/fgs_hip.h fgs_gemm_f32.  A, B, C, mask are 2-D row-major views
     (stride(1) == 1); leading dimensions are taken from stride(0).  `stream_k` selects the opt-in stream-K grid for
-    NT / NN (measured: no faster than one tile per workgroup at the MLP shapes, see csrc/gemm_f32.hip)."""
+    NT / NN (measured: no faster than one tile per workgroup at the MLP shapes, see csrc/gemm_f32.hip).  `rows_dev`: device address of the
+    actual row count (NT / NN: M is then the capacity of A and C; fgs_dyn_t.row_count)."""
     for t in (A, B, C) + ((mask,) if mask is not None else ()):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError("gemm operands must be 2-D float32 CUDA tensors with unit column stride")
     ws = gemm_workspace(C.device) if (stream_k and op != GEMM_TN) else None
     call("fgs_gemm_f32", op, M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), ptr(bias),
          int(bool(relu)), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(ws),
-         0 if ws is None else ws.numel(), stream())
+         0 if ws is None else ws.numel(), dyn(row_count=rows_dev), stream())
     return C
 
 
@@ -144,7 +145,8 @@ def rc_mask_bits(M: int, device) -> torch.Tensor:
     return torch.empty(((M + 31) // 32 + 4) * 64 * 4, dtype=torch.int32, device=device)
 
 
-def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None) -> None:
+def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None,
+             rows_dev=None) -> None:
     """Register-resident MLP chain (include/fgs_hip.h fgs_mlp_rc_chain).  `layers`: list of dicts with W (the nn.Linear
     weight [n_out, >= n_in], any leading dimension) and optional n_in (default W.shape[1]), bias, relu, mask_bits (int32
     buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext ([M, >= ext_cols] view) / ext_cols."""
@@ -173,10 +175,10 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, f
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
     _timed(label or ("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)"), flop,
            lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),
-                        in0_cols, ptr(ws), ws.numel(), stream()))
+                        in0_cols, ptr(ws), ws.numel(), dyn(row_count=rows_dev), stream()))
 
 
-def mlp_wgrad(M: int, items, flop: float = 0.0) -> None:
+def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:
     """All weight / bias gradients of the MLPs in one launch (include/fgs_hip.h fgs_mlp_wgrad).  `items`: list of
     (dY [M, >= n_out], X [M, >= n_in], dW [n_out, >= n_in] zero-initialised, dbias [n_out] or None, n_out, n_in)."""
     import ctypes
@@ -187,4 +189,5 @@ def mlp_wgrad(M: int, items, flop: float = 0.0) -> None:
         arr[i].dY, arr[i].ld_dy, arr[i].n_out = ptr(dY), dY.stride(0), int(n_out)
         arr[i].X, arr[i].ld_x, arr[i].n_in = ptr(X), X.stride(0), int(n_in)
         arr[i].dW, arr[i].ld_dw, arr[i].dbias = ptr(dW), dW.stride(0), ptr(db)
-    _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), stream()))
+    _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), dyn(row_count=rows_dev),
+                                             stream()))

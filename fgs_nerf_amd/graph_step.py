@@ -5,7 +5,7 @@ this build still read the survivor count back once per step and spent ~2 ms of P
 step's data ever reaches the host:
 
 * the survivor count M_s stays in device memory; result tensors, activations and gradients are allocated once for a fixed
-  CAPACITY of rows and every kernel behind the C ABI clamps to the device-side count (fgs_set_row_count_ptr);
+  CAPACITY of rows and every kernel behind the C ABI clamps to the device-side count (fgs_dyn_t.row_count);
 * the per-iteration scalars -- Adam's step size of every parameter group, NeuS 1/s -- are rows of a table the host fills once
   per stage with the same float arithmetic the per-call entry points use (fgs_adam_step_size; the reference's s_val formula);
   a one-wave kernel copies this iteration's row into device scalars and advances a device counter (fgs_step_scalars_tick);
@@ -186,8 +186,8 @@ class CapturedFineStep:
         if av is not None:
             # the bricks this step's k0 gradient can touch, their union over ranks and the union's brick list -- all on a side
             # stream under the MLP forward / backward, the count never leaving the device (GradAverager.use_device_counts)
-            with fused._DeviceScalars(count=res['survivor_count_ptr']):
-                av.hint_touched(self.model.k0.grid, res['survivor_pts'], self.model.xyz_min, self.model.xyz_max)
+            av.hint_touched(self.model.k0.grid, res['survivor_pts'], self.model.xyz_min, self.model.xyz_max,
+                            count_ptr=res['survivor_count_ptr'])
         self.opt.zero_grad(set_to_none=True)
         # An update issued from inside the backward pass (fused.enable_early_update: k0's Adam pass) belongs to the update: the
         # warm-up pass (update=False) must not apply it, and no record of an earlier pass may make this one skip it.

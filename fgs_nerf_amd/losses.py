@@ -12,7 +12,7 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
-from ._lib import call, ptr, stream
+from ._lib import call, dyn, ptr, stream
 
 
 def render_losses(res, target, cfg, model=None):
@@ -40,12 +40,6 @@ def _w5(cfg):
                                 float(cfg.get('sigmoid_rgb_loss', 0)))
 
 
-def _rows(count_ptr):
-    """Sync-free results carry the device address of their survivor count: their per-survivor arrays have CAPACITY rows."""
-    from .fused import _DeviceScalars
-    return _DeviceScalars(count=count_ptr)
-
-
 class _FineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_marched, sigmoid_rgb, alphainv_cum, normal, raw_rgb, weights, ray_id, ray_viewdirs, target, w5,
@@ -55,8 +49,8 @@ class _FineLoss(torch.autograd.Function):
         args = (rgb_marched.contiguous(), sigmoid_rgb.contiguous(), target.contiguous(), alphainv_cum.contiguous(),
                 weights.contiguous(), normal.contiguous(), raw_rgb.contiguous(), ray_id.contiguous(),
                 ray_viewdirs.contiguous())
-        with _rows(count_ptr):
-            call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), stream())
+        # (sync-free results carry the device address of their survivor count: their per-survivor arrays have CAPACITY rows)
+        call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), dyn(row_count=count_ptr), stream())
         ctx.save_for_backward(*args)
         ctx.w5, ctx.count_ptr = w5, count_ptr
         return loss
@@ -72,9 +66,8 @@ class _FineLoss(torch.autograd.Function):
         g_last = torch.empty(N, dtype=torch.float32, device=dev)
         g_normal = torch.empty(M, 3, dtype=torch.float32, device=dev)
         g_raw = torch.empty(M, 3, dtype=torch.float32, device=dev) if ctx.w5[1] > 0 else None
-        with _rows(ctx.count_ptr):
-            call("fgs_fine_loss_bwd", N, M, *(ptr(a) for a in args), ctx.w5, ptr(grad_out.contiguous()), ptr(g_rm), ptr(g_sr),
-                 ptr(g_last), ptr(g_normal), ptr(g_raw), stream())
+        call("fgs_fine_loss_bwd", N, M, *(ptr(a) for a in args), ctx.w5, ptr(grad_out.contiguous()), ptr(g_rm), ptr(g_sr),
+             ptr(g_last), ptr(g_normal), ptr(g_raw), dyn(row_count=ctx.count_ptr), stream())
         return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None, None
 
 

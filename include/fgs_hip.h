@@ -34,31 +34,39 @@ typedef void *fgs_stream_t;
 /* ABI version: bumped whenever an entry point is added, removed or changes its argument list.  fgs_version() returns the
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
- * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3. */
-#define FGS_ABI_VERSION 3
+ * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
+ * thread-local setters. */
+#define FGS_ABI_VERSION 4
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
 /* Fills name (<=255 chars + NUL), CU count, wavefront size, LDS bytes per CU. */
 int fgs_device_info(int device, char *name, int name_len, int *cu_count, int *wave_size, int64_t *lds_bytes);
 
-/* Dynamic row count (sync-free / graph-capturable steps).  The survivor count M_s of a step lives in
- * device memory (the last entry of the march kernels' survivor offsets).  While a pointer is set (per host thread), every
- * entry point below that takes a per-survivor row count treats the HOST value as the CAPACITY of its buffers -- it sizes
- * the grid for it -- and the kernels read the ACTUAL count min(*count, capacity) from the device: the host never needs the
- * number, so nothing in a step waits for a device->host copy and the whole step can be captured in a hipGraph.
- * NULL (the default) restores plain host counts.  The pointer must stay valid while launches issued under it run. */
-int fgs_set_row_count_ptr(const int64_t *count_dev);
-/* The same for the NeuS sharpness: while set, the march kernels (fgs_march_*) read inv_s = 1 / s_val from this device float
- * instead of their argument (model/nerf.py:514,522: s_val follows the iteration number, which a captured step cannot pass by
- * value).  NULL restores the argument. */
-int fgs_set_inv_s_ptr(const float *inv_s_dev);
-/* Thread-local, like the two above: while on, the fine-stage backward entries (fgs_feat_fine_bwd, fgs_sdf_scatter_surv) read dX0
- * in COMPACT form -- the columns of the xyz and view-direction encodings (functions of the fixed ray inputs: no gradient is
- * needed, model/nerf.py:837-874) are absent, i.e. row = [k0 | sdf | taps | tap differences | gradient], pitch = that width
- * rounded up to 4 -- so that the caller's dX0 product only multiplies the weight columns that matter (52 of 106).  Coarse
- * stages (fgs_feat_coarse_bwd): row = [k0 | reflect_emb | normal] (48 of 90 columns with the shipped coarse config). */
-int fgs_set_dx0_compact(int on);
+/* Device-resident values of a sync-free / graph-capturable step, handed EXPLICITLY to every entry point
+ * that can read them (rounds 1-2 had thread-local setters instead -- fgs_set_row_count_ptr / fgs_set_inv_s_ptr /
+ * fgs_set_dx0_compact: state that changed what every later call did, per host thread; removed in ABI version 4).
+ *   row_count   : the survivor count M_s of a step lives in device memory (the last entry of the march kernels' survivor
+ *                 offsets).  Entry points that take a per-survivor row count M treat the HOST value as the CAPACITY of their
+ *                 buffers -- they size the grid for it -- and the kernels read the ACTUAL count min(*row_count, M) from the
+ *                 device: the host never needs the number, nothing in a step waits for a device->host copy, the whole step can
+ *                 be captured in a hipGraph.  Entry points that cannot honour a device-side count (fgs_gemm_f32's TN and
+ *                 stream-K forms) return FGS_E_INVALID when one is given.
+ *   inv_s       : the march kernels (fgs_march_*) read NeuS inv_s = 1 / s_val from this device float instead of their argument
+ *                 (model/nerf.py:514,522: s_val follows the iteration number, which a captured step cannot pass by value).
+ *   dx0_compact : the backward entries (fgs_feat_fine_bwd, fgs_sdf_scatter_surv, fgs_feat_coarse_bwd) read dX0 in COMPACT form --
+ *                 the columns of the xyz and view-direction encodings (functions of the fixed ray inputs: no gradient is needed,
+ *                 model/nerf.py:837-874) are absent: row = [k0 | sdf | taps | tap differences | gradient], pitch = that width
+ *                 rounded up to 4, so that the caller's dX0 product only multiplies the weight columns that matter (52 of 106);
+ *                 coarse stages: row = [k0 | reflect_emb | normal] (48 of 90 columns with the shipped coarse config).
+ * `dyn` == NULL, or a member NULL / 0: the host arguments alone.  The pointed-to device values must stay valid while the
+ * launches issued with them run. */
+typedef struct fgs_dyn {
+  const int64_t *row_count;
+  const float *inv_s;
+  int dx0_compact;
+} fgs_dyn_t;
+
 /* Device-resident schedule of a captured training step (model/nerf_training.py:389-436, model/adam.py:205-221).  `table` is
  * [n_rows][n_cols] floats the host fills once per stage -- row = iteration, columns = whatever per-iteration scalars the
  * step's kernels read (Adam step sizes from fgs_adam_step_size, inv_s).  fgs_step_scalars_tick copies row
@@ -194,7 +202,7 @@ int fgs_brick_scatter(float *grad, int C, int X, int Y, int Z, const int64_t *id
  * non-zero bricks, known right after the forward): ORs 1 into flags[b]; the caller zeroes flags once per step.
  * xyz_min / xyz_max on the HOST; index mapping identical to fgs_trilerp_*. */
 int fgs_brick_flags_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
-                        int Z, int *flags, fgs_stream_t stream);
+                        int Z, int *flags, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* idx[0 .. *count) = ascending indices of the set flags, entirely on the device (idx holds `total` entries, count is a
  * device int64): the exchange is sized from a count fetched asynchronously, never from a blocking nonzero(). */
 int fgs_brick_compact(const int *flags, int64_t total, int64_t *idx, int64_t *count, fgs_stream_t stream);
@@ -225,12 +233,12 @@ int fgs_brick_count_guard(int64_t *count_dev, int64_t capacity, int *flags, int 
 int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                       const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                       const int64_t *ray_id, const float *viewdirs, const float *weights5_host, float *loss_out,
-                      fgs_stream_t stream);
+                      const fgs_dyn_t *dyn, fgs_stream_t stream);
 int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                       const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                       const int64_t *ray_id, const float *viewdirs, const float *weights5_host, const float *grad_out,
                       float *g_rgb_marched, float *g_sigmoid_rgb, float *g_last, float *g_normal, float *g_raw_rgb,
-                      fgs_stream_t stream);
+                      const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Trilinear grid lookup -- replaces F.grid_sample(grid[1,C,X,Y,Z], ind_norm, 'bilinear',
@@ -333,7 +341,7 @@ typedef struct fgs_rc_layer {
 } fgs_rc_layer_t;
 int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers);
 int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0, int64_t ld_in0,
-                     int in0_cols, float *image_ws, int64_t image_ws_floats, fgs_stream_t stream);
+                     int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* Every weight and bias gradient of the MLPs in ONE launch (csrc/mlp_wgrad.hip): for each item
  *   dW[n_out, n_in] += dY[M, n_out]^T . X[M, n_in]      dbias[n_out] += column sums of dY   (dbias may be NULL)
  * with fp32 atomics (zero-initialise dW / dbias).  The samples are split over the chip, a workgroup holds a 256 x 256 block
@@ -345,7 +353,7 @@ typedef struct fgs_wgrad_item {
   float *dW; int64_t ld_dw;
   float *dbias;
 } fgs_wgrad_item_t;
-int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, fgs_stream_t stream);
+int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* Diagnostics for fgs_mlp_wgrad: while a device buffer of >= 2048 uint64 is set, workgroup w records into stamps[8 w ..]
  * the shader clock at its start [0], after its prologue [2], after its sample loop [3] and after issuing its flush [4], the
  * 100 MHz wall clock at start [1] and end [5], its chunk count [6] and its block index [7].  NULL switches it off. */
@@ -384,7 +392,7 @@ int fgs_debug_pad_cols_old_indexing(const float *src, int rows, int cols, int64_
 int64_t fgs_gemm_workspace_bytes(void);
 int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B, int64_t ldb,
                  float *C, int64_t ldc, const float *bias, int relu, const float *mask, int64_t ldm, float *colsum,
-                 void *workspace, int64_t workspace_bytes, fgs_stream_t stream);
+                 void *workspace, int64_t workspace_bytes, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Fused fine-stage render path -- nerf.forward_fine (model/nerf.py:776-941) as a short kernel chain.
@@ -409,7 +417,7 @@ int fgs_march_fine_fwd(const float *rays_o, const float *rays_d, const float *vi
                        const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY,
                        int mZ, float mask_thres, int max_steps, int *a_step, float *a_alpha, float *a_T, float *a_weight,
                        float *a_sdf, float *a_grad, int *a_surv, int *surv_slot, int64_t *n_alive, int64_t *n_surv,
-                       int64_t *n_inbbox, float *alphainv_last, fgs_stream_t stream);
+                       int64_t *n_inbbox, float *alphainv_last, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Same walk without early termination and without writing records: n_m1[r] = number of samples of ray r with
  * alpha > thres (the length of the reference's first compacted list, model/nerf.py:802-810), n_inbbox[r] = in-bbox
@@ -418,7 +426,7 @@ int fgs_march_count(const float *rays_o, const float *rays_d, const float *viewd
                     const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, float voxel_size, float near,
                     float far, float stepdist, const float *sdf, float dist, float inv_s, float thres,
                     const float *mask_grid, const float *mask_min_host, const float *mask_max_host, int mX, int mY, int mZ,
-                    float mask_thres, int max_steps, int64_t *n_m1, int64_t *n_inbbox, fgs_stream_t stream);
+                    float mask_thres, int max_steps, int64_t *n_m1, int64_t *n_inbbox, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Survivor position t in [0, M_s) -> ray (binary search in surv_off) and the per-survivor arrays of the result
  * dict: ray_id, step_id, weights, raw alpha, sdf, gradient[3], ray_pts[3]; rec_idx = local alive index. */
@@ -427,7 +435,7 @@ int fgs_surv_compact(int64_t n_rays, int64_t n_surv_total, const int64_t *surv_o
                      const float *a_grad, const float *rays_o, const float *rays_d, const float *xyz_min_host,
                      const float *xyz_max_host, int X, int Y, int Z, float near, float far, float stepdist,
                      int64_t *ray_id, int64_t *step_id, int *rec_idx, float *weights, float *alpha, float *sdf,
-                     float *gradient, float *pts, fgs_stream_t stream);
+                     float *gradient, float *pts, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Backward of fgs_march_fine_fwd: alpha2weight backward (render_utils_kernel.cu:653-677) over the alive records,
  * NeuS-alpha backward, plus the per-survivor gradients arriving through the feature path (g_sdf [M_s], g_gradient
@@ -439,7 +447,7 @@ int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const float *vi
                        const float *a_sdf, const float *a_grad, const int64_t *n_alive, const int64_t *surv_off,
                        const float *alphainv_last, const float *g_weights, const float *g_last, const float *g_sdf,
                        const float *g_gradient, float *grad_sdf_grid, float *tot_sdf, float *tot_grad,
-                       fgs_stream_t stream);
+                       const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* tot_sdf [M_s] / tot_grad [M_s,3] (both or neither): when given, the survivors' total gradients w.r.t. their sdf value
  * and sdf gradient vector are written there instead of being scattered, and fgs_sdf_scatter_surv combines them on chip
  * with the hierarchical-tap gradients (8x8x8 LDS brick per survivor, row-wise flush: ~30 atomic line requests per
@@ -447,7 +455,7 @@ int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const float *vi
 int fgs_sdf_scatter_surv(int64_t M, const float *pts, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
                          int Z, float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
                          const float *dX0, const float *tot_sdf, const float *tot_grad, float *sdf_grad_grid,
-                         fgs_stream_t stream);
+                         const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Per-survivor MLP inputs (model/nerf.py:835-883).  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq,
  * use_viewdir, center_sdf, use_grad_norm, K, ldx0, off_ref, ldz}; displace_host = K sorted displacements (K <= 5).
@@ -458,7 +466,7 @@ int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts, const 
                       const float *viewdirs, const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z,
                       float voxel_size, const int *layout_i, const float *displace_host, const float *sdf_grid,
                       const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *X0, float *Zbuf,
-                      float *normal_out, fgs_stream_t stream);
+                      float *normal_out, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* Backward: scatter-adds into sdf_grad_grid and k0_grad_grid, writes g_sdf [M] and g_gradient [M,3] for
  * fgs_march_fine_bwd.  g_normal [M,3] (direct gradient on the `normal` output) may be NULL.  The k0 scatter and the encoding
  * part are independent kernels: k0_grad_grid == NULL issues only the latter, g_sdf == g_gradient == NULL only the former. */
@@ -467,17 +475,17 @@ int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts, const 
                       float voxel_size, const int *layout_i, const float *displace_host, const float *X0,
                       const float *Zbuf, const float *dX0, const float *dZ, const float *g_normal, float *sdf_grad_grid,
                       float *k0_grad_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *g_sdf,
-                      float *g_gradient, fgs_stream_t stream);
+                      float *g_gradient, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Last refnet Linear (W -> 3) + sigmoid (model/nerf.py:884): rgb[m,:] = sigmoid(R[m,:W] . V[3,W]^T + bias). */
 int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *bias, float *rgb,
-                 fgs_stream_t stream);
+                 const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* d_out [M,3] (w.r.t. the pre-sigmoid output) -> dR = (d_out . V) * (R > 0), dV += d_out^T R, dbias += colsum(d_out),
  * dR_colsum[W] += colsum(dR) (the bias gradient of the layer that produced R; may be NULL).
  * `scratch`: fgs_head_bwd_scratch_floats(W) floats (uninitialised) -> per-workgroup partial sums + a second, atomic-free
  * reduction launch; NULL -> the sums go out as float atomics (1024 workgroups on the same 64 cache lines). */
 int fgs_head_bwd(const float *R, int64_t ldr, int W, int64_t M, const float *V, const float *d_out, float *dR, float *dV,
-                 float *dbias, float *dR_colsum, float *scratch, fgs_stream_t stream);
+                 float *dbias, float *dR_colsum, float *scratch, const fgs_dyn_t *dyn, fgs_stream_t stream);
 int64_t fgs_head_bwd_scratch_floats(int W);
 
 /* The three segment_coo sums + background + clamp (model/nerf.py:888-903), optional normal_marched / depth
@@ -489,7 +497,7 @@ int fgs_composite_fwd(int64_t n_rays, const int64_t *surv_off, const float *weig
  * NULL) -> d_out [M,3] (pre-sigmoid head output) and d_w [M]. */
 int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, const float *rgb, const float *pre_rgb,
                       const float *pre_sig, const float *g_rgb_marched, const float *g_sigmoid_rgb, const float *g_raw_rgb,
-                      const float *g_weights_direct, float bg, float *d_out, float *d_w, fgs_stream_t stream);
+                      const float *g_weights_direct, float bg, float *d_out, float *d_w, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Coarse stages (nerf.forward_coarse, model/nerf.py:943-1075) -- SURVEY.md 8a row a6 and BASELINE config 3.
@@ -540,7 +548,7 @@ int fgs_march_coarse_fwd(const float *rays_o, const float *rays_d, const float *
                          const float *inc_scale_host, const float *inc_shift_host, int max_steps, int *a_step,
                          float *a_alpha, float *a_T, float *a_weight, float *a_sdf, float *a_grad, int *a_surv,
                          int *surv_slot, int64_t *n_alive, int64_t *n_surv, int64_t *n_inbbox, float *alphainv_last,
-                         fgs_stream_t stream);
+                         const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* Backward of the second Alphas2Weights + NeuS alpha + the two trilinear lookups: g_weights [M_s], g_last [n_rays]
  * (may be NULL), g_gradient [M_s,3] (gradient reaching the sampled gradient vectors through the features, may be NULL)
  * -> atomically accumulated into d_grid4 [X,Y,Z,4] (not zeroed here): per voxel (d smoothed-sdf, d gradient-volume x,y,z)
@@ -552,20 +560,20 @@ int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const float *
                          const float *a_T, const float *a_weight, const float *a_sdf, const float *a_grad,
                          const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off, const float *alphainv_last,
                          const float *g_weights, const float *g_last, const float *g_gradient, float *d_grid4,
-                         fgs_stream_t stream);
+                         const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Coarse-stage MLP operand rows X0 [M, ldx0] = torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb]) (zero padded),
  * model/nerf.py:992-1009.  layout_i = {k0_dim, n_posfreq, n_viewfreq, n_reffreq, use_viewdir, ldx0}. */
 int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient, const float *viewdirs,
                         const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, const int *layout_i,
                         const float *k0_grid, int64_t ksC, int64_t ksX, int64_t ksY, int64_t ksZ, float *X0,
-                        float *normal_out, fgs_stream_t stream);
+                        float *normal_out, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* dX0 [M, ldx0] (+ optional direct gradient g_normal [M,3]) -> scatter-add into k0_grad_grid, g_gradient [M,3] for
  * fgs_march_coarse_bwd. */
 int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *pts, const float *gradient, const float *viewdirs,
                         const float *xyz_min_host, const float *xyz_max_host, int X, int Y, int Z, const int *layout_i,
                         const float *X0, const float *dX0, const float *g_normal, float *k0_grad_grid, int64_t ksC,
-                        int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient, fgs_stream_t stream);
+                        int64_t ksX, int64_t ksY, int64_t ksZ, float *g_gradient, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Marching cubes on a device-resident field -- replaces the host call mcubes.marching_cubes(u, threshold) of
@@ -617,7 +625,7 @@ int fgs_adam_upd_bricks(float *param, float *grad, float *exp_avg, float *exp_av
  * aligned buffer once); fgs_adam_upd_voxels walks the recorded voxels only, applies the masked update to their C floats,
  * zeroes the consumed gradient and clears the bytes.  C a multiple of 4, <= 64. */
 int fgs_brick_masks_pts(const float *pts, int64_t M, const float *xyz_min_host, const float *xyz_max_host, int X, int Y,
-                        int Z, unsigned char *masks, fgs_stream_t stream);
+                        int Z, unsigned char *masks, const fgs_dyn_t *dyn, fgs_stream_t stream);
 int fgs_adam_upd_voxels(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int C, int X, int Y, int Z,
                         unsigned char *masks, int step, float beta1, float beta2, float lr, float eps,
                         const float *step_size_dev, const int *skip_dev, fgs_stream_t stream);

@@ -68,8 +68,7 @@ def step(batch):
     t1 = time.perf_counter()
     loss = fused_render_losses(res, target, synth.FINE_LOSS, model)
     t2 = time.perf_counter()
-    with fused._DeviceScalars(count=res.get('survivor_count_ptr')):
-        avg.hint_touched(model.k0.grid, res.get('survivor_pts'), model.xyz_min, model.xyz_max)
+    avg.hint_touched(model.k0.grid, res.get('survivor_pts'), model.xyz_min, model.xyz_max, count_ptr=res.get('survivor_count_ptr'))
     opt.zero_grad(set_to_none=True)
     t3 = time.perf_counter()
     loss.backward()

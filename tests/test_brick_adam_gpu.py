@@ -35,7 +35,7 @@ def _flags_for(pts, lo, hi, dims, dev):
     C, X, Y, Z = dims
     flags = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4), dtype=torch.int32, device=dev)
     call("fgs_brick_flags_pts", ptr(pts), pts.shape[0], (ctypes.c_float * 3)(*lo), (ctypes.c_float * 3)(*hi), X, Y, Z,
-         ptr(flags), stream())
+         ptr(flags), None, stream())
     return flags
 
 
@@ -81,7 +81,7 @@ def _masks_for(pts, lo, hi, dims, dev):
     C, X, Y, Z = dims
     masks = torch.zeros(((X + 3) // 4) * ((Y + 3) // 4) * ((Z + 3) // 4) * 64, dtype=torch.uint8, device=dev)
     call("fgs_brick_masks_pts", ptr(pts), pts.shape[0], (ctypes.c_float * 3)(*lo), (ctypes.c_float * 3)(*hi), X, Y, Z,
-         ptr(masks), stream())
+         ptr(masks), None, stream())
     return masks
 
 

@@ -1,7 +1,7 @@
 """GPU tests of the register-resident MLP chains (csrc/mlp_rc.hip, fgs_mlp_rc_chain) against float64 torch: forward
 (bias, ReLU, appended columns, saved activations, ReLU sign bits), backward data gradients (transposed images, masks from
 the forward's bits, narrow and 308-wide outputs), ragged M, padding columns holding NaN, coarse-stage widths, and the
-device-side row count (fgs_set_row_count_ptr)."""
+device-side row count (fgs_dyn_t.row_count)."""
 import pytest
 import torch
 
@@ -25,7 +25,7 @@ def _fine_setup(M, dev, seed=0):
     return X0, Z, Ws, bs, relu
 
 
-def _forward(M, X0, Z, Ws, bs, relu, dev, cap=None):
+def _forward(M, X0, Z, Ws, bs, relu, dev, cap=None, rows_dev=None):
     from fgs_nerf_amd import fused_ops as fo
     cap = cap or M
     outs = [torch.full((cap, 256), float('nan'), device=dev) for _ in Ws]
@@ -37,7 +37,7 @@ def _forward(M, X0, Z, Ws, bs, relu, dev, cap=None):
         if i == 4:
             L.update(ext=Z[:, 256:], ext_cols=52)
         layers.append(L)
-    fo.rc_chain(False, cap, X0, 108, layers)
+    fo.rc_chain(False, cap, X0, 108, layers, rows_dev=rows_dev)
     return outs, bits
 
 
@@ -136,19 +136,14 @@ def test_rc_coarse_widths(dev, width, n_in, M):
 
 
 def test_rc_device_row_count(dev):
-    """fgs_set_row_count_ptr: the host count is only the capacity; rows beyond the device count are never written, rows
+    """fgs_dyn_t.row_count: the host count is only the capacity; rows beyond the device count are never written, rows
     below it are bit-identical to a plain launch with that count."""
-    from fgs_nerf_amd._lib import call
     cap, M = 3000, 1777
     X0, Z, Ws, bs, relu = _fine_setup(cap, dev, seed=5)
     outs_a, _ = _forward(M, X0[:M].contiguous(), Z[:M].clone(), Ws, bs, relu, dev)
     count = torch.tensor([M], dtype=torch.int64, device=dev)
-    call("fgs_set_row_count_ptr", count.data_ptr())
-    try:
-        Zb = Z.clone()
-        outs_b, _ = _forward(M, X0, Zb, Ws, bs, relu, dev, cap=cap)
-    finally:
-        call("fgs_set_row_count_ptr", None)
+    Zb = Z.clone()
+    outs_b, _ = _forward(M, X0, Zb, Ws, bs, relu, dev, cap=cap, rows_dev=count.data_ptr())
     for a, b in zip(outs_a, outs_b):
         assert torch.equal(a[:M, :256], b[:M, :256])
         assert bool(torch.isnan(b[M:, :256]).all())
