@@ -94,8 +94,8 @@ _SIGNATURES = {
     "fgs_smooth3d_fwd": [P, I32, I32, I32, I32, P, P, P],
     "fgs_smooth3d_bwd": [P, I64, I32, I32, I32, I32, P, P, P, P],
     "fgs_smooth_tv_loss": [P, I32, I32, I32, P, P, P, F32, P, P, P],
-    "fgs_sdf_gradvol_fwd": [P, I32, I32, I32, F32, P, P, P, P],
-    "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, P, I32, P],
+    "fgs_sdf_gradvol_fwd": [P, I32, I32, I32, F32, I32, P, P, P, P],
+    "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, I32, P, I32, P],
     "fgs_march_coarse_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, P, P, P, F32, F32, F32,
                              P, P, P, I32, I32, I32, F32, P, I32, I32, I32, P, P, I32,
                              P, P, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -155,6 +155,9 @@ void launch_conv(const float *in, int nx, int ny, int nz, const Conv3 &c, int sh
 // g[0] = (s[x+1] - s[x-1]) / 2 / vs on 1 <= x <= X-2 (zero on the two faces), likewise g[1] along y, g[2] along z
 // vol4 (optional): the voxel-interleaved copy [X][Y][Z][4] = {pack_s[v], g_x[v], g_y[v], g_z[v]} the coarse march samples
 // with ONE 16-byte load per trilinear corner instead of four 4-byte gathers from four arrays (pack_s = the smoothed SDF).
+// MODE 0 = 'interpolate' (model/nerf.py:490-494), MODE 1 = 'raw' (:501-505): g[0] = (s[x+1] - s[x]) / vs on x <= X-2, zero on
+// the last face.
+template <int MODE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_fwd(const float *__restrict__ s, int X, int Y, int Z, float vs,
                                                            float *__restrict__ g, const float *__restrict__ pack_s,
                                                            float4 *__restrict__ vol4) {
@@ -163,17 +166,26 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_fwd(const float *__restri
   if (idx >= N) return;
   const int z = (int)(idx % Z), y = (int)((idx / Z) % Y), x = (int)(idx / ((int64_t)Z * Y));
   const int64_t sx = (int64_t)Y * Z, sy = Z;
-  const float gx = (x >= 1 && x <= X - 2) ? (s[idx + sx] - s[idx - sx]) / 2.f / vs : 0.f;
-  const float gy = (y >= 1 && y <= Y - 2) ? (s[idx + sy] - s[idx - sy]) / 2.f / vs : 0.f;
-  const float gz = (z >= 1 && z <= Z - 2) ? (s[idx + 1] - s[idx - 1]) / 2.f / vs : 0.f;
+  float gx, gy, gz;
+  if (MODE == 0) {
+    gx = (x >= 1 && x <= X - 2) ? (s[idx + sx] - s[idx - sx]) / 2.f / vs : 0.f;
+    gy = (y >= 1 && y <= Y - 2) ? (s[idx + sy] - s[idx - sy]) / 2.f / vs : 0.f;
+    gz = (z >= 1 && z <= Z - 2) ? (s[idx + 1] - s[idx - 1]) / 2.f / vs : 0.f;
+  } else {
+    gx = (x <= X - 2) ? (s[idx + sx] - s[idx]) / vs : 0.f;
+    gy = (y <= Y - 2) ? (s[idx + sy] - s[idx]) / vs : 0.f;
+    gz = (z <= Z - 2) ? (s[idx + 1] - s[idx]) / vs : 0.f;
+  }
   g[idx] = gx;
   g[N + idx] = gy;
   g[2 * N + idx] = gz;
   if (vol4) vol4[idx] = make_float4(pack_s[idx], gx, gy, gz);
 }
 
-// d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v-1 interior] - dg_axis[v+1] * [v+1 interior] ) / 2 / vs
+// d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v-1 interior] - dg_axis[v+1] * [v+1 interior] ) / 2 / vs          (MODE 0)
+// d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v >= 1] - dg_axis[v] * [v <= n-2] ) / vs                            (MODE 1)
 // dg component c of voxel v lives at dg[c * sC + v * sV] ((XYZ, 1) for the dense [3,X,Y,Z] layout)
+template <int MODE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restrict__ dg, int64_t sC, int64_t sV, int X,
                                                            int Y, int Z, float vs, float *__restrict__ d_s, int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,13 +194,23 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restri
   const int z = (int)(idx % Z), y = (int)((idx / Z) % Y), x = (int)(idx / ((int64_t)Z * Y));
   const int64_t sx = (int64_t)Y * Z, sy = Z;
   float acc = 0.f;
-  // s[v] appears as "+" in g at v-1 (needs 1 <= v-1 <= n-2) and as "-" in g at v+1 (needs 1 <= v+1 <= n-2)
-  if (x - 1 >= 1 && x - 1 <= X - 2) acc += dg[(idx - sx) * sV] / 2.f / vs;
-  if (x + 1 >= 1 && x + 1 <= X - 2) acc -= dg[(idx + sx) * sV] / 2.f / vs;
-  if (y - 1 >= 1 && y - 1 <= Y - 2) acc += dg[sC + (idx - sy) * sV] / 2.f / vs;
-  if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= dg[sC + (idx + sy) * sV] / 2.f / vs;
-  if (z - 1 >= 1 && z - 1 <= Z - 2) acc += dg[2 * sC + (idx - 1) * sV] / 2.f / vs;
-  if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= dg[2 * sC + (idx + 1) * sV] / 2.f / vs;
+  if (MODE == 0) {
+    // s[v] appears as "+" in g at v-1 (needs 1 <= v-1 <= n-2) and as "-" in g at v+1 (needs 1 <= v+1 <= n-2)
+    if (x - 1 >= 1 && x - 1 <= X - 2) acc += dg[(idx - sx) * sV] / 2.f / vs;
+    if (x + 1 >= 1 && x + 1 <= X - 2) acc -= dg[(idx + sx) * sV] / 2.f / vs;
+    if (y - 1 >= 1 && y - 1 <= Y - 2) acc += dg[sC + (idx - sy) * sV] / 2.f / vs;
+    if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= dg[sC + (idx + sy) * sV] / 2.f / vs;
+    if (z - 1 >= 1 && z - 1 <= Z - 2) acc += dg[2 * sC + (idx - 1) * sV] / 2.f / vs;
+    if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= dg[2 * sC + (idx + 1) * sV] / 2.f / vs;
+  } else {
+    // s[v] appears as "+" in g at v-1 (needs v-1 <= n-2, i.e. always, and v >= 1) and as "-" in g at v (needs v <= n-2)
+    if (x >= 1) acc += dg[(idx - sx) * sV] / vs;
+    if (x <= X - 2) acc -= dg[idx * sV] / vs;
+    if (y >= 1) acc += dg[sC + (idx - sy) * sV] / vs;
+    if (y <= Y - 2) acc -= dg[sC + idx * sV] / vs;
+    if (z >= 1) acc += dg[2 * sC + (idx - 1) * sV] / vs;
+    if (z <= Z - 2) acc -= dg[2 * sC + idx * sV] / vs;
+  }
   d_s[idx] = accumulate ? d_s[idx] + acc : acc;
 }
 
@@ -234,23 +256,33 @@ FGS_API int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int 
   return 0;
 }
 
-FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, const float *pack_sdf,
-                                float *vol4, fgs_stream_t stream) {
+FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, int mode, float *grad3,
+                                const float *pack_sdf, float *vol4, fgs_stream_t stream) {
   FGS_REQUIRE(X > 0 && Y > 0 && Z > 0 && (int64_t)X * Y * Z < ((int64_t)1 << 38), FGS_E_RANGE, "fgs_sdf_gradvol_fwd: size");
+  FGS_REQUIRE(mode == 0 || mode == 1, FGS_E_INVALID, "fgs_sdf_gradvol_fwd: mode=%d (0 = interpolate, 1 = raw)", mode);
   FGS_REQUIRE(sdf && grad3 && (!vol4 || (pack_sdf && (reinterpret_cast<uintptr_t>(vol4) & 15) == 0)), FGS_E_INVALID,
               "fgs_sdf_gradvol_fwd: null pointer (vol4 needs pack_sdf and 16-byte alignment)");
-  hipLaunchKernelGGL(k_gradvol_fwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), sdf, X, Y, Z,
-                     voxel_size, grad3, pack_sdf, reinterpret_cast<float4 *>(vol4));
+  if (mode == 0)
+    hipLaunchKernelGGL(k_gradvol_fwd<0>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), sdf, X, Y, Z,
+                       voxel_size, grad3, pack_sdf, reinterpret_cast<float4 *>(vol4));
+  else
+    hipLaunchKernelGGL(k_gradvol_fwd<1>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), sdf, X, Y, Z,
+                       voxel_size, grad3, pack_sdf, reinterpret_cast<float4 *>(vol4));
   FGS_LAUNCH_OK("fgs_sdf_gradvol_fwd");
   return 0;
 }
 
 FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
-                                float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream) {
+                                float voxel_size, int mode, float *d_sdf, int accumulate, fgs_stream_t stream) {
   FGS_REQUIRE(X > 0 && Y > 0 && Z > 0 && (int64_t)X * Y * Z < ((int64_t)1 << 38), FGS_E_RANGE, "fgs_sdf_gradvol_bwd: size");
+  FGS_REQUIRE(mode == 0 || mode == 1, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: mode=%d (0 = interpolate, 1 = raw)", mode);
   FGS_REQUIRE(d_grad3 && d_sdf && chan_stride >= 1 && voxel_stride >= 1, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: bad arguments");
-  hipLaunchKernelGGL(k_gradvol_bwd, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
-                     chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_gradvol_bwd<0>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
+                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
+  else
+    hipLaunchKernelGGL(k_gradvol_bwd<1>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
+                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
   FGS_LAUNCH_OK("fgs_sdf_gradvol_bwd");
   return 0;
 }

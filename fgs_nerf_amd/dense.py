@@ -3,7 +3,9 @@
 ``smooth3d(grid, taps)``      = ``nn.Conv3d(1, 1, k, padding=k//2, padding_mode='replicate')(grid)`` with the frozen
                                 Gaussian taps of model/nerf.py:260-272 (the coarse stages smooth the SDF grid on
                                 every forward, :791 / :969).
-``sdf_gradient_volume(g, vs)`` = ``nerf.neus_sdf_gradient(mode='interpolate')`` (model/nerf.py:485-494): [1,3,X,Y,Z].
+``sdf_gradient_volume(g, vs)`` = ``nerf.neus_sdf_gradient(mode)`` (model/nerf.py:485-508): [1,3,X,Y,Z]; 'interpolate' and 'raw'
+                                are one stencil kernel each way, 'grad_conv' three ``smooth3d`` passes with the reference's
+                                Sobel-like taps (:224-247).
 """
 from __future__ import annotations
 
@@ -67,7 +69,7 @@ def smooth3d(grid: torch.Tensor, taps: torch.Tensor, taps_c=None) -> torch.Tenso
 
 class _GradVol(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grid, voxel_size, pack):
+    def forward(ctx, grid, voxel_size, pack, mode=0):
         X, Y, Z = _check_grid(grid)
         g = grid.contiguous()
         out = torch.empty(1, 3, X, Y, Z, dtype=torch.float32, device=g.device)
@@ -78,30 +80,41 @@ class _GradVol(torch.autograd.Function):
             vol4 = torch.empty(X, Y, Z, 4, dtype=torch.float32, device=g.device)
             holder['vol4'] = vol4
             pack_sdf = pack_sdf.detach().contiguous()
-        call("fgs_sdf_gradvol_fwd", ptr(g), X, Y, Z, float(voxel_size), ptr(out), ptr(pack_sdf) if pack is not None else None,
-             ptr(vol4), stream())
-        ctx.meta = (X, Y, Z, float(voxel_size))
+        call("fgs_sdf_gradvol_fwd", ptr(g), X, Y, Z, float(voxel_size), int(mode), ptr(out),
+             ptr(pack_sdf) if pack is not None else None, ptr(vol4), stream())
+        ctx.meta = (X, Y, Z, float(voxel_size), int(mode))
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
-        X, Y, Z, vs = ctx.meta
+        X, Y, Z, vs, mode = ctx.meta
         sv = _voxel_stride(d_out, X, Y, Z)
         if sv is None:
             d_out, sv = d_out.contiguous(), 1
         sc = d_out.stride(1)
         d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
-        call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, ptr(d_in), 0, stream())
-        return d_in, None, None
+        call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, mode, ptr(d_in), 0, stream())
+        return d_in, None, None, None
 
 
-def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, holder=None) -> torch.Tensor:
-    """[1,3,X,Y,Z] central-difference gradient volume (model/nerf.py:485-494).  With `pack_sdf` (the smoothed SDF grid) and a
-    dict `holder`, the same pass also leaves the voxel-interleaved volume {pack_sdf, g_x, g_y, g_z} in holder['vol4'] for
-    the coarse march (a plain by-product: no gradient flows through it)."""
+GRAD_MODES = {'interpolate': 0, 'raw': 1}
+
+
+def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, holder=None, mode: str = 'interpolate',
+                        grad_conv_weight=None) -> torch.Tensor:
+    """[1,3,X,Y,Z] gradient volume of model/nerf.py:485-508.  'interpolate' (central difference, zero faces) and 'raw' (forward
+    difference, zero last face): one stencil pass; with `pack_sdf` (the smoothed SDF grid) and a dict `holder`, the same pass
+    also leaves the voxel-interleaved volume {pack_sdf, g_x, g_y, g_z} in holder['vol4'] for the coarse march (a plain
+    by-product: no gradient flows through it).  'grad_conv': `grad_conv_weight` [3,1,3,3,3] (nerf.init_gradient_conv), one
+    replicate-padded 3^3 convolution per component (smooth3d: forward and exact adjoint); no interleaved copy."""
+    if mode == 'grad_conv':
+        if grad_conv_weight is None:
+            raise RuntimeError("sdf_gradient_volume(mode='grad_conv') needs the grad_conv weight")
+        w = grad_conv_weight.detach()
+        return torch.cat([smooth3d(grid, w[c, 0]) for c in range(3)], dim=1)
     pack = None if pack_sdf is None else (pack_sdf, holder)
-    return _GradVol.apply(grid, float(voxel_size), pack)
+    return _GradVol.apply(grid, float(voxel_size), pack, GRAD_MODES[mode])
 
 
 class _SmoothTV(torch.autograd.Function):

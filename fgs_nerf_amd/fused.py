@@ -1092,7 +1092,7 @@ def supports_coarse(model) -> bool:
     from .nerf import mlp_layers
     if model.stage not in ('coarse', 'geometry_searching') or model.s_learn or not (model.fast_color_thres > 0):
         return False
-    if getattr(model, 'grad_mode', 'interpolate') != 'interpolate':
+    if getattr(model, 'grad_mode', 'interpolate') not in ('interpolate', 'raw', 'grad_conv'):
         return False
     if model.smooth_sdf and int(model.smooth_conv.weight.shape[-1]) > 7:
         return False
@@ -1519,7 +1519,10 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     # (the gradient-volume pass also leaves the voxel-interleaved copy {smoothed sdf, g_x, g_y, g_z} the march samples with
     # one 16-byte load per trilinear corner: FGS_COARSE_VOL4=0 switches it off)
     holder = {}
-    model.gradient = dense.sdf_gradient_volume(model.sdf.grid, g.voxel_size, sdf_smooth if _COARSE_VOL4 else None, holder)
+    gmode = getattr(model, 'grad_mode', 'interpolate')
+    model.gradient = dense.sdf_gradient_volume(model.sdf.grid, g.voxel_size, sdf_smooth if (_COARSE_VOL4 and gmode != 'grad_conv') else None,
+                                               holder, mode=gmode,
+                                               grad_conv_weight=model.grad_conv.weight if gmode == 'grad_conv' else None)
     run.vol4 = holder.get('vol4')
     mlp = []
     for layer in fl:

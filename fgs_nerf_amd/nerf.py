@@ -189,9 +189,10 @@ class nerf(torch.nn.Module):
 
     def _gradient_volume(self):
         g = self.sdf.grid
-        if g.is_cuda and self.grad_mode == 'interpolate' and g.is_contiguous():
+        if g.is_cuda and self.grad_mode in ('interpolate', 'raw', 'grad_conv') and g.is_contiguous():
             from . import dense
-            return dense.sdf_gradient_volume(g, float(self.voxel_size))
+            return dense.sdf_gradient_volume(g, float(self.voxel_size), mode=self.grad_mode,
+                                             grad_conv_weight=self.grad_conv.weight if self.grad_mode == 'grad_conv' else None)
         return self.neus_sdf_gradient()
 
     # ------------------------------------------------------------------ resolution / bookkeeping
@@ -311,12 +312,26 @@ class nerf(torch.nn.Module):
             self.smooth_conv = self._gaussian_3dconv(ksize, sigma)
 
     def init_gradient_conv(self, sigma=0):
-        """model/nerf.py:224-258: only ``tv_smooth_conv`` (3^3 binomial, replicate pad) is used on the path
-        (by density_total_variation); the Sobel ``grad_conv`` belongs to grad_mode='grad_conv', which no config selects."""
+        """model/nerf.py:224-258: ``tv_smooth_conv`` (3^3 binomial, replicate pad; used by density_total_variation) and the
+        Sobel-like ``grad_conv`` of grad_mode='grad_conv' (no shipped config selects it; pinned against the reference's own
+        weights and output in tests/golden/ref_fns.npz)."""
         base = np.asarray([[[1, 2, 1], [2, 4, 2], [1, 2, 1]], [[2, 4, 2], [4, 8, 4], [2, 4, 2]],
                            [[1, 2, 1], [2, 4, 2], [1, 2, 1]]], dtype=np.float64)
         dist = np.fromfunction(lambda i, j, k: (i - 1) ** 2 + (j - 1) ** 2 + (k - 1) ** 2 - 1, (3, 3, 3))
         kernel0 = base * np.exp(-dist * sigma)
+        kernel1 = kernel0 / (kernel0[0].sum() * 2 * float(self.voxel_size))                      # :238
+        weight = torch.from_numpy(np.concatenate([kernel1[None] for _ in range(3)])).float()     # :239-245
+        weight[0, 1, :, :] *= 0
+        weight[0, 0, :, :] *= -1
+        weight[1, :, 1, :] *= 0
+        weight[1, :, 0, :] *= -1
+        weight[2, :, :, 1] *= 0
+        weight[2, :, :, 0] *= -1
+        self.grad_conv = nn.Conv3d(1, 3, (3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1), padding_mode='replicate')
+        self.grad_conv.weight.data = weight.unsqueeze(1).float()
+        self.grad_conv.bias.data = torch.zeros(3)
+        for p in self.grad_conv.parameters():
+            p.requires_grad = False
         self.tv_smooth_conv = nn.Conv3d(1, 1, (3, 3, 3), stride=1, padding=1, padding_mode='replicate')
         self.tv_smooth_conv.weight.data = torch.from_numpy(kernel0 / kernel0.sum()).float()[None, None]
         self.tv_smooth_conv.bias.data = torch.zeros(1)
@@ -324,7 +339,7 @@ class nerf(torch.nn.Module):
             p.requires_grad = False
 
     def neus_sdf_gradient(self, mode=None, sdf=None):
-        """model/nerf.py:485-508, mode 'interpolate' (central difference, zero faces) and 'raw'."""
+        """model/nerf.py:485-508: 'interpolate' (central difference, zero faces), 'raw' (forward difference), 'grad_conv'."""
         sdf = self.sdf.grid if sdf is None else sdf
         mode = self.grad_mode if mode is None else mode
         g = torch.zeros([1, 3, *self.sdf.grid.shape[-3:]], device=sdf.device)
@@ -336,6 +351,11 @@ class nerf(torch.nn.Module):
             g[:, 0, :-1, :, :] = (sdf[:, 0, 1:, :, :] - sdf[:, 0, :-1, :, :]) / self.voxel_size
             g[:, 1, :, :-1, :] = (sdf[:, 0, :, 1:, :] - sdf[:, 0, :, :-1, :]) / self.voxel_size
             g[:, 2, :, :, :-1] = (sdf[:, 0, :, :, 1:] - sdf[:, 0, :, :, :-1]) / self.voxel_size
+        elif mode == 'grad_conv':
+            if sdf.is_cuda and sdf.is_contiguous():
+                from . import dense
+                return dense.sdf_gradient_volume(sdf, float(self.voxel_size), mode='grad_conv', grad_conv_weight=self.grad_conv.weight)
+            return self.grad_conv.to(sdf.device)(sdf)
         else:
             raise NotImplementedError(mode)
         return g

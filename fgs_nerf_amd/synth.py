@@ -133,6 +133,9 @@ def oracle_params(model) -> Dict:
              smooth_kernel=None)
     if model.smooth_sdf:
         P['smooth_kernel'] = cpu(model.smooth_conv.weight)[0, 0]
+    P['grad_mode'] = getattr(model, 'grad_mode', 'interpolate')
+    if P['grad_mode'] == 'grad_conv':
+        P['grad_conv_w'] = cpu(model.grad_conv.weight)
     if model.mask_cache is not None:
         mc = model.mask_cache
         P['mask_cache'] = dict(sdf_mask=cpu(mc.sdf_mask), xyz_min=cpu(mc.xyz_min), xyz_max=cpu(mc.xyz_max),

@@ -507,7 +507,9 @@ int fgs_composite_bwd(int64_t M, const int64_t *ray_id, const float *weights, co
  *   model/nerf.py:260-278 (`smooth_conv`, applied every forward at :969).  taps_host: k^3 floats on the HOST in torch's
  *   weight order; k odd, <= 7.  in/out [X,Y,Z] fp32, must not alias.  The backward is the exact adjoint: the same
  *   LDS-tiled kernel evaluated on the padded domain into `scratch` [(X+k-1)(Y+k-1)(Z+k-1) floats], then folded.
- * fgs_sdf_gradvol_*: neus_sdf_gradient(mode='interpolate') (model/nerf.py:485-494): grad3 [3,X,Y,Z], central
+ * fgs_sdf_gradvol_*: neus_sdf_gradient (model/nerf.py:485-508), mode 0 = 'interpolate' (central difference, zero faces), mode
+ *   1 = 'raw' (forward difference, zero last face); 'grad_conv' is three fgs_smooth3d_* passes with the reference's Sobel-like
+ *   taps (model/nerf.py:224-247), one per component.  grad3 [3,X,Y,Z], central
  *   differences / 2 / voxel_size, zero on the two boundary faces of each axis.  bwd: d_sdf (+)= adjoint(d_grad3). */
 int fgs_smooth3d_fwd(const float *in, int X, int Y, int Z, int k, const float *taps_host, float *out, fgs_stream_t stream);
 /* The two adjoints read their incoming gradient through element strides, so they can consume the voxel-interleaved
@@ -518,10 +520,10 @@ int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int Y, int Z
                      float *scratch, float *d_in, fgs_stream_t stream);
 /* vol4 (optional, with pack_sdf [X,Y,Z]): also writes the voxel-interleaved volume [X,Y,Z,4] = {pack_sdf, g_x, g_y, g_z}
  * that fgs_march_coarse_fwd samples with one 16-byte load per trilinear corner (pack_sdf = the smoothed SDF). */
-int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, float *grad3, const float *pack_sdf,
-                        float *vol4, fgs_stream_t stream);
+int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, int mode, float *grad3,
+                        const float *pack_sdf, float *vol4, fgs_stream_t stream);
 int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
-                        float voxel_size, float *d_sdf, int accumulate, fgs_stream_t stream);
+                        float voxel_size, int mode, float *d_sdf, int accumulate, fgs_stream_t stream);
 
 /* Smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446; the shipped fine config adds it every
  * third iteration) over the gradient volume g3 [3,X,Y,Z], value and gradient in one LDS-tiled pass per channel:

@@ -275,9 +275,40 @@ def grid_sampler_ret_grad(xyz, grid, xyz_min, xyz_max, voxel_size):
     return val, grad, feat
 
 
-def neus_sdf_gradient(sdf: torch.Tensor, voxel_size) -> torch.Tensor:
-    """model/nerf.py:485-494 (mode 'interpolate'): interior central difference, zero faces."""
+def grad_conv_weight(voxel_size, sigma: float = 0) -> torch.Tensor:
+    """model/nerf.py:224-247: the [3,1,3,3,3] weight of `grad_conv` (Sobel-like taps over the 3^3 neighbourhood, sign and zero
+    planes per component, scaled by 1 / (plane sum * 2 * voxel_size))."""
+    kernel = np.asarray([[[1, 2, 1], [2, 4, 2], [1, 2, 1]], [[2, 4, 2], [4, 8, 4], [2, 4, 2]], [[1, 2, 1], [2, 4, 2], [1, 2, 1]]])
+    distance = np.zeros((3, 3, 3))
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                distance[i, j, k] = ((i - 1) ** 2 + (j - 1) ** 2 + (k - 1) ** 2 - 1)
+    kernel0 = kernel * np.exp(-distance * sigma)
+    kernel1 = kernel0 / (kernel0[0].sum() * 2 * float(voxel_size))
+    weight = torch.from_numpy(np.concatenate([kernel1[None] for _ in range(3)])).float()
+    weight[0, 1, :, :] *= 0
+    weight[0, 0, :, :] *= -1
+    weight[1, :, 1, :] *= 0
+    weight[1, :, 0, :] *= -1
+    weight[2, :, :, 1] *= 0
+    weight[2, :, :, 0] *= -1
+    return weight.unsqueeze(1).float()
+
+
+def neus_sdf_gradient(sdf: torch.Tensor, voxel_size, mode: str = 'interpolate', conv_weight=None) -> torch.Tensor:
+    """model/nerf.py:485-508: 'interpolate' (interior central difference, zero faces), 'raw' (forward difference, zero last
+    face), 'grad_conv' (Conv3d(1, 3, 3, padding=1, padding_mode='replicate') with `grad_conv_weight`, zero bias)."""
+    if mode == 'grad_conv':
+        w = (conv_weight if conv_weight is not None else grad_conv_weight(voxel_size)).to(sdf.dtype)
+        return F.conv3d(F.pad(sdf, (1,) * 6, mode='replicate'), w, bias=torch.zeros(3, dtype=sdf.dtype))
     g = torch.zeros([1, 3, *sdf.shape[-3:]], dtype=sdf.dtype)
+    if mode == 'raw':
+        g[:, 0, :-1, :, :] = (sdf[:, 0, 1:, :, :] - sdf[:, 0, :-1, :, :]) / voxel_size
+        g[:, 1, :, :-1, :] = (sdf[:, 0, :, 1:, :] - sdf[:, 0, :, :-1, :]) / voxel_size
+        g[:, 2, :, :, :-1] = (sdf[:, 0, :, :, 1:] - sdf[:, 0, :, :, :-1]) / voxel_size
+        return g
+    assert mode == 'interpolate', mode
     g[:, 0, 1:-1, :, :] = (sdf[:, 0, 2:, :, :] - sdf[:, 0, :-2, :, :]) / 2 / voxel_size
     g[:, 1, :, 1:-1, :] = (sdf[:, 0, :, 2:, :] - sdf[:, 0, :, :-2, :]) / 2 / voxel_size
     g[:, 2, :, :, 1:-1] = (sdf[:, 0, :, :, 2:] - sdf[:, 0, :, :, :-2]) / 2 / voxel_size
@@ -711,7 +742,7 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
         ray_pts, ray_id, viewdirs_pts, step_id = ray_pts[m], ray_id[m], viewdirs_pts[m], step_id[m]
     sdf_grid = smooth_conv(P['sdf'], P['smooth_kernel']) if P.get('smooth_kernel') is not None else P['sdf']
     sdf = dense_grid_forward(sdf_grid, ray_pts, xyz_min, xyz_max)
-    grad_vol = neus_sdf_gradient(P['sdf'], voxel_size)
+    grad_vol = neus_sdf_gradient(P['sdf'], voxel_size, P.get('grad_mode', 'interpolate'), P.get('grad_conv_w'))   # nerf.py:972
     gradient = dense_grid_forward(grad_vol, ray_pts, xyz_min, xyz_max)
     dist = stepsize * voxel_size
     s_val = s_val_schedule(global_step, P['s_ratio'], P['s_start'])

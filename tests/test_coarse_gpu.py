@@ -94,6 +94,8 @@ def test_fused_coarse_is_selected_and_matches_golden(dev, golden):
     (48, 512, "coarse", {}),
     (40, 300, "coarse", {"mask_cache": True, "inc_mask": True}),
     (32, 257, "geometry_searching", {"render": True, "tv": True}),
+    (32, 300, "coarse", {"grad_mode": "raw"}),            # the reference's non-default gradient volumes (model/nerf.py:495-506)
+    (32, 300, "coarse", {"grad_mode": "grad_conv"}),
 ])
 def test_fused_coarse_vs_oracle_and_composed(dev, oracle, G, N, stage, extra):
     from fgs_nerf_amd import synth
@@ -105,8 +107,12 @@ def test_fused_coarse_vs_oracle_and_composed(dev, oracle, G, N, stage, extra):
     target_c = torch.rand(N, 3, generator=torch.Generator().manual_seed(8))
     target = target_c.to(dev)
     lossw = synth.COARSE_LOSS
-    a = synth.build_model(G, cfg, device=dev, fused=True)
-    b = synth.build_model(G, cfg, device=dev, fused=False)
+    over = {"grad_mode": extra["grad_mode"]} if extra.get("grad_mode") else {}
+    a = synth.build_model(G, cfg, device=dev, fused=True, **over)
+    b = synth.build_model(G, cfg, device=dev, fused=False, **over)
+    if over:
+        from fgs_nerf_amd import fused as fused_mod
+        assert fused_mod.supports_coarse(a)              # the fused kernels cover these modes, not only the composed path
     for m in (a, b):
         if extra.get("mask_cache"):
             sdf_mask = ((m.sdf.grid.detach() < 0.25) * 1e-3).float()

@@ -49,6 +49,13 @@ def test_alpha2weight_matches_cumprod_compositing_without_early_stop(oracle, ref
 def test_gradient_volume_matches_the_reference(oracle, ref):
     """model/nerf.py:485-494 ('interpolate')."""
     assert torch.equal(oracle.neus_sdf_gradient(ref["gv_sdf"], ref["gv_voxel_size"]), ref["gv_interpolate"])
+    # the two non-default modes (:495-506) and the grad_conv weight (:224-247)
+    assert torch.equal(oracle.neus_sdf_gradient(ref["gv_sdf"], ref["gv_voxel_size"], 'raw'), ref["gv_raw"])
+    assert torch.equal(oracle.grad_conv_weight(ref["gv_voxel_size"], 0), ref["gradconv_w_0"])
+    assert torch.equal(oracle.grad_conv_weight(ref["gv_voxel_size"], 0.5), ref["gradconv_w_05"])
+    # (the fixture's 'grad_conv' volume was produced with the sigma = 0.5 weight: the last init_gradient_conv call of the generator)
+    got = oracle.neus_sdf_gradient(ref["gv_sdf"], ref["gv_voxel_size"], 'grad_conv', oracle.grad_conv_weight(ref["gv_voxel_size"], 0.5))
+    assert rel_l2(got, ref["gv_grad_conv"]) < 1e-7
 
 
 @pytest.mark.parametrize("ks,sigma", [(3, 1.0), (5, 0.8)])

@@ -42,6 +42,33 @@ def test_gradient_volume_kernel_matches_reference(dev, ref):
     assert torch.equal(out.cpu(), ref["gv_interpolate"])
 
 
+def test_raw_and_grad_conv_gradient_volumes_match_reference(dev, ref):
+    """The reference's two non-default gradient volumes (model/nerf.py:495-506): 'raw' (forward difference: fgs_sdf_gradvol_fwd
+    mode 1, bit-exact) and 'grad_conv' (its own Sobel-like weight, model/nerf.py:224-247: three fgs_smooth3d_fwd passes);
+    their adjoints against torch autograd of the same expressions."""
+    import torch.nn.functional as F
+    from fgs_nerf_amd import dense
+    sdf, vs = ref["gv_sdf"].to(dev), float(ref["gv_voxel_size"])
+    assert torch.equal(dense.sdf_gradient_volume(sdf, vs, mode='raw').cpu(), ref["gv_raw"])
+    w = ref["gradconv_w_05"].to(dev)             # the reference's grad_conv weight the fixture's volume was made with (sigma = 0.5)
+    got = dense.sdf_gradient_volume(sdf, vs, mode='grad_conv', grad_conv_weight=w)
+    assert rel_l2(got.cpu(), ref["gv_grad_conv"]) < 1e-6
+    up = torch.randn(1, 3, *sdf.shape[2:], generator=torch.Generator().manual_seed(4)).to(dev)
+    for mode in ('raw', 'grad_conv'):
+        a = sdf.clone().requires_grad_(True)
+        dense.sdf_gradient_volume(a, vs, mode=mode, grad_conv_weight=w).backward(up)
+        b = sdf.clone().requires_grad_(True)
+        if mode == 'raw':
+            g = torch.zeros(1, 3, *sdf.shape[2:], device=dev)
+            g[:, 0, :-1] = (b[:, 0, 1:] - b[:, 0, :-1]) / vs
+            g[:, 1, :, :-1] = (b[:, 0, :, 1:] - b[:, 0, :, :-1]) / vs
+            g[:, 2, :, :, :-1] = (b[:, 0, :, :, 1:] - b[:, 0, :, :, :-1]) / vs
+        else:
+            g = F.conv3d(F.pad(b, (1,) * 6, mode='replicate'), w)
+        g.backward(up)
+        assert rel_l2(a.grad, b.grad) < 2e-6, mode
+
+
 @pytest.mark.parametrize("ks", [3, 5])
 def test_smoothing_kernel_matches_reference_conv(dev, ref, ks):
     """fgs_smooth3d_fwd == the reference's replicate-padded Conv3d with its own Gaussian taps (model/nerf.py:260-272)."""
