@@ -66,7 +66,7 @@ _SIGNATURES = {
     "fgs_surv_compact": [I64, I64, P, I32, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, F32, F32,
                          P, P, P, P, P, P, P, P, P, P],
     "fgs_march_fine_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, F32, I32,
-                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_sdf_scatter_surv": [I64, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P],
     "fgs_brick_flags": [P, I32, I32, I32, I32, P, P],
     "fgs_brick_gather": [P, I32, I32, I32, I32, P, I64, P, P],
@@ -100,7 +100,7 @@ _SIGNATURES = {
                              P, P, P, I32, I32, I32, F32, P, I32, I32, I32, P, P, I32,
                              P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_march_coarse_bwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, F32, I32,
-                             P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+                             P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "fgs_feat_coarse_fwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, I64, I64, I64, I64, P, P, P, P],
     "fgs_feat_coarse_bwd": [I64, P, P, P, P, P, P, I32, I32, I32, P, P, P, P, P, I64, I64, I64, I64, P, P, P],
     "fgs_ide_fwd": [P, P, P, P, I32, I32, I64, P, P],

@@ -46,9 +46,9 @@ __device__ __forceinline__ float neus_alpha(float sdf, float gx, float gy, float
   return fminf(fmaxf(a, 0.f), 1.f);
 }
 
-// Autograd of neus_alpha: g_alpha -> (d sdf, d gradient xyz)
+// Autograd of neus_alpha: g_alpha -> (d sdf, d gradient xyz, d inv_s)
 struct AlphaGrad {
-  float d_sdf, dgx, dgy, dgz;
+  float d_sdf, dgx, dgy, dgz, d_inv_s;
 };
 
 __device__ __forceinline__ AlphaGrad neus_alpha_bwd(float g_alpha, float sdf, float gx, float gy, float gz, float vx,
@@ -58,13 +58,14 @@ __device__ __forceinline__ AlphaGrad neus_alpha_bwd(float g_alpha, float sdf, fl
   const float half = iter_cos * dist * 0.5f;
   const float pc = sigmoidf_((sdf - half) * inv_s), nc = sigmoidf_((sdf + half) * inv_s);
   const float num = (pc - nc) + 1e-5f, dn = pc + 1e-5f, q = num / dn;
-  AlphaGrad o = {0.f, 0.f, 0.f, 0.f};
+  AlphaGrad o = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (q >= 0.f && q <= 1.f) {  // clip passes the gradient on the closed interval
     const float d_p = g_alpha / dn;
     const float d_c = -g_alpha * num / (dn * dn);
     const float d_prev = (d_p + d_c) * (pc * (1.f - pc));
     const float d_next = -d_p * (nc * (1.f - nc));
     o.d_sdf = (d_prev + d_next) * inv_s;
+    o.d_inv_s = d_prev * (sdf - half) + d_next * (sdf + half);   // the two sigmoid arguments are (sdf -/+ half) * inv_s
     const float d_half = (d_next - d_prev) * inv_s;
     const float d_iter = d_half * dist * 0.5f;
     const float d_cos = (true_cos < 0.f) ? d_iter : 0.f;  // iter_cos = cos where cos < 0, else 0
@@ -73,4 +74,12 @@ __device__ __forceinline__ AlphaGrad neus_alpha_bwd(float g_alpha, float sdf, fl
     o.dgz = d_cos * vz;
   }
   return o;
+}
+
+// Sum of `v` over the lanes of a wavefront, added to *dst by lane 0 (the s_learn gradient: d loss / d inv_s of model/nerf.py:
+// 512-522, where s_val is a learnable parameter).
+__device__ __forceinline__ void fgs_wave_atomic_sum(float v, float *dst) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dst, v);
 }

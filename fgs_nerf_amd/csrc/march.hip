@@ -206,6 +206,7 @@ struct MarchBwdArgs {
   float *grad_sdf_grid;     // [X,Y,Z] accumulated with atomics
   float *tot_sdf, *tot_grad;  // [M_s], [M_s,3]: if non-null, survivors' totals are written here instead of scattered
   int prio;                   // s_setprio level (FGS_PRIO_MARCH_BWD): the kernel runs beside k_mlp_wgrad, see fused.py _wgrad
+  float *g_inv_s;             // device float accumulating d loss / d inv_s (s_learn, model/nerf.py:512-522), or null
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
 
   // alpha2weight backward, back to front (render_utils_kernel.cu:671-675)
   float back_cum = (A.g_last ? A.g_last[ray] : 0.f) * A.alphainv_last[ray];
+  float acc_inv_s = 0.f;
   for (int top = n_alive; top > 0; top -= FGS_WAVE) {
     const int cnt = top < FGS_WAVE ? top : FGS_WAVE;
     const int a_local = top - 1 - lane;
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
       const float d_prev = (d_p + d_c) * (pc * (1.f - pc));
       const float d_next = -d_p * (nc * (1.f - nc));
       d_sdf = (d_prev + d_next) * A.inv_s;
+      acc_inv_s += d_prev * (sdf - half) + d_next * (sdf + half);
       const float d_half = (d_next - d_prev) * A.inv_s;
       const float d_iter = d_half * A.dist * 0.5f;
       d_cos = (true_cos < 0.f) ? d_iter : 0.f;  // iter_cos = cos where cos < 0, else 0
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_bwd(MarchBwdArgs A) {
       fgs_tri_scatter(A.grad_sdf_grid, gd, 0, fgs_tri_setup(tm.fx, tm.fy, tm.fz), -coef);
     }
   }
+  if (A.g_inv_s) fgs_wave_atomic_sum(acc_inv_s, A.g_inv_s);
 }
 
 SceneGeom make_geom(const float *lo, const float *hi, int X, int Y, int Z, float voxel_size) {
@@ -413,7 +417,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
                                const float *a_weight, const float *a_sdf, const float *a_grad, const int64_t *n_alive,
                                const int64_t *surv_off, const float *alphainv_last, const float *g_weights,
                                const float *g_last, const float *g_sdf, const float *g_gradient, float *grad_sdf_grid,
-                               float *tot_sdf, float *tot_grad, const fgs_dyn_t *dyn, fgs_stream_t stream) {
+                               float *tot_sdf, float *tot_grad, float *g_inv_s, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_fine_bwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_surv && a_alpha && a_T && a_weight &&
@@ -433,6 +437,7 @@ FGS_API int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const f
   // or k0's Adam pass moved to the branch's end all measured within +-0.5 % or worse: scripts/r3_branch_sweep*.sh)
   static const int prio = fgs_env_int("FGS_PRIO_MARCH_BWD", 1);
   A.prio = prio;
+  A.g_inv_s = g_inv_s;
   hipLaunchKernelGGL(k_march_fine_bwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
   FGS_LAUNCH_OK("fgs_march_fine_bwd");
   return 0;

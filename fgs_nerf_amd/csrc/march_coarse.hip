@@ -198,6 +198,7 @@ struct CoarseBwdArgs {
   const float *alphainv_last;
   const float *g_weights, *g_last, *g_gradient;  // [M_s], [n_rays] or null, [M_s,3] or null
   float *d_grid4;   // [X,Y,Z,4] voxel-interleaved (d smoothed-sdf, d gradient-volume xyz), accumulated with atomics
+  float *g_inv_s;   // device float accumulating d loss / d inv_s (s_learn), or null
 };
 
 __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A) {
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A)
   const GridDesc sd = fgs_sdf_desc(A.geom);
 
   float back_cum = (A.g_last ? A.g_last[ray] : 0.f) * A.alphainv_last[ray];
+  float acc_inv_s = 0.f;
   for (int top = n_kept; top > 0; top -= FGS_WAVE) {
     const int cnt = top < FGS_WAVE ? top : FGS_WAVE;
     const int k_local = top - 1 - lane;
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A)
       const AlphaGrad ag = neus_alpha_bwd(g_alpha, A.a_sdf[rec], A.a_grad[3 * rec], A.a_grad[3 * rec + 1],
                                           A.a_grad[3 * rec + 2], vx, vy, vz, A.dist, A.inv_s);
       gq[0] = ag.d_sdf; gq[1] = ag.dgx; gq[2] = ag.dgy; gq[3] = ag.dgz;
+      acc_inv_s += ag.d_inv_s;
     }
     if (act && A.g_gradient) {
 #pragma unroll
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_coarse_bwd(CoarseBwdArgs A)
         atomicAdd(A.d_grid4 + ((((int64_t)x * A.geom.Y + y) * A.geom.Z + z) << 2) + ch, wk * go);
     }
   }
+  if (A.g_inv_s) fgs_wave_atomic_sum(acc_inv_s, A.g_inv_s);
 }
 
 SceneGeom geom_make(const float *lo, const float *hi, int X, int Y, int Z, float voxel_size) {
@@ -349,7 +353,8 @@ FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const
                                  const float *a_alpha, const float *a_T, const float *a_weight, const float *a_sdf,
                                  const float *a_grad, const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off,
                                  const float *alphainv_last, const float *g_weights, const float *g_last,
-                                 const float *g_gradient, float *d_grid4, const fgs_dyn_t *dyn, fgs_stream_t stream) {
+                                 const float *g_gradient, float *d_grid4, float *g_inv_s, const fgs_dyn_t *dyn,
+                                 fgs_stream_t stream) {
   FGS_REQUIRE(n_rays >= 0 && n_rays < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_march_coarse_bwd: n_rays=%lld", (long long)n_rays);
   if (n_rays == 0) return 0;
   FGS_REQUIRE(rays_o && rays_d && viewdirs && xyz_min_host && xyz_max_host && a_step && a_alpha && a_T && a_weight && a_sdf &&
@@ -363,6 +368,7 @@ FGS_API int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const
   A.n_alive = n_alive; A.n_surv = n_surv; A.surv_off = surv_off; A.alphainv_last = alphainv_last;
   A.g_weights = g_weights; A.g_last = g_last; A.g_gradient = g_gradient;
   A.d_grid4 = d_grid4;
+  A.g_inv_s = g_inv_s;
   hipLaunchKernelGGL(k_march_coarse_bwd, dim3(fgs_blocks(n_rays * FGS_WAVE)), dim3(FGS_BLOCK), 0, fgs_s(stream), A);
   FGS_LAUNCH_OK("fgs_march_coarse_bwd");
   return 0;

@@ -39,7 +39,7 @@ PROFILE = {"enabled": False, "gemm_events": [], "open": None}      # see set_pro
 def supports(model) -> bool:
     """Configurations the fused kernels cover (everything the shipped fine-stage configs use)."""
     from .nerf import mlp_layers
-    if model.stage != 'fine' or model.rgbnet is None or model.s_learn:
+    if model.stage != 'fine' or model.rgbnet is None:
         return False
     if model.smooth_sdf and int(model.smooth_conv.weight.shape[-1]) > 7:      # dense.smooth3d covers kernel sides <= 7
         return False
@@ -653,6 +653,8 @@ class _FusedFine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run, sdf_grid, k0_grid, *mlp):
+        if run.s_param is not None:
+            mlp = mlp[:-1]              # (the learnable s_val rides along as the last input: only its gradient matters here)
         # outputs the loss does not use arrive as None in backward (the kernels take NULL) instead of as zero tensors that
         # autograd would fill -- six launches of ~5 us at the head of the backward pass, one of them an int64 fill for ray_id
         ctx.set_materialize_grads(False)
@@ -873,6 +875,8 @@ class _FusedFine(torch.autograd.Function):
             grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
         for i in range(n_ref):
             grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
+        if run.s_param is not None:
+            grads.append(torch.zeros_like(run.s_param))
         return tuple(grads)
 
     @staticmethod
@@ -1010,12 +1014,14 @@ class _FusedFine(torch.autograd.Function):
                  ptr(g_sdf_s) if enc_part else None, ptr(g_grad_s) if enc_part else None,
                  dyn(row_count=_rows(run), compact=compact), st)
 
+        g_inv_s = torch.zeros(1, dtype=F32, device=dev) if run.s_param is not None else None
+
         def march_bwd():
             call("fgs_march_fine_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
                  g.voxel_size, run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']),
                  ptr(ws['a_surv']), ptr(ws['a_alpha']), ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']),
                  ptr(ws['n_alive']), ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_sdf_s),
-                 ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), dyn(inv_s=_inv_s(run)), st)
+                 ptr(g_grad_s), ptr(grad_sdf), ptr(tot_sdf), ptr(tot_grad), ptr(g_inv_s), dyn(inv_s=_inv_s(run)), st)
 
         if march_first:
             feat_bwd(False, True)
@@ -1054,6 +1060,8 @@ class _FusedFine(torch.autograd.Function):
             grads += [gw_rgb[i].contiguous(), gb_rgb[i].contiguous()]
         for i in range(n_ref):
             grads += [gw_ref[i].contiguous(), gb_ref[i].contiguous()]
+        if run.s_param is not None:     # inv_s = 1 / s_val  =>  d s_val = -d inv_s / s_val^2
+            grads.append((-g_inv_s / run.s_param.detach().to(dev).float() ** 2).reshape(run.s_param.shape))
         return tuple(grads)
 
 
@@ -1090,7 +1098,7 @@ def _early_hooks(run):
 def supports_coarse(model) -> bool:
     """Coarse-stage configurations ('coarse', 'geometry_searching') the fused kernels cover."""
     from .nerf import mlp_layers
-    if model.stage not in ('coarse', 'geometry_searching') or model.s_learn or not (model.fast_color_thres > 0):
+    if model.stage not in ('coarse', 'geometry_searching') or not (model.fast_color_thres > 0):
         return False
     if getattr(model, 'grad_mode', 'interpolate') not in ('interpolate', 'raw', 'grad_conv'):
         return False
@@ -1114,6 +1122,8 @@ class _FusedCoarse(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, run, sdf_smooth, gradvol, k0_grid, *mlp):
+        if run.s_param is not None:
+            mlp = mlp[:-1]              # (see _FusedFine.forward)
         ctx.set_materialize_grads(False)              # see _FusedFine.forward
         dev = sdf_smooth.device
         g, N, st, ms, ws = run.geom, run.n_rays, stream(), run.max_steps, run.workspace
@@ -1270,6 +1280,8 @@ class _FusedCoarse(torch.autograd.Function):
                      torch.zeros(1, 3, g.X, g.Y, g.Z, dtype=F32, device=dev), grad_k0]
             for i in range(n_ref):
                 grads += [gw[i].contiguous(), gb[i].contiguous()]
+            if run.s_param is not None:
+                grads.append(torch.zeros_like(run.s_param))
             return tuple(grads)
         d_out = torch.empty(M, 3, dtype=F32, device=dev)
         d_w = torch.empty(M, dtype=F32, device=dev)
@@ -1348,11 +1360,12 @@ class _FusedCoarse(torch.autograd.Function):
             opt_hook(k0_grid, grad_k0)
         # d4: voxel-interleaved accumulation buffer [X,Y,Z,4]; the two dense adjoints (dense.py) read their channel(s) of
         # it in place through element strides
+        g_inv_s = torch.zeros(1, dtype=F32, device=dev) if run.s_param is not None else None
         call("fgs_march_coarse_bwd", ptr(run.rays_o), ptr(run.rays_d), ptr(run.viewdirs), N, g.lo_c, g.hi_c, g.X, g.Y, g.Z,
              run.near, 1e9, run.stepdist, run.dist, run.inv_s, run.max_steps, ptr(ws['a_step']), ptr(ws['a_alpha']),
              ptr(ws['a_T']), ptr(ws['a_weight']), ptr(ws['a_sdf']), ptr(ws['a_grad']), ptr(ws['n_alive']), ptr(ws['n_surv']),
-             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), dyn(inv_s=_inv_s(run)),
-             st)
+             ptr(ws['surv_off']), ptr(S['alphainv_last']), ptr(d_w), ptr(g_last), ptr(g_grad_s), ptr(d4), ptr(g_inv_s),
+             dyn(inv_s=_inv_s(run)), st)
         d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
         d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
         _join_side(dev)
@@ -1361,6 +1374,8 @@ class _FusedCoarse(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]
         for i in range(n_ref):
             grads += [gw[i].contiguous(), gb[i].contiguous()]
+        if run.s_param is not None:
+            grads.append((-g_inv_s / run.s_param.detach().to(dev).float() ** 2).reshape(run.s_param.shape))
         return tuple(grads)
 
 
@@ -1466,6 +1481,11 @@ def _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, defa
     s32 = np.float32(s_val) if is_train else np.float32(getattr(model, '_s_val_host', model.s_start))
     model._s_val_host = float(s32)
     run.inv_s = float(np.float32(1.0) / s32)
+    # s_learn (model/nerf.py:512-522): s_val is a trained parameter; the march backward accumulates d loss / d inv_s for it
+    run.s_param = model.s_val if (getattr(model, 's_learn', False) and is_train and model.s_val.requires_grad) else None
+    if run.s_param is not None and run.cache.get('sync_free') is not None:
+        raise RuntimeError("the sync-free / captured step reads 1/s from a device-resident SCHEDULE; a learnable s_val (s_learn) is "
+                           "served by the eager fused path only")
     run.max_steps = int(math.ceil(run.geom.diag / run.stepdist)) + 2
     run.workspace = _workspace(model, N, run.max_steps, rays_o.device)
     run.sync_free = run.cache.get('sync_free')
@@ -1531,6 +1551,8 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
     if run.sync_free and not (_MLP_IMPL == "rc" and fw_ % 32 == 0 and fw_ <= 256 and run.ldx0 <= 256 and len(fl) - 1 <= 8):
         raise RuntimeError("the sync-free coarse-stage path needs the register-resident MLP kernels (FGS_MLP=rc, refnet width "
                            "a multiple of 32, <= 256)")
+    if run.s_param is not None:
+        mlp = mlp + [run.s_param]
     (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedCoarse.apply(
         run, sdf_smooth, model.gradient, model.k0.grid, *mlp)
     ex = run.extras
@@ -1592,6 +1614,8 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
             model._fused_taps = taps
         sdf_in = dense.smooth3d(model.sdf.grid, model.smooth_conv.weight, taps[1])
     run.sdf_in = sdf_in.detach()
+    if run.s_param is not None:
+        mlp = mlp + [run.s_param]
     (rgb_marched, sigmoid_rgb, alphainv_last, weights, rgb, normal, ray_id, alpha, gradient) = _FusedFine.apply(
         run, sdf_in, model.k0.grid, *mlp)
     ex = run.extras

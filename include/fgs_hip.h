@@ -446,9 +446,12 @@ int fgs_march_fine_bwd(const float *rays_o, const float *rays_d, const float *vi
                        const int *a_surv, const float *a_alpha, const float *a_T, const float *a_weight,
                        const float *a_sdf, const float *a_grad, const int64_t *n_alive, const int64_t *surv_off,
                        const float *alphainv_last, const float *g_weights, const float *g_last, const float *g_sdf,
-                       const float *g_gradient, float *grad_sdf_grid, float *tot_sdf, float *tot_grad,
+                       const float *g_gradient, float *grad_sdf_grid, float *tot_sdf, float *tot_grad, float *g_inv_s,
                        const fgs_dyn_t *dyn, fgs_stream_t stream);
-/* tot_sdf [M_s] / tot_grad [M_s,3] (both or neither): when given, the survivors' total gradients w.r.t. their sdf value
+/* g_inv_s (may be NULL; fgs_march_fine_bwd and fgs_march_coarse_bwd): a device float, zeroed by the caller, into which the
+ * kernel accumulates d loss / d inv_s -- the gradient of a LEARNABLE NeuS sharpness (s_learn, model/nerf.py:512-522:
+ * inv_s = 1 / s_val with s_val an nn.Parameter); the caller turns it into d s_val = -g_inv_s / s_val^2.
+ * tot_sdf [M_s] / tot_grad [M_s,3] (both or neither): when given, the survivors' total gradients w.r.t. their sdf value
  * and sdf gradient vector are written there instead of being scattered, and fgs_sdf_scatter_surv combines them on chip
  * with the hierarchical-tap gradients (8x8x8 LDS brick per survivor, row-wise flush: ~30 atomic line requests per
  * survivor instead of ~250).  dX0 is the gradient w.r.t. the rgbnet input buffer; X0 the saved forward buffer. */
@@ -561,7 +564,7 @@ int fgs_march_coarse_bwd(const float *rays_o, const float *rays_d, const float *
                          float stepdist, float dist, float inv_s, int max_steps, const int *a_step, const float *a_alpha,
                          const float *a_T, const float *a_weight, const float *a_sdf, const float *a_grad,
                          const int64_t *n_alive, const int64_t *n_surv, const int64_t *surv_off, const float *alphainv_last,
-                         const float *g_weights, const float *g_last, const float *g_gradient, float *d_grid4,
+                         const float *g_weights, const float *g_last, const float *g_gradient, float *d_grid4, float *g_inv_s,
                          const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* Coarse-stage MLP operand rows X0 [M, ldx0] = torch.cat([k0, xyz_emb, reflect_emb, normal, viewdirs_emb]) (zero padded),

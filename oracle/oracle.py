@@ -361,9 +361,11 @@ def s_val_schedule(global_step, s_ratio, s_start, step_start=0) -> float:
     return 1. / (global_step + s_ratio / s_start - step_start) * s_ratio
 
 
-def neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradients, s_val: float):
-    """model/nerf.py:510-544 (is_train, not s_learn, use_mid, cos_anneal_ratio=1)."""
-    s_param = torch.ones(1) * s_val
+def neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradients, s_val: float, s_param=None):
+    """model/nerf.py:510-544 (is_train, use_mid, cos_anneal_ratio=1).  `s_param`: the learnable s_val parameter of s_learn
+    (:516-517; a [1] tensor that may require grad) -- otherwise the scheduled value (:514-515)."""
+    if s_param is None:
+        s_param = torch.ones(1) * s_val
     dirs = viewdirs[ray_id]
     inv_s = torch.ones(1) / s_param
     true_cos = (dirs * gradients).sum(-1, keepdim=True)
@@ -646,8 +648,8 @@ def forward_fine(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsize,
     sdf_grid = smooth_conv(P['sdf'], P['smooth_kernel']) if P.get('smooth_kernel') is not None else P['sdf']
     sdf, gradient, _ = grid_sampler_ret_grad(ray_pts, sdf_grid, xyz_min, xyz_max, voxel_size)
     dist = stepsize * voxel_size
-    s_val = s_val_schedule(global_step, P['s_ratio'], P['s_start'])
-    alpha = neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradient, s_val)
+    s_val = float(P['s_param']) if P.get('s_param') is not None else s_val_schedule(global_step, P['s_ratio'], P['s_start'])
+    alpha = neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradient, s_val, P.get('s_param'))
     mask = None
     viewdirs_pts = viewdirs[ray_id]
     thres = P['fast_color_thres']
@@ -745,8 +747,8 @@ def forward_coarse(P: Dict, rays_o, rays_d, viewdirs, global_step, near, stepsiz
     grad_vol = neus_sdf_gradient(P['sdf'], voxel_size, P.get('grad_mode', 'interpolate'), P.get('grad_conv_w'))   # nerf.py:972
     gradient = dense_grid_forward(grad_vol, ray_pts, xyz_min, xyz_max)
     dist = stepsize * voxel_size
-    s_val = s_val_schedule(global_step, P['s_ratio'], P['s_start'])
-    alpha = neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradient, s_val)
+    s_val = float(P['s_param']) if P.get('s_param') is not None else s_val_schedule(global_step, P['s_ratio'], P['s_start'])
+    alpha = neus_alpha_from_sdf_scatter(viewdirs, ray_id, dist, sdf, gradient, s_val, P.get('s_param'))
     mask = None
     thres = P['fast_color_thres']
     pass1 = None

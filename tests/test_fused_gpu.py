@@ -536,3 +536,35 @@ def grads_of_any(model):
             for i, l in enumerate(mlp_layers(getattr(model, net))):
                 out[f'{net}.{i}.weight'], out[f'{net}.{i}.bias'] = l.weight.grad, l.bias.grad
     return out
+
+
+@pytest.mark.parametrize("stage", ["fine", "coarse"])
+def test_learnable_s_val_through_the_fused_path(dev, oracle, stage):
+    """s_learn (model/nerf.py:512-522): s_val is a trained parameter and inv_s = 1 / s_val carries a gradient.  The fused march
+    backward accumulates d loss / d inv_s (fgs_march_*_bwd g_inv_s); values and every gradient -- s_val's included -- against
+    the CPU oracle run with the same parameter."""
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.losses import render_losses
+    from fgs_nerf_amd.nerf import mlp_layers
+    cfg = synth.FINE_MODEL if stage == "fine" else synth.COARSE_MODEL
+    lossw = synth.FINE_LOSS if stage == "fine" else synth.COARSE_LOSS
+    model = synth.build_model(32, cfg, device=dev, s_learn=True)
+    with torch.no_grad():
+        model.s_val.fill_(0.043)
+    assert model.s_val.requires_grad and (fused.supports(model) if stage == "fine" else fused.supports_coarse(model))
+    N = 300
+    ro, rd, vd = synth.random_rays(N, seed=21)
+    target = torch.rand(N, 3, generator=torch.Generator().manual_seed(5))
+    res = model(ro.to(dev), rd.to(dev), vd.to(dev), global_step=500, **synth.RENDER_KWARGS)
+    render_losses(res, target.to(dev), lossw, model).backward()
+    P = synth.oracle_params(model)
+    P['s_param'] = model.s_val.detach().cpu().clone().requires_grad_(True)
+    P['sdf'].requires_grad_(True)
+    fwd = oracle.forward_fine if stage == "fine" else oracle.forward_coarse
+    ref = fwd(P, ro, rd, vd, global_step=500, near=2.0, stepsize=0.5, bg=1)
+    render_losses(ref, target, lossw).backward()
+    assert torch.equal(res['ray_id'].cpu(), ref['ray_id'])
+    assert rel_l2(res['rgb_marched'].detach(), ref['rgb_marched'].detach()) < 1e-5
+    assert rel_l2(model.sdf.grid.grad, P['sdf'].grad) < 1e-3
+    g_hip, g_ref = float(model.s_val.grad), float(P['s_param'].grad)
+    assert g_ref != 0.0 and abs(g_hip - g_ref) <= 2e-4 * abs(g_ref), (g_hip, g_ref)
