@@ -193,6 +193,46 @@ def pmc_traffic_live(args, timeout_s=180):
                       "workload); bytes = FETCH_SIZE KB x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE KB x 1024"}
 
 
+def rccl_graph_selftest(dev, timeout_s: float = 20.0) -> bool:
+    """Before the N > 1 step is captured with its collectives inside: can THIS stack replay a hipGraph that holds an RCCL
+    all-reduce between these ranks?  A tiny all-reduce on a communicator of its own (a wedged replay must not block the
+    communicators the run uses) is captured, replayed and waited for with a timeout; the ranks then agree (MIN) on the outcome.
+    False sends the run to the eager form -- a number from the slower path beats a hang."""
+    import torch.distributed as dist
+    ok = 1
+    try:
+        grp = dist.new_group(backend="nccl")
+        t = torch.ones(4096, device=dev)
+        dist.all_reduce(t, group=grp)                      # communicator set-up happens eagerly
+        torch.cuda.synchronize()
+        t.fill_(1.0)
+        side = torch.cuda.Stream(device=dev)
+        graph = torch.cuda.CUDAGraph()
+        time.sleep(0.35)                                   # (the watchdog's list drains: see CapturedFineStep.capture)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                dist.all_reduce(t, group=grp)
+            graph.replay()
+            done = torch.cuda.Event()
+            done.record(side)
+        t0 = time.perf_counter()
+        while not done.query():
+            if time.perf_counter() - t0 > timeout_s:
+                print("[bench] RCCL-in-hipGraph self-test: the replay did not complete", file=sys.stderr, flush=True)
+                ok = 0
+                break
+            time.sleep(0.005)
+        if ok and not bool((t == float(dist.get_world_size())).all()):
+            print("[bench] RCCL-in-hipGraph self-test: wrong values after the replay", file=sys.stderr, flush=True)
+            ok = 0
+    except Exception as e:          # noqa: BLE001
+        print(f"[bench] RCCL-in-hipGraph self-test failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def launch_ranks(n_gpus: int, argv) -> int:
     """One process per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port); returns the children's
     exit status (non-zero if any rank failed: torchrun tears the others down)."""
@@ -348,6 +388,9 @@ def main():
     # device-counted form; the warm-up steps below run the host-counted exchange and thereby measure the union's brick count,
     # identical on every rank, from which the exchange capacity is derived)
     use_graph = (args.mode == "graph" and not args.composed and os.environ.get("FGS_MLP", "rc") == "rc")
+    if use_graph and (world > 1 or force_dist) and not rccl_graph_selftest(dev):
+        use_graph = False
+        print("[bench] collectives inside a hipGraph are not usable here: running the eager form", file=sys.stderr, flush=True)
     STEP_STATS["max_survivors"] = 0
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
