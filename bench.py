@@ -406,7 +406,7 @@ def main():
             seen = int(seen_t.item())
         capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
         captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
-                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + 16,
+                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + args.warmup + 16,
                                     global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
                                     tv=(0.01 * 0.1 / n_global, True), capacity=capacity,
                                     averager=averager if (world > 1 or force_dist) else None)
@@ -428,7 +428,9 @@ def main():
             capture_ok = int(ok_t.item())
         if capture_ok:
             packed = [torch.stack(b).contiguous() for b in batches]     # rays_o / rays_d / viewdirs / target as one [4, N, 3] block
-            for i in range(2):                       # two untimed replays (the first launch of a graph uploads it)
+            # the W warm-up steps in the form the timed steps have: untimed replays (the first launch of a graph uploads it; the
+            # eager warm-up steps above served the allocator and the capacity estimates)
+            for i in range(max(2, args.warmup)):
                 captured.replay(packed[i % N_BATCHES])
             torch.cuda.synchronize()
             captured.clear_counters()

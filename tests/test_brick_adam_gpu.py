@@ -265,3 +265,42 @@ def test_gradient_accumulation_and_foreign_writes_are_detected(dev):
     opt.step()
     torch.cuda.synchronize()
     assert gb['clean'] and not bool(gb['buf'].any())
+
+
+def test_resumed_reference_layout_moments_take_the_same_step_as_the_oracle(dev, oracle):
+    """moments loaded from a reference-layout (NCDHW-contiguous) optimizer state next to a channel-last k0 --
+    after load_state_dict one MaskedAdam step equals the oracle's masked Adam on the same logical tensors, bit for bit."""
+    from fgs_nerf_amd.adam import MaskedAdam
+    from fgs_nerf_amd.grid import to_grid_layout
+    g = torch.Generator().manual_seed(3)
+    shape = (1, 12, 8, 12, 16)
+    p0, m0, v0 = torch.randn(shape, generator=g), torch.randn(shape, generator=g) * 0.1, torch.rand(shape, generator=g) * 0.01
+    grad = torch.randn(shape, generator=g) * (torch.rand(shape, generator=g) < 0.3)
+    p = torch.nn.Parameter(to_grid_layout(p0.to(dev)))
+    opt = MaskedAdam([{'params': [p], 'lr': 0.1, 'skip_zero_grad': True}])
+    opt.ensure_state()
+    sd = opt.state_dict()
+    sd['state'][0].update(exp_avg=m0.clone(), exp_avg_sq=v0.clone(), step=4)       # NCDHW-contiguous, as the reference saves
+    opt.load_state_dict(sd)
+    p.grad = to_grid_layout(grad.to(dev))
+    opt.step()
+    pr, mr, vr = p0.numpy().copy(), m0.numpy().copy(), v0.numpy().copy()
+    oracle.K.adam_upd(pr.reshape(-1), grad.numpy().reshape(-1), mr.reshape(-1), vr.reshape(-1), 5, 0.9, 0.99, 0.1, 1e-8, mode=1)
+    assert torch.equal(p.detach().cpu().contiguous(), torch.from_numpy(pr))
+    assert torch.equal(opt.state[p]['exp_avg'].cpu().contiguous(), torch.from_numpy(mr))
+
+
+def test_second_backward_before_step_with_the_in_backward_update_raises(dev):
+    """with k0's Adam pass issued from inside the backward pass, a second backward() before step() used to have
+    its k0 gradient dropped without a word; it raises now."""
+    import bench
+    from fgs_nerf_amd import fused, synth
+    from fgs_nerf_amd.losses import fused_render_losses
+    model = synth.build_model(32, synth.FINE_MODEL, device=dev)
+    opt = bench.make_optimizer(model)
+    fused.enable_early_update(model, opt, None, inline=True)
+    rays = tuple(r.to(dev) for r in synth.random_rays(256, seed=2))
+    target = torch.rand(256, 3, device=dev)
+    fused_render_losses(model(*rays, global_step=1000, **synth.RENDER_KWARGS), target, synth.FINE_LOSS, model).backward()
+    with pytest.raises(RuntimeError, match="already updated"):
+        fused_render_losses(model(*rays, global_step=1000, **synth.RENDER_KWARGS), target, synth.FINE_LOSS, model).backward()

@@ -131,3 +131,34 @@ def test_compute_bbox_by_coarse_geo_equals_the_dense_lattice_expression(tmp_path
     got_min, got_max = checkpoint.compute_bbox_by_coarse_geo(None, path, 0.0)
     assert torch.equal(got_min, pts.amin(0)) and torch.equal(got_max, pts.amax(0))
     assert bool((got_min > lo).all() and (got_max < hi).all())
+
+
+def test_optimizer_state_written_in_the_reference_layout_is_relaid_on_load():
+    """A reference-written checkpoint holds MaskedAdam moments NCDHW-contiguous (model/adam.py state); here k0 is channel-last
+    and the update kernels walk parameter, gradient and both moments with ONE flat offset.  load_state_dict must re-lay the
+    moments out like their parameter (same logical values), and a moment that does not share its parameter's layout must be
+    refused by the kernels' host checks rather than silently paired with another voxel's elements."""
+    import bench
+    from fgs_nerf_amd.adam import MaskedAdam
+    model = _model(G=8)
+    opt = bench.make_optimizer(model)
+    opt.ensure_state()
+    k0 = model.k0.grid
+    assert k0.stride() != k0.contiguous().stride()                      # channel-last storage
+    sd = opt.state_dict()
+    gen = torch.Generator().manual_seed(1)
+    idx = [i for i, g in enumerate(opt.param_groups) if any(p is k0 for p in g['params'])][0]
+    pid = sd['param_groups'][idx]['params'][0]
+    m_ref = torch.randn(k0.shape, generator=gen).contiguous()            # what the reference would have saved: NCDHW-contiguous
+    v_ref = torch.rand(k0.shape, generator=gen).contiguous()
+    sd['state'][pid]['exp_avg'], sd['state'][pid]['exp_avg_sq'], sd['state'][pid]['step'] = m_ref, v_ref, 7
+    opt2 = bench.make_optimizer(model)
+    opt2.load_state_dict(sd)
+    st = opt2.state[k0]
+    assert st['step'] == 7
+    assert st['exp_avg'].stride() == k0.stride() and st['exp_avg_sq'].stride() == k0.stride()
+    assert torch.equal(st['exp_avg'], m_ref) and torch.equal(st['exp_avg_sq'], v_ref)       # same logical values
+    # a moment forced into another layout is refused by the host check the kernels sit behind
+    st['exp_avg'] = m_ref.clone()
+    with pytest.raises(RuntimeError, match="memory layout"):
+        MaskedAdam._check_layout(k0, st)
