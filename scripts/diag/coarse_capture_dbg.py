@@ -13,8 +13,8 @@ model = synth.build_model(G, synth.COARSE_MODEL, device=dev)
 opt = bench.make_optimizer(model)
 ro, rd, vd = synth.random_rays(N, seed=1)
 batch = tuple(t.to(dev).contiguous() for t in (ro, rd, vd, torch.rand(N, 3)))
-if 'novol4' in skip: fused._COARSE_VOL4 = False
-if 'nobrick' in skip: fused._BRICK_ADAM = False
+if 'novol4' in skip: fused.FLAGS['coarse_vol4'] = False
+if 'nobrick' in skip: fused.FLAGS['brick_adam'] = False
 tv = None if 'notv' in skip else (1e-6, True)
 step = CapturedStep(model, opt, synth.COARSE_LOSS, synth.RENDER_KWARGS, N, n_iters=4, global_step_of=lambda it: 300,
                     lr_of=lambda it, g: g['lr'], tv=tv, capacity=int(os.environ.get('CAP', 40 * N)))

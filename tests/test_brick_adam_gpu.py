@@ -172,8 +172,8 @@ def _train(dev, steps, brick, oracle, tv_dense_k0=False, G=48, N=1024):
     import bench
     from fgs_nerf_amd import fused, synth
     from fgs_nerf_amd.losses import fused_render_losses
-    old = fused._BRICK_ADAM
-    fused._BRICK_ADAM = brick
+    old = fused.FLAGS['brick_adam']
+    fused.FLAGS['brick_adam'] = brick
     try:
         model = synth.build_model(G, synth.FINE_MODEL, device=dev)
         opt = bench.make_optimizer(model)
@@ -206,7 +206,7 @@ def _train(dev, steps, brick, oracle, tv_dense_k0=False, G=48, N=1024):
                 assert not bool(gb['buf'].any()) and not bool(gb['flags'].any()), it
         return model._fused_cache, used, bricked
     finally:
-        fused._BRICK_ADAM = old
+        fused.FLAGS['brick_adam'] = old
 
 
 def test_fused_step_with_the_persistent_gradient_buffer_is_bit_exact(dev, oracle):

@@ -195,10 +195,10 @@ def test_interleaved_volume_lookups_are_bit_identical(dev):
     rays = tuple(t.to(dev) for t in synth.random_rays(700, seed=21))
     target = torch.rand(700, 3, generator=torch.Generator().manual_seed(2)).to(dev)
     outs = {}
-    old = fused._COARSE_VOL4
+    old = fused.FLAGS['coarse_vol4']
     try:
         for flag in (True, False):
-            fused._COARSE_VOL4 = flag
+            fused.FLAGS['coarse_vol4'] = flag
             model = synth.build_model(40, synth.COARSE_MODEL, device=dev)
             res = model(*rays, global_step=300, **synth.RENDER_KWARGS)
             loss = fused_render_losses(res, target, synth.COARSE_LOSS, model)
@@ -207,7 +207,7 @@ def test_interleaved_volume_lookups_are_bit_identical(dev):
                                                                  'gradient', 'alphainv_cum')},
                           model.sdf.grid.grad.clone(), float(loss))
     finally:
-        fused._COARSE_VOL4 = old
+        fused.FLAGS['coarse_vol4'] = old
     for k in outs[True][0]:
         assert torch.equal(outs[True][0][k], outs[False][0][k]), k
     # (the loss scalar is a sum of per-workgroup partials added with float atomics: equal up to their order, like sdf.grad)
