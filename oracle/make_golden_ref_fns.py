@@ -29,8 +29,16 @@ What is taken (file:line of the definitions executed) and what it pins (tests/te
   model/nerf.py:734-758    nerf.sample_ray_ori               -> oracle.sample_ray_ori (a3 cross-check: the padded sampler)
   model/nerf.py:1203-1209  MaskCache.forward                 -> oracle.mask_cache_forward, nerf.MaskCache here (a4)
 
-Not runnable here, hence still unpinned: everything that calls `.cuda()` inside its body (neus_alpha_from_sdf_scatter
-model/nerf.py:510-544, sample_sdfs :597-637), the CUDA extension wrappers, torch_scatter.segment_coo.
+Second file, tests/golden/ref_fns_cuda_shim.npz (`main_cuda_shim`).  Three more functions are pure torch except that their
+bodies move small constants to the GPU with `.cuda()`: `nerf.neus_alpha_from_sdf_scatter` (model/nerf.py:510-544, `torch.ones(1)
+.cuda()`), `nerf.sample_sdfs` (:597-637, three index tables), and through it `nerf.grid_sampler(sample_grad=True)` (:639-672).
+There is no GPU in this container.  For THESE calls only, and kept apart from the vectors above, the generator runs the
+unmodified function bodies with `torch.Tensor.cuda` temporarily replaced by the identity (the tensor stays on the CPU): a
+change of placement, not of arithmetic -- every value is produced by the reference's own statements on torch's CPU ops, exactly
+like the vectors of the first file.  They pin the NeuS alpha (a8) and the 6 K axis taps / tap differences (a7).
+
+Not runnable here under any honest arrangement, hence still unpinned: the CUDA extension kernels and their wrappers (a3 packed
+sampler, a9 early-terminating scan, a14, a15), torch_scatter.segment_coo, PyMCubes.
 """
 from __future__ import annotations
 
@@ -187,6 +195,74 @@ def main() -> None:
         print("  ", s)
 
 
+class _cuda_is_identity:
+    """`with _cuda_is_identity():` -- torch.Tensor.cuda returns the tensor itself (see the module docstring)."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda = self.orig
+        return False
+
+
+def main_cuda_shim() -> None:
+    sys.dont_write_bytecode = True
+    g = torch.Generator().manual_seed(778)
+    nerf_py = os.path.join(REF, "model", "nerf.py")
+    out, lines = {}, {}
+    alpha_fn, lines["neus_alpha_from_sdf_scatter"] = extract(nerf_py, "neus_alpha_from_sdf_scatter", cls="nerf")
+    sdfs_fn, lines["sample_sdfs"] = extract(nerf_py, "sample_sdfs", cls="nerf")
+    gs_fn, lines["grid_sampler"] = extract(nerf_py, "grid_sampler", cls="nerf")
+
+    # ---- NeuS alpha on a spread of (sdf, gradient, view direction) incl. back-facing samples, tiny and large |sdf| --------------
+    M, N = 600, 40
+    ray_id = torch.sort(torch.randint(0, N, (M,), generator=g))[0]
+    viewdirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    sdf = torch.randn(M, generator=g) * 0.05
+    sdf[:20] *= 40.0
+    sdf[20:30] = 0.0
+    grad = torch.randn(M, 3, generator=g) * torch.rand(M, 1, generator=g) * 2.0
+    dist = torch.tensor(0.5) * torch.tensor(0.0125)
+    for tag, gstep in (("a", 1000), ("b", 15000)):
+        me = types.SimpleNamespace(s_learn=False, s_ratio=50, s_start=0.05, step_start=0, s_val=nn.Parameter(torch.ones(1) * 0.05))
+        with _cuda_is_identity(), torch.no_grad():
+            s_val, alpha = alpha_fn(me, viewdirs, ray_id, dist, sdf, grad, gstep, True)
+        out[f"alpha_{tag}"], out[f"alpha_s_val_{tag}"], out[f"alpha_step_{tag}"] = alpha, torch.tensor(s_val), torch.tensor(gstep)
+    out.update(alpha_viewdirs=viewdirs, alpha_ray_id=ray_id, alpha_sdf=sdf, alpha_grad=grad, alpha_dist=dist)
+
+    # ---- sample_sdfs: 6 K taps and 3 K tap differences, with and without normalisation; points on and outside the faces ----------
+    lo, hi = torch.tensor([-1.0, -0.8, -1.2]), torch.tensor([1.1, 0.9, 1.0])
+    pts = lo + (hi - lo) * (torch.rand(200, 3, generator=g) * 1.1 - 0.05)
+    pts[:4] = torch.stack([lo, hi, lo + (hi - lo) * 0.999, lo + (hi - lo) * 0.001])
+    grid = torch.randn(1, 1, 9, 10, 11, generator=g)
+    vs = torch.tensor(0.21)
+    me_s = types.SimpleNamespace(xyz_min=lo, xyz_max=hi, voxel_size=vs, nearest=False)
+    me_s.sample_sdfs = lambda *a, **k: sdfs_fn(me_s, *a, **k)
+    out.update(taps_lo=lo, taps_hi=hi, taps_pts=pts, taps_grid=grid, taps_voxel_size=vs)
+    for tag, disp, norm in (("k4", [0.5, 1.0, 1.5, 2.0], True), ("k4_raw", [0.5, 1.0, 1.5, 2.0], False), ("k1", [1.0], False)):
+        with _cuda_is_identity(), torch.no_grad():
+            feat, gr = sdfs_fn(me_s, pts, grid, displace_list=disp, use_grad_norm=norm)
+        out[f"taps_feat_{tag}"], out[f"taps_grad_{tag}"] = feat, gr
+        out[f"taps_disp_{tag}"] = torch.tensor(disp)
+    with _cuda_is_identity(), torch.no_grad():
+        val, grad_xyz, feat_xyz = gs_fn(me_s, pts, grid, sample_ret=True, sample_grad=True)
+    out.update(gs_val=val, gs_grad_xyz=grad_xyz, gs_feat_xyz=feat_xyz)
+
+    arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()}
+    arrays["source_lines"] = np.array([f"{k}:{a}-{b}" for k, (a, b) in sorted(lines.items())])
+    path = os.path.join(ROOT, "tests", "golden", "ref_fns_cuda_shim.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(arrays), "arrays")
+    for s_ in arrays["source_lines"]:
+        print("  ", s_)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
-    main()
+    if len(sys.argv) < 2 or sys.argv[1] == "pure":
+        main()
+    if len(sys.argv) < 2 or sys.argv[1] == "cuda_shim":
+        main_cuda_shim()

@@ -100,3 +100,34 @@ def test_mask_cache_matches_the_reference(oracle, ref):
     """model/nerf.py:1193-1209 (max-pooled mask, trilinear sample >= thres)."""
     mc = oracle.make_mask_cache(ref["mc_raw"], ref["tri_lo"], ref["tri_hi"], 1e-3)
     assert torch.equal(oracle.mask_cache_forward(mc, ref["mc_pts"]), ref["mc_keep"].bool())
+
+
+# ---- vectors of tests/golden/ref_fns_cuda_shim.npz: the reference's own bodies of neus_alpha_from_sdf_scatter, sample_sdfs and
+# ---- grid_sampler(sample_grad=True), executed with torch.Tensor.cuda as the identity (oracle/make_golden_ref_fns.py: no GPU here)
+@pytest.fixture(scope="module")
+def shim(golden):
+    g = golden("ref_fns_cuda_shim.npz")
+    return {k: (torch.from_numpy(g[k]) if g[k].dtype.kind in "fbiu" else g[k]) for k in g.files}
+
+
+def test_neus_alpha_matches_the_reference(oracle, shim):
+    """model/nerf.py:510-544 (scheduled s_val, use_mid): alpha of 600 samples, at two points of the s_val schedule."""
+    for tag in ("a", "b"):
+        s_val = oracle.s_val_schedule(int(shim[f"alpha_step_{tag}"]), 50, 0.05)
+        assert abs(s_val - float(shim[f"alpha_s_val_{tag}"])) <= 1e-7 * abs(s_val)        # (stored as float32)
+        got = oracle.neus_alpha_from_sdf_scatter(shim["alpha_viewdirs"], shim["alpha_ray_id"], shim["alpha_dist"], shim["alpha_sdf"],
+                                                 shim["alpha_grad"], s_val)
+        assert torch.equal(got, shim[f"alpha_{tag}"])
+        assert float(got.max()) == 1.0 and float(got.min()) < 2e-5         # the vector spans the whole range
+
+
+def test_sdf_taps_match_the_reference(oracle, shim):
+    """model/nerf.py:597-637 (sample_sdfs: 6 K clamped axis taps, 3 K tap differences, optional normalisation) and :639-672
+    (grid_sampler with sample_grad: value, xyz-ordered gradient and taps)."""
+    args = (shim["taps_pts"], shim["taps_grid"], shim["taps_lo"], shim["taps_hi"], shim["taps_voxel_size"])
+    for tag, norm in (("k4", True), ("k4_raw", False), ("k1", False)):
+        feat, grad = oracle.sample_sdfs(*args, shim[f"taps_disp_{tag}"].tolist(), use_grad_norm=norm)
+        assert torch.equal(feat, shim[f"taps_feat_{tag}"]), tag
+        assert torch.equal(grad, shim[f"taps_grad_{tag}"]), tag
+    val, grad, feat = oracle.grid_sampler_ret_grad(*args)
+    assert torch.equal(val, shim["gs_val"]) and torch.equal(grad, shim["gs_grad_xyz"]) and torch.equal(feat, shim["gs_feat_xyz"])

@@ -152,3 +152,17 @@ def test_normal_and_orientation_loss_match_reference(dev, ref):
                ray_id=torch.arange(M, dtype=torch.int64, device=dev))
     loss = fused_render_losses(res, z3, dict(weight_main=0.0, weight_orientation=1.0))
     assert abs(float(loss) - float(ref["ori_loss"])) <= 2e-6 * abs(float(ref["ori_loss"]))
+
+
+def test_sdf_tap_kernels_match_reference_sample_sdfs(dev, golden):
+    """fgs_sdf_taps_fwd (render.sample_sdfs) == nerf.sample_sdfs of the reference (model/nerf.py:597-637, executed with
+    Tensor.cuda as the identity: tests/golden/ref_fns_cuda_shim.npz): 6 K clamped taps and 3 K (normalised) differences for
+    K = 4 and K = 1, points on the faces and outside the box included."""
+    from fgs_nerf_amd.render import sample_sdfs
+    g = golden("ref_fns_cuda_shim.npz")
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    for tag, norm in (("k4", True), ("k4_raw", False), ("k1", False)):
+        feat, grad = sample_sdfs(T("taps_pts"), T("taps_grid"), T("taps_lo"), T("taps_hi"), float(g["taps_voxel_size"]),
+                                 g[f"taps_disp_{tag}"].tolist(), use_grad_norm=norm)
+        assert rel_l2(feat.cpu(), torch.from_numpy(g[f"taps_feat_{tag}"])) < 1e-6, tag
+        assert rel_l2(grad.cpu(), torch.from_numpy(g[f"taps_grad_{tag}"])) < 5e-6, tag
