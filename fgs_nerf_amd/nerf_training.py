@@ -193,6 +193,33 @@ class TrainStepper:
         self._bind_averager()                            # new grids, new optimizer
         return True
 
+    def _update_tables(self):
+        return (self.cfg_train.get('decay_step_module', {}), self.cfg_train.get('tv_updates', {}),
+                self.cfg_model.get('s_updates', {}), self.cfg_model.get('smooth_updates', {}))
+
+    def _has_table_update(self, global_step: int) -> bool:
+        return any((global_step - 1) in t for t in self._update_tables())
+
+    def _apply_table_updates(self, global_step: int) -> None:
+        """The entries the reference applies at the END of iteration `global_step` (keyed by global_step - 1,
+        model/nerf_training.py:431-456): per-module lr factors, TV-term updates, s_val schedule and smoothing-kernel updates."""
+        model, ct, opt = self.model, self.cfg_train, self.optimizer
+        g_ = global_step - 1
+        dsm, tvu, su, smu = self._update_tables()
+        if g_ in dsm:
+            for group in opt.param_groups:
+                if group['name'] in dsm[g_]:
+                    group['lr'] = group['lr'] * dsm[g_][group['name']]
+        if g_ in tvu:
+            terms = dict(ct.get('tv_terms', {}))
+            terms.update(tvu[g_])
+            ct['tv_terms'] = terms
+        if g_ in su:
+            for k, v in su[g_].items():
+                setattr(model, k, v)
+        if g_ in smu:
+            model.init_smooth_conv(**smu[g_])
+
     def step(self, global_step: int) -> torch.Tensor:
         model, ct = self.model, self.cfg_train
         self._maybe_rescale(global_step)
@@ -263,32 +290,18 @@ class TrainStepper:
         f = lr_decay_factor(ct, global_step)
         for group in opt.param_groups:
             group['lr'] = group['lr'] * f
-        dsm = ct.get('decay_step_module', {})
-        if g_ in dsm:
-            for group in opt.param_groups:
-                if group['name'] in dsm[g_]:
-                    group['lr'] = group['lr'] * dsm[g_][group['name']]
-        tvu = ct.get('tv_updates', {})
-        if g_ in tvu:
-            terms = dict(ct.get('tv_terms', {}))
-            terms.update(tvu[g_])
-            ct['tv_terms'] = terms
-        su = self.cfg_model.get('s_updates', {})
-        if g_ in su:
-            for k, v in su[g_].items():
-                setattr(model, k, v)
-        smu = self.cfg_model.get('smooth_updates', {})
-        if g_ in smu:
-            model.init_smooth_conv(**smu[g_])
+        self._apply_table_updates(global_step)
         return loss
 
     # ------------------------------------------------------------------------------------------------ captured windows
     def run_captured(self, first_step: int, n_steps: int, capacity: Optional[int] = None):
-        """Iterations first_step .. first_step + n_steps - 1 of the fine stage as hipGraph replays
-        (graph_step.CapturedFineStep): one capture, then per iteration a batch gather + one graph launch, nothing read by the
-        host.  Equivalent to calling `step()` for each of them, for windows in which the iteration's SHAPE does not change:
-        no grid rescale, no voxel increment, no `ori_tv` terms, no `decay_step_module` / `tv_updates` / `s_updates` /
-        `smooth_updates` entry inside it, one GPU.  Iterations with and without the TV schedule active (sdf TV add-grad +
+        """Iterations first_step .. first_step + n_steps - 1 of a stage (fine, coarse, geometry_searching) as hipGraph replays
+        (graph_step.CapturedFineStep): per iteration a batch gather + one graph launch, nothing read by the host.  Equivalent
+        to calling `step()` for each of them, one GPU.  The window is cut -- and captured anew -- wherever an iteration changes
+        what the graphs were built from: a `pg_scale` rescale, a `decay_step_module` / `tv_updates` / `s_updates` /
+        `smooth_updates` entry.  `ori_tv` (the coarse stages' autograd TV terms, every iteration in the shipped configs) is part of
+        the captured iteration.  Only the voxel-increment phase (`voxel_inc`, global_step <= inc_steps: a new mask per
+        iteration) and a TV term on k0 are refused.  Iterations with and without the TV schedule active (sdf TV add-grad +
         the autograd smooth-gradient TV term, every `tv_every`-th iteration) are two graphs over the same state.  The learning-rate decay (model/nerf_training.py:389-436) and the NeuS s_val schedule
         become rows of the device-resident table.  Returns (losses [n_steps] device tensor, overflowed: bool); on overflow
         (more survivors than `capacity` in some iteration: that iteration's update was skipped) the caller re-runs with a
@@ -297,18 +310,23 @@ class TrainStepper:
         # grids are rescaled and the optimizer re-created exactly as step() does at the head of that iteration, and the rest of
         # the window is captured anew (one warm-up pass + one capture per cut: ~1 s, against thousands of iterations between
         # two cuts in the shipped configs: model/nerf_training.py:244-253, config/shiny_blender.py:203-204).
+        # The same holds for an iteration with an end-of-iteration table entry (decay_step_module, tv_updates, s_updates,
+        # smooth_updates: they change learning rates, loss terms or the schedule the device table was built from): it becomes
+        # the LAST iteration of its window, the entry is applied as step() applies it, the next window is captured on the result.
         ct = self.cfg_train
         end = first_step + n_steps
-        cuts = [first_step] + [g for g in range(first_step + 1, end) if g in ct.get('pg_scale', [])] + [end]
-        if len(cuts) > 2 or first_step in ct.get('pg_scale', []):
-            losses, overflow = [], False
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                rescaled = self._maybe_rescale(a)
-                l, o = self._run_captured_window(a, b - a, None if (rescaled or a != first_step) else capacity)
-                losses.append(l)
-                overflow = overflow or o
-            return torch.cat(losses), overflow
-        return self._run_captured_window(first_step, n_steps, capacity)
+        starts = sorted({first_step} | {g for g in range(first_step + 1, end)
+                                        if g in ct.get('pg_scale', []) or self._has_table_update(g - 1)})
+        cuts = starts + [end]
+        losses, overflow = [], False
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            rescaled = self._maybe_rescale(a)
+            l, o = self._run_captured_window(a, b - a, capacity if (a == first_step and not rescaled) else None)
+            losses.append(l)
+            overflow = overflow or o
+            if self._has_table_update(b - 1):
+                self._apply_table_updates(b - 1)
+        return (torch.cat(losses) if len(losses) > 1 else losses[0]), overflow
 
     def _run_captured_window(self, first_step: int, n_steps: int, capacity: Optional[int] = None):
         """One capture, n_steps replays (see run_captured); no shape-changing iteration inside."""
@@ -316,16 +334,19 @@ class TrainStepper:
         from .graph_step import CapturedFineStep
         model, ct, opt = self.model, self.cfg_train, self.optimizer
         steps = range(first_step, first_step + n_steps)
-        if self.stage != 'fine' or not fused.supports(model) or self.averager is not None:
-            raise RuntimeError("run_captured covers the fused fine stage on one GPU")
-        if ct.get('voxel_inc', False) or ct.get('ori_tv', False):
-            raise RuntimeError("run_captured: voxel_inc / ori_tv iterations change shape from step to step; use step()")
+        covered = fused.supports(model) if self.stage == 'fine' else fused.supports_coarse(model)
+        if not covered or self.averager is not None:
+            raise RuntimeError("run_captured covers the fused paths (fine, coarse, geometry_searching) on one GPU")
+        if ct.get('voxel_inc', False):
+            if any(g <= ct.inc_steps for g in steps):
+                raise RuntimeError("run_captured: the voxel-increment phase (global_step <= inc_steps) rebuilds the increment mask "
+                                   "every iteration; use step() for it")
+        else:
+            model.unset_inc_mask()
         if any(g in ct.get('pg_scale', []) for g in list(steps)[1:]):
             raise RuntimeError("_run_captured_window: pg_scale inside the window (run_captured cuts windows there)")
-        for key, cfg in (('decay_step_module', ct), ('tv_updates', ct), ('s_updates', self.cfg_model),
-                         ('smooth_updates', self.cfg_model)):
-            if any((g - 1) in cfg.get(key, {}) for g in steps):
-                raise RuntimeError(f"run_captured: a {key} entry falls inside the window")
+        if any(self._has_table_update(g) for g in list(steps)[:-1]):
+            raise RuntimeError("_run_captured_window: a table update inside the window (run_captured cuts windows there)")
         # Iterations come in (at most) two shapes: plain ones, and those in which the TV schedule is active -- the sdf TV
         # add-grad after the backward pass and the autograd smooth-gradient TV term added to the loss (:330-371; every
         # `tv_every`-th iteration in the shipped configs).  One captured graph per shape, chosen per iteration.
@@ -336,13 +357,21 @@ class TrainStepper:
         dense = {g < ct.get('tv_dense_before', 0) for g, on in zip(steps, tv_flags) if on}
         if len(dense) > 1:
             raise RuntimeError("run_captured: tv_dense_before falls inside the window")
+        # the TV schedule of an active iteration, as step() issues it: autograd terms added to the loss (:330-345: the smooth-gradient
+        # term always, the sdf TV term under `ori_tv`), the sdf TV add-grad after the backward pass otherwise (:353-371)
         tv, extra = None, None
+        ori_tv = bool(ct.get('ori_tv', False))
         if any(tv_flags) and ct.get('weight_tv_density', 0) > 0:
-            if tv_terms.get('sdf_tv', 0) > 0:
-                tv = (ct.weight_tv_density * tv_terms.sdf_tv / ct.N_rand, dense.pop())
-            if tv_terms.get('smooth_grad_tv', 0) > 0:
-                w_tv, s_tv = ct.weight_tv_density, tv_terms.smooth_grad_tv
-                extra = lambda m: w_tv * m.density_total_variation(sdf_tv=0, smooth_grad_tv=s_tv)   # noqa: E731
+            w_tv, sdf_tv, s_tv = ct.weight_tv_density, tv_terms.get('sdf_tv', 0), tv_terms.get('smooth_grad_tv', 0)
+            if sdf_tv > 0 and not ori_tv:
+                tv = (w_tv * sdf_tv / ct.N_rand, dense.pop())
+            pieces = []
+            if s_tv > 0:
+                pieces.append(lambda m: m.density_total_variation(sdf_tv=0, smooth_grad_tv=s_tv))
+            if ori_tv and sdf_tv > 0:
+                pieces.append(lambda m: m.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0))
+            if pieces:
+                extra = lambda m: w_tv * sum(f(m) for f in pieces)   # noqa: E731
         variants = [dict(tv=None, extra_loss=None)]
         tv_variant = 0
         if tv is not None or extra is not None:

@@ -135,8 +135,12 @@ def test_stepper_captured_window_matches_step_by_step(dev):
     assert not overflow and bool(torch.isfinite(losses).all())
     # windows the captured form does not cover are refused, not silently mis-run
     model = synth.build_model(32, synth.FINE_MODEL, device=dev)
-    st = nt.TrainStepper(model, dict(cfg, ori_tv=True), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
-    with pytest.raises(RuntimeError):
+    st = nt.TrainStepper(model, dict(cfg, voxel_inc=True, inc_steps=100, x_mid=0.5, y_mid=0.5, z_mid=0.5, x_init_ratio=0.2,
+                                      y_init_ratio=0.2, z_init_ratio=0.2), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
+    with pytest.raises(RuntimeError, match="voxel-increment"):
+        st.run_captured(1, 6)                      # the increment mask is rebuilt every iteration up to inc_steps
+    st = nt.TrainStepper(model, dict(cfg, weight_tv_k0=0.1), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
+    with pytest.raises(RuntimeError, match="k0"):
         st.run_captured(1, 6)
 
 
@@ -337,3 +341,44 @@ def test_inline_early_k0_update_matches_the_update_in_step(dev, captured):
     for pa, pb in zip(runs[False][1], runs[True][1]):
         assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 5e-3
     assert runs[False][2] == runs[True][2] and set(runs[True][2]) == {ITERS}
+
+
+def test_captured_coarse_window_with_ori_tv_and_table_updates_matches_step_by_step(dev):
+    """The shipped COARSE-stage loop body (config/shiny_blender.py:105-146): `ori_tv` autograd TV terms every iteration, a
+    `tv_updates` entry, a `decay_step_module` entry and a `pg_scale` rescale inside the window.  run_captured cuts the window at
+    each of them, applies what step() applies, and captures the rest anew: same losses, parameters, learning rates and TV terms
+    as step() iteration by iteration."""
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    cfg = dict(N_iters=15000, N_rand=512, lrate_k0=0.1, lrate_sdf=0.005, lrate_refnet=1e-3, lrate_decay=20,
+               ray_sampler='flatten', weight_main=1.0, weight_entropy_last=0.001, weight_rgbper=0.2, weight_tv_density=0.01,
+               weight_tv_k0=0.0, sigmoid_rgb_loss=0.1, weight_orientation=1e-4, tv_every=1, tv_from=0, tv_end=40000,
+               voxel_inc=False, pg_scale=[904], scale_ratio=2.0, reset_iter=[], ori_tv=True,
+               tv_terms=dict(sdf_tv=0.1, smooth_grad_tv=0.05), tv_updates={901: dict(sdf_tv=0.2)},
+               decay_step_module={902: dict(sdf=0.5, k0=0.3)}, tv_dense_before=20000, cosine_lr=True,
+               cosine_lr_cfg=dict(warm_up_iters=0, const_warm_up=True, warm_up_min_ratio=1.0),
+               skip_zero_grad_fields=['density', 'k0', 'k1'])
+    R, FIRST, N = 2048, 900, 7
+    rays = tuple(r.to(dev) for r in synth.random_rays(R, seed=41))
+    target = torch.rand(R, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+    runs = {}
+    for mode in ("steps", "captured"):
+        model = synth.build_model(32, synth.COARSE_MODEL, device=dev)
+        st = nt.TrainStepper(model, dict(cfg), {}, synth.RENDER_KWARGS, target, *rays, stage='coarse', seed=17)
+        if mode == "steps":
+            losses = torch.stack([st.step(g).detach() for g in range(FIRST, FIRST + N)])
+        else:
+            losses, overflow = st.run_captured(FIRST, N)
+            assert not overflow
+        torch.cuda.synchronize()
+        runs[mode] = (losses.cpu(), [p.detach().clone() for p in model.parameters()], tuple(model.sdf.grid.shape),
+                      {g['name']: g['lr'] for g in st.optimizer.param_groups}, dict(st.cfg_train['tv_terms']))
+    assert runs["steps"][2] == runs["captured"][2] and runs["captured"][2][2] > 32            # rescaled at 904, identically
+    assert runs["steps"][4] == runs["captured"][4] and runs["captured"][4]['sdf_tv'] == 0.2  # the tv_updates entry was applied
+    for k, v in runs["steps"][3].items():
+        assert abs(v - runs["captured"][3][k]) <= 1e-12 * abs(v), k                          # lr schedule incl. decay_step_module
+    la, lb = runs["steps"][0], runs["captured"][0]
+    assert la.shape == lb.shape == (N,)
+    assert float(((la - lb) / la).abs().max()) < 2e-3, (la, lb)
+    for pa, pb in zip(runs["steps"][1], runs["captured"][1]):
+        assert pa.shape == pb.shape and float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 1e-2
