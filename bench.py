@@ -413,9 +413,17 @@ def main():
         # Several ranks: a capture that fails on ANY rank (the capture pass itself issues no collective, so a failure is local
         # and leaves the others unharmed) sends ALL ranks to the eager form below -- decided by one MIN all-reduce, so that
         # no rank replays a graph whose collectives the others never launch.
+        # In-kernel timing of the matrix-core launches (fgs_dyn_t.stamps): the captured launches write their workgroups' wall-clock
+        # start / end into the slot the step counter selects -- the roofline figure then comes from the timed replays themselves.
+        from fgs_nerf_amd import fused_ops as _fo
+        stamp_buf, stamp_launches = None, None
+        if rank == 0 and not args.composed and os.environ.get("FGS_BENCH_STAMPS", "1") == "1":
+            stamp_buf = torch.zeros(max(args.steps, 1), _fo.STAMP_LAUNCHES, _fo.STAMP_WORDS, dtype=torch.int64, device=dev)
+            _fo.STAMPS["buf"], _fo.STAMPS["counter"] = stamp_buf, captured.counter
         capture_ok = 1
         try:
             captured.capture(batches[0])
+            stamp_launches = list(_fo.STAMPS["launches"])
         except Exception as e:        # noqa: BLE001
             if world == 1 and not force_dist:
                 raise
@@ -434,7 +442,10 @@ def main():
                 captured.replay(packed[i % N_BATCHES])
             torch.cuda.synchronize()
             captured.clear_counters()
+            if stamp_buf is not None:
+                stamp_buf.zero_()
         else:
+            _fo.STAMPS["buf"] = None
             captured.release()
             captured, use_graph = None, False
             from fgs_nerf_amd import fused as _f
@@ -495,6 +506,7 @@ def main():
     digest_after = _digest()          # (device scalars, compared at the very end: a host read here would let the GPU idle -- and
                                       #  its clock drop -- in front of the profiling steps that follow)
     roofline_note = "HIP events on the launch stream immediately around every MLP matrix-core launch in the timed region"
+    stamped = None
     if sync_free_eager:
         from fgs_nerf_amd import fused as _fused
         overflow, total = _fused.sync_free_state(model)
@@ -514,17 +526,26 @@ def main():
                   file=sys.stderr, flush=True)
             STEP_STATS["overflow"] = True
         survivors_timed = total
-        # A graph replay cannot carry timing events around individual kernels: the MLP kernels are timed right behind the
-        # timed region, in the same process on the same model and batches, by PROFILE_STEPS eager steps of the same loop
-        PROFILE_STEPS = 10
-        fused.set_profiling(rank == 0, clear=True)
-        for i in range(PROFILE_STEPS):
-            train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
-        torch.cuda.synchronize()
-        fused.set_profiling(False)
-        STEP_STATS["survivors"] = survivors_timed        # (the profiling steps above counted theirs)
-        roofline_note = (f"HIP events on the launch stream immediately around every MLP matrix-core launch, in {PROFILE_STEPS} eager steps "
-                         "of the same loop run right behind the timed region (graph replays cannot carry timing events)")
+        if stamp_buf is not None and stamp_launches:
+            # the timed replays timed their own matrix-core launches (a graph replay cannot carry HIP events around a kernel):
+            # min(start) .. max(end) over each launch's workgroups, 100 MHz wall clock, one reading per launch and replay
+            stamped = _fo.stamps_read(stamp_buf, stamp_launches)
+            _fo.STAMPS["buf"] = None
+            roofline_note = (f"in-kernel wall-clock readings (s_memrealtime, 100 MHz; fgs_dyn_t.stamps) of every MLP matrix-core launch of "
+                             f"the {args.steps} hipGraph replays of the timed region itself: first workgroup's start to last workgroup's end")
+            STEP_STATS["survivors"] = survivors_timed
+        else:
+            # without the stamps: the MLP kernels are timed right behind the timed region, in the same process on the same model
+            # and batches, by PROFILE_STEPS eager steps of the same loop
+            PROFILE_STEPS = 10
+            fused.set_profiling(rank == 0, clear=True)
+            for i in range(PROFILE_STEPS):
+                train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
+            torch.cuda.synchronize()
+            fused.set_profiling(False)
+            STEP_STATS["survivors"] = survivors_timed        # (the profiling steps above counted theirs)
+            roofline_note = (f"HIP events on the launch stream immediately around every MLP matrix-core launch, in {PROFILE_STEPS} eager steps "
+                             "of the same loop run right behind the timed region (graph replays cannot carry timing events)")
 
     stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -581,7 +602,9 @@ def main():
         if sync_free_eager:
             cap_rows = model._fused_cache['sync_free']['capacity'] * max(args.steps, 1)
             flop_scale = STEP_STATS["survivors"] / max(cap_rows, 1)
-        line["roofline"] = fused.roofline_report(pmc, flop_scale)
+        if stamped is not None:       # (captured launches were issued for the CAPACITY too)
+            flop_scale = STEP_STATS["survivors"] / max(captured.capacity * max(args.steps, 1), 1)
+        line["roofline"] = fused.roofline_report(pmc, flop_scale, stamped=stamped)
         if line["roofline"] is not None:
             line["roofline"]["timing"] = roofline_note
         if line["roofline"] is not None and args.stage == "fine":

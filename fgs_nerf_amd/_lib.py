@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -131,16 +131,21 @@ class WgradItem(ctypes.Structure):
 
 class Dyn(ctypes.Structure):
     """fgs_dyn_t (include/fgs_hip.h): the device-resident values a launch may read instead of its host arguments."""
-    _fields_ = [("row_count", c_void_p), ("inv_s", c_void_p), ("dx0_compact", c_int)]
+    _fields_ = [("row_count", c_void_p), ("inv_s", c_void_p), ("dx0_compact", c_int),
+                ("stamps", c_void_p), ("stamp_step", c_void_p), ("stamp_slots", c_int64), ("stamp_stride", c_int64)]
 
 
-def dyn(row_count=None, inv_s=None, compact: bool = False):
+def dyn(row_count=None, inv_s=None, compact: bool = False, stamps=None):
     """`const fgs_dyn_t *` argument for the entry points that take one: None (NULL) when nothing is device-resident, else a
     pointer to a struct holding the raw device addresses (ints) of the survivor count / NeuS 1/s and the compact-dX0 flag.
+    `stamps`: (address of this launch's region in slot 0, address of the device step counter or None, slots, stride in uint64)
+    -- the in-kernel wall-clock stamps of the matrix-core launches (measurement only).
     The C side copies the members into its kernel arguments before it returns: the struct need not outlive the call."""
-    if row_count is None and inv_s is None and not compact:
+    if row_count is None and inv_s is None and not compact and stamps is None:
         return None
-    return ctypes.byref(Dyn(row_count, inv_s, int(bool(compact))))
+    if stamps is None:
+        return ctypes.byref(Dyn(row_count, inv_s, int(bool(compact)), None, None, 0, 0))
+    return ctypes.byref(Dyn(row_count, inv_s, int(bool(compact)), stamps[0], stamps[1], int(stamps[2]), int(stamps[3])))
 
 
 class FgsError(RuntimeError):

@@ -35,6 +35,27 @@ static inline const int64_t *fgs_dyn_rows(const fgs_dyn_t *d) { return d ? d->ro
 static inline const float *fgs_dyn_inv_s(const fgs_dyn_t *d) { return d ? d->inv_s : nullptr; }
 static inline int fgs_dyn_compact(const fgs_dyn_t *d) { return d ? d->dx0_compact : 0; }
 
+// In-kernel wall-clock stamps of a launch (fgs_dyn_t.stamps: measurement only).
+struct FgsStamps {
+  unsigned long long *p;
+  const int64_t *step;
+  int64_t slots, stride;
+};
+static inline FgsStamps fgs_dyn_stamps(const fgs_dyn_t *d, unsigned long long *fallback = nullptr) {
+  FgsStamps s;
+  s.p = (d && d->stamps) ? d->stamps : fallback;
+  s.step = (d && d->stamps) ? d->stamp_step : nullptr;
+  s.slots = (d && d->stamps && d->stamp_slots > 0) ? d->stamp_slots : 1;
+  s.stride = (d && d->stamps) ? d->stamp_stride : 0;
+  return s;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long *fgs_stamp_base(const FgsStamps &s) {
+  if (!s.p) return nullptr;
+  return s.step ? s.p + (*s.step % s.slots) * s.stride : s.p;
+}
+#endif
+
 constexpr int FGS_WAVE = 64;      // gfx950 wavefront
 constexpr int FGS_BLOCK = 256;    // 4 waves: one per SIMD of a CU
 constexpr int64_t FGS_MAX_ELEMS = (int64_t)1 << 40;

@@ -41,6 +41,7 @@ struct GemmArgs {
   float *colsum;              // NT/NN: if non-null, colsum[n] += sum_m C[m,n] (after the epilogue) -> bias gradients
   int64_t k_per_split;        // TN: reduction rows handled by one workgroup (multiple of BK)
   int tiles_m, tiles_n;
+  FgsStamps stamps;           // fgs_dyn_t.stamps (k_gemm only): {~min start, max end} of the launch's workgroups, 100 MHz wall clock
 };
 
 enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
@@ -375,7 +376,14 @@ template <bool A_KC, bool B_KC, int EPI, bool CLAMP = false, bool NARROW = false
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) LdsImage lds;
   if (EPI != EPI_ATOMIC) g.M = fgs_rows(g.M, g.m_dev);       // row tiles beyond the device-side count return at once
+  unsigned long long *const stamps = fgs_stamp_base(g.stamps);
+  if (stamps && threadIdx.x == 0) atomicMax(stamps, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   gemm_block<A_KC, B_KC, EPI, CLAMP, NARROW>(g, (int)blockIdx.x, lds);
+  if (stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(stamps + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
 }
 
 // Backward of one Linear layer in ONE launch: the data-gradient product (NN, store epilogue with ReLU mask / column sums)
@@ -546,6 +554,7 @@ GemmArgs make_args(int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
   g.bias = bias; g.relu = relu; g.mask = mask; g.ldm = ldm; g.colsum = colsum; g.k_per_split = 0;
   g.tiles_m = (int)((M + BM - 1) / BM);
   g.tiles_n = (int)((N + BN - 1) / BN);
+  g.stamps = fgs_dyn_stamps(nullptr);
   return g;
 }
 
@@ -584,6 +593,7 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
     FGS_REQUIRE(!colsum, FGS_E_INVALID, "fgs_gemm_f32: colsum is not available under fgs_set_row_count_ptr");
     g.m_dev = fgs_dyn_rows(dyn);
   }
+  g.stamps = fgs_dyn_stamps(dyn);
   if (op != FGS_GEMM_TN && workspace) {
     // the caller asked for stream-K (by passing a workspace); used when it can balance: more than a handful of tiles,
     // a K loop worth cutting, every range non-empty

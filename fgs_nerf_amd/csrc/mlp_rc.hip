@@ -80,7 +80,7 @@ struct RcArgs {
   int64_t M;
   const int64_t *m_dev;
   int n_layers, total_chunks;
-  unsigned long long *stamps;              // diagnostics (fgs_mlp_rc_debug_stamps): per workgroup {s_memtime, s_memrealtime} x 2
+  FgsStamps stamps;                        // fgs_dyn_t.stamps / fgs_mlp_rc_debug_stamps: per workgroup {s_memtime, s_memrealtime} x 2
   const float *img;
   int64_t sink_off;                        // floats from img to the sink (RC_SINK_FLOATS of them)
   // (chunk j of the stream starts at 1 KB piece j * 4 NTT of the image and has 4 NTT pieces: every layer of a launch has the
@@ -443,16 +443,17 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   const int64_t nb = (M + RC_BLOCK - 1) / RC_BLOCK;
   if ((int64_t)blockIdx.x >= nb) return;
   const int64_t my_blocks = (nb - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  if (a.stamps && tid == 0) {
-    a.stamps[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    a.stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long *const stamps = fgs_stamp_base(a.stamps);
+  if (stamps && tid == 0) {
+    stamps[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+    stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   }
   RcState s;
   s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = __builtin_amdgcn_readfirstlane((int)(my_blocks * a.total_chunks));
   s.issue_j = 0; s.issue_slot = 0; s.slot = 0; s.wave = wave; s.lane = lane; s.done = 0; s.total_chunks = a.total_chunks;
   s.dma_p = 0; s.dma_pieces = 0; s.dma_src = a.img; s.dma_lane = (unsigned)lane * 16u; s.dma_dst = ring;
   s.pend_row = nullptr; s.pend_on = 0; s.sink = const_cast<float *>(a.img) + a.sink_off;
-  s.timed = RC_PHASES && a.stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
+  s.timed = RC_PHASES && stamps != nullptr; s.t_init = s.t_chunks = s.t_epi = s.t_load = 0;
   rc_dma<NTT>(s);
   if (s.total_steps > 1) rc_dma<NTT>(s);
   {   // bias table -> LDS, once (a layer's epilogue then reads 16 bytes per output group instead of waiting on HBM)
@@ -519,11 +520,11 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (a.stamps && tid == 0) {
-    a.stamps[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    a.stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-    a.stamps[8 * blockIdx.x + 4] = s.t_init; a.stamps[8 * blockIdx.x + 5] = s.t_chunks;
-    a.stamps[8 * blockIdx.x + 6] = s.t_epi; a.stamps[8 * blockIdx.x + 7] = s.t_load;
+  if (stamps && tid == 0) {
+    stamps[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    stamps[8 * blockIdx.x + 4] = s.t_init; stamps[8 * blockIdx.x + 5] = s.t_chunks;
+    stamps[8 * blockIdx.x + 6] = s.t_epi; stamps[8 * blockIdx.x + 7] = s.t_load;
   }
 }
 
@@ -569,7 +570,7 @@ FGS_API int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc
               (long long)image_ws_floats, (long long)need);
   RcArgs a;
   PackArgs p;
-  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.n_layers = n_layers; a.img = image_ws; a.stamps = g_rc_stamps;
+  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.n_layers = n_layers; a.img = image_ws; a.stamps = fgs_dyn_stamps(dyn, g_rc_stamps);
   p.n_layers = n_layers; p.transpose = backward ? 1 : 0; p.img = image_ws;
   int carried = in0_cols;            // columns of the input carried in registers
   int64_t base = 0, f4 = 0;

@@ -54,7 +54,7 @@ struct WgBlock {
 struct WgArgs {
   int64_t M;
   const int64_t *m_dev;
-  unsigned long long *stamps;     // diagnostics (fgs_mlp_wgrad_debug_stamps): 8 words per workgroup
+  FgsStamps stamps;               // fgs_dyn_t.stamps / fgs_mlp_wgrad_debug_stamps: 8 words per workgroup
   int n_blocks;
   WgBlock B[WG_MAXBLK];
 };
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
   const WgBlock &b = a.B[blk];
   const int j = (int)blockIdx.x - b.wg0;
   if (j >= b.n_wg) return;
-  unsigned long long *stamps = a.stamps ? a.stamps + 8 * blockIdx.x : nullptr;
+  unsigned long long *stamps = fgs_stamp_base(a.stamps);
+  if (stamps) stamps += 8 * blockIdx.x;
   if (stamps && threadIdx.x == 0) {
     stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)blk;
   }
@@ -327,8 +328,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
     case 1: wgrad_block<1>(b, M, j, lds, stamps); break;
     default: wgrad_block<0>(b, M, j, lds, stamps); break;
   }
-  if (stamps && threadIdx.x == 0) {       // (the atomics of the flush have been ISSUED here, not necessarily performed)
-    stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime();
+  if (stamps) {                           // (every lane's flush atomics performed, not merely issued, before the end stamp)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) { stamps[4] = __builtin_amdgcn_s_memtime(); stamps[5] = __builtin_amdgcn_s_memrealtime(); }
   }
 }
 
@@ -371,7 +374,7 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
   if (M == 0) return 0;
   FGS_REQUIRE(items, FGS_E_INVALID, "fgs_mlp_wgrad: null pointer");
   WgArgs a;
-  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.stamps = g_wg_stamps;
+  a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.stamps = fgs_dyn_stamps(dyn, g_wg_stamps);
   int nb = 0, cost_total = 0;
   int cost[WG_MAXBLK];
   for (int i = 0; i < n_items; ++i) {

@@ -152,6 +152,8 @@ class _gemm_group:
 def _gemm(op, A, B, C, M, N, K, logical=None, **kw):
     """`logical` = un-padded (M, N, K) of the product, for the algorithmic FLOP count of the roofline report."""
     lm, ln, lk = logical or (M, N, K)
+    if _MLP_IMPL == "rc":
+        kw = dict(kw, stamp=("k_gemm (first-layer data gradients)", 2.0 * lm * ln * lk))   # (fused_ops.STAMPS, when on)
     if _MLP_IMPL == "rc" and fo.TIMING["enabled"]:      # the rc path times every launch on its own (fused_ops._timed)
         fo._timed("k_gemm (first-layer data gradients)", 2.0 * lm * ln * lk, lambda: fo.gemm(op, A, B, C, M, N, K, **kw))
         return
@@ -591,23 +593,30 @@ def _setup_run(model, rays_o, rays_d, viewdirs, global_step, render_kwargs, defa
     return run, s_val
 
 
-def roofline_report(pmc=None, flop_scale: float = 1.0):
+def roofline_report(pmc=None, flop_scale: float = 1.0, stamped=None):
     """Achieved fp32 FLOP/s of the dominant kernels -- the MLP matrix-core kernels: k_mlp_rc (register-resident forward chain
     and backward data-gradient chain, one launch each), k_mlp_wgrad (all weight / bias gradients, one launch), k_gemm (the two
     first-layer data gradients) -- from the HIP events recorded around every uninterrupted run of them, against the gfx950
     fp32 matrix-core peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, v_mfma_f32_32x32x2_f32 at 256 FLOP/clk/CU, 2.4 GHz).
     `pmc`: bench.pmc_traffic_live()'s per-kernel HBM bytes (or None / {'error': ...}): `traffic` is then the mean over the
     launches of one step, measured in this run; without it `traffic` is null (never a number from another run)."""
-    ev = PROFILE["gemm_events"] + fo.TIMING["events"]
+    if stamped is not None:
+        # fused_ops.stamps_read(): the launches of a captured step timed by their own workgroups (wall-clock readings), one
+        # duration per replay of the timed region
+        ev = [(None, None, None, label.replace(" (+ k_rc_pack)", ""), len(durs), fl * len(durs), sum(durs) * 1e3)
+              for label, fl, durs in stamped if durs]
+    else:
+        ev = [e + (None,) for e in PROFILE["gemm_events"] + fo.TIMING["events"]]
     if not ev:
         return None
     per = {}
     tot_ms, tot_fl, tot_n = 0.0, 0.0, 0
-    for e0, e1, e1s, label, n, fl in ev:
+    for e0, e1, e1s, label, n, fl, ms in ev:
         fl = fl * flop_scale
-        ms = e0.elapsed_time(e1)
-        if e1s is not None:
-            ms = max(ms, e0.elapsed_time(e1s))
+        if ms is None:
+            ms = e0.elapsed_time(e1)
+            if e1s is not None:
+                ms = max(ms, e0.elapsed_time(e1s))
         d = per.setdefault(label, [0, 0.0, 0.0])
         d[0] += n
         d[1] += ms

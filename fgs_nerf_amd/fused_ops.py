@@ -26,18 +26,20 @@ def gemm_workspace(device: torch.device) -> torch.Tensor:
 
 
 def gemm(op: int, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, bias=None, relu=False,
-         mask=None, colsum=None, stream_k: bool = False, rows_dev=None) -> torch.Tensor:
+         mask=None, colsum=None, stream_k: bool = False, rows_dev=None, stamp=None) -> torch.Tensor:
     """C = op(A, B) with the epilogues of include/fgs_hip.h fgs_gemm_f32.  A, B, C, mask are 2-D row-major views
     (stride(1) == 1); leading dimensions are taken from stride(0).  `stream_k` selects the opt-in stream-K grid for
     NT / NN (measured: no faster than one tile per workgroup at the MLP shapes, see csrc/gemm_f32.hip).  `rows_dev`: device address of the
-    actual row count (NT / NN: M is then the capacity of A and C; fgs_dyn_t.row_count)."""
+    actual row count (NT / NN: M is then the capacity of A and C; fgs_dyn_t.row_count).  `stamp`: (label, flop) -- the launch
+    takes part in the in-kernel timing of a step (STAMPS)."""
     for t in (A, B, C) + ((mask,) if mask is not None else ()):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
             raise RuntimeError("gemm operands must be 2-D float32 CUDA tensors with unit column stride")
     ws = gemm_workspace(C.device) if (stream_k and op != GEMM_TN) else None
     call("fgs_gemm_f32", op, M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(C), C.stride(0), ptr(bias),
          int(bool(relu)), ptr(mask), 0 if mask is None else mask.stride(0), ptr(colsum), ptr(ws),
-         0 if ws is None else ws.numel(), dyn(row_count=rows_dev), stream())
+         0 if ws is None else ws.numel(),
+         dyn(row_count=rows_dev, stamps=None if stamp is None else _stamp_arg(stamp[0], stamp[1], "gemm")), stream())
     return C
 
 
@@ -129,6 +131,64 @@ _RC_IMAGES = {}   # (device index, stream handle, backward) -> packed-weight scr
 TIMING = {"enabled": False, "events": []}
 
 
+# The same figure from INSIDE a captured step, whose replays cannot carry events: while STAMPS["buf"] is set, every matrix-core
+# launch is handed a region of it (fgs_dyn_t.stamps) and its workgroups write their 100 MHz wall-clock start / end readings
+# there, into the slot the device-side step counter selects -- bench.py reads the slots of the timed replays afterwards.
+#   buf      int64 tensor [slots, STAMP_LAUNCHES, STAMP_WORDS] (zeroed by the owner before the steps it wants to read)
+#   counter  device int64 the step's tick kernel advances (graph_step.CapturedFineStep.counter), or None (slot 0)
+#   launches [(label, flop, kind)] in issue order of ONE step, rebuilt by stamps_begin_step() ... the launches that follow
+STAMP_LAUNCHES, STAMP_WORDS = 8, 2048
+STAMPS = {"buf": None, "counter": None, "launches": [], "seq": 0}
+
+
+def stamps_begin_step() -> None:
+    STAMPS["seq"] = 0
+    STAMPS["launches"] = []
+
+
+def _stamp_arg(label: str, flop: float, kind: str):
+    buf = STAMPS["buf"]
+    if buf is None:
+        return None
+    seq = STAMPS["seq"]
+    if seq >= STAMP_LAUNCHES:
+        return None
+    STAMPS["seq"] = seq + 1
+    STAMPS["launches"].append((label, float(flop), kind))
+    cnt = STAMPS["counter"]
+    return (buf.data_ptr() + seq * STAMP_WORDS * 8, None if cnt is None else cnt.data_ptr(), buf.shape[0],
+            STAMP_LAUNCHES * STAMP_WORDS)
+
+
+def stamps_read(buf=None, launches=None):
+    """Per launch of a step: (label, flop, [duration in seconds of that launch in every slot that holds one]) from the wall-clock
+    readings (100 MHz: s_memrealtime): chain / weight-gradient kernels min(start) .. max(end) over their workgroups, the tiled
+    product its two atomically reduced words."""
+    buf = STAMPS["buf"] if buf is None else buf
+    launches = STAMPS["launches"] if launches is None else launches
+    host = buf.cpu().numpy().astype("uint64")
+    import numpy as np
+    out = []
+    for seq, (label, flop, kind) in enumerate(launches):
+        durs = []
+        for slot in range(host.shape[0]):
+            w = host[slot, seq]
+            if kind == "gemm":
+                if w[1] == 0:
+                    continue
+                t0, t1 = int(~w[0] & np.uint64(0xFFFFFFFFFFFFFFFF)), int(w[1])
+            else:
+                rec = w.reshape(-1, 8)
+                end = rec[:, 3] if kind == "rc" else rec[:, 5]
+                live = end != 0
+                if not live.any():
+                    continue
+                t0, t1 = int(rec[live, 1].min()), int(end[live].max())
+            durs.append((t1 - t0) / 100e6)
+        out.append((label, flop, durs))
+    return out
+
+
 def _timed(label: str, flop: float, launch) -> None:
     if not TIMING["enabled"]:
         launch()
@@ -173,9 +233,11 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, f
     ws = _RC_IMAGES.get(key)
     if ws is None or ws.numel() < need:
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
-    _timed(label or ("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)"), flop,
+    label = label or ("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)")
+    d = dyn(row_count=rows_dev, stamps=_stamp_arg(label, flop, "rc"))
+    _timed(label, flop,
            lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),
-                        in0_cols, ptr(ws), ws.numel(), dyn(row_count=rows_dev), stream()))
+                        in0_cols, ptr(ws), ws.numel(), d, stream()))
 
 
 def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:
@@ -189,5 +251,5 @@ def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:
         arr[i].dY, arr[i].ld_dy, arr[i].n_out = ptr(dY), dY.stride(0), int(n_out)
         arr[i].X, arr[i].ld_x, arr[i].n_in = ptr(X), X.stride(0), int(n_in)
         arr[i].dW, arr[i].ld_dw, arr[i].dbias = ptr(dW), dW.stride(0), ptr(db)
-    _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), dyn(row_count=rows_dev),
-                                             stream()))
+    d = dyn(row_count=rows_dev, stamps=_stamp_arg("k_mlp_wgrad", flop, "wgrad"))
+    _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), d, stream()))

@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from . import fused
+from . import fused_ops as fo
 from ._lib import call, lib, ptr, stream
 from .losses import fused_render_losses
 
@@ -176,6 +177,7 @@ class CapturedFineStep:
         # writes this iteration's s_val into the model's parameter (model/nerf.py:520 refreshes it in every forward).
         call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
              self.n_cols - 1, ptr(self.model.s_val.data), stream())
+        fo.stamps_begin_step()            # (bench.py's in-kernel timing of the matrix-core launches, when it is on)
         # (global_step only selects the training branch here: 1/s comes from the device scalars)
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)

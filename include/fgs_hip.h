@@ -35,8 +35,8 @@ typedef void *fgs_stream_t;
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
- * thread-local setters. */
-#define FGS_ABI_VERSION 4
+ * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches. */
+#define FGS_ABI_VERSION 5
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -65,6 +65,16 @@ typedef struct fgs_dyn {
   const int64_t *row_count;
   const float *inv_s;
   int dx0_compact;
+  /* Measurement only (no effect on results; NULL = off), honoured by the matrix-core entries fgs_mlp_rc_chain, fgs_mlp_wgrad and
+   * fgs_gemm_f32: the launch writes 100 MHz wall-clock readings (s_memrealtime) of its workgroups into
+   * stamps + (*stamp_step % stamp_slots) * stamp_stride (uint64 units; stamp_step NULL: slot 0) -- the chain and weight-gradient
+   * kernels 8 words per workgroup (word 1 = start, word 3 resp. 5 = end; >= 2048 words), the tiled product two words
+   * (~min start, max end, by atomicMax: zero-initialise).  A captured step thereby times its own launches: bench.py's roofline
+   * figure comes from the replays of the timed region itself (a graph replay cannot carry HIP events). */
+  unsigned long long *stamps;
+  const int64_t *stamp_step;
+  int64_t stamp_slots;
+  int64_t stamp_stride;
 } fgs_dyn_t;
 
 /* Device-resident schedule of a captured training step (model/nerf_training.py:389-436, model/adam.py:205-221).  `table` is

@@ -242,3 +242,49 @@ def test_canary_catches_the_old_pad_cols_index_expression(dev):
     from fgs_nerf_amd import fused_ops as fo
     fo.pad_cols_multi([src], [40], outs=[dst[:, 12:]])
     assert int(((canvas != 7.0) & ~inside).sum()) == 0 and torch.equal(dst[:, 12:], src)
+
+
+def test_in_kernel_stamps_time_the_launches_and_change_nothing(dev):
+    """fgs_dyn_t.stamps: the chain, weight-gradient and tiled-product launches write wall-clock readings of their workgroups into
+    the slot a device-side counter selects (bench.py times the launches of a captured step with them).  Same results as without
+    them, one plausible duration per launch and slot, nothing written outside the launch's region."""
+    from fgs_nerf_amd import fused_ops as fo
+    M = 30000
+    X0, Z, Ws, bs, relu = _fine_setup(M, dev)
+    ref_outs, _ = _forward(M, X0, Z.clone(), Ws, bs, relu, dev)
+    dY, Xa = torch.randn(M, 256, device=dev), torch.randn(M, 256, device=dev)
+    dW_ref, db_ref = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
+    fo.mlp_wgrad(M, [(dY, Xa, dW_ref, db_ref, 256, 256)])
+    Wn = torch.randn(256, 52, device=dev) * 0.05
+    C_ref = torch.empty(M, 52, device=dev)
+    fo.gemm(fo.GEMM_NN, dY, Wn, C_ref, M, 52, 256)
+
+    SLOTS = 3
+    buf = torch.zeros(SLOTS, fo.STAMP_LAUNCHES, fo.STAMP_WORDS, dtype=torch.int64, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    fo.STAMPS.update(buf=buf, counter=counter)
+    try:
+        for step in range(SLOTS):
+            counter.fill_(step + 7)                       # slot (step + 7) % 3: every slot once
+            fo.stamps_begin_step()
+            Z2 = Z.clone()
+            outs, _ = _forward(M, X0, Z2, Ws, bs, relu, dev)
+            dW, db = torch.zeros(256, 256, device=dev), torch.zeros(256, device=dev)
+            fo.mlp_wgrad(M, [(dY, Xa, dW, db, 256, 256)], flop=2.0 * M * 256 * 256)
+            C = torch.empty(M, 52, device=dev)
+            fo.gemm(fo.GEMM_NN, dY, Wn, C, M, 52, 256, stamp=("k_gemm", 2.0 * M * 52 * 256))
+        torch.cuda.synchronize()
+        launches = list(fo.STAMPS["launches"])
+        rec = fo.stamps_read()
+    finally:
+        fo.STAMPS.update(buf=None, counter=None)
+    assert [k for _, _, k in launches] == ["rc", "wgrad", "gemm"]
+    for (label, flop, durs), lo in zip(rec, (20e-6, 10e-6, 3e-6)):
+        assert len(durs) == SLOTS, (label, durs)
+        assert all(lo < d < 5e-3 for d in durs), (label, durs)
+    assert int((buf[:, 3:] != 0).sum()) == 0                          # launch regions 3.. untouched
+    assert int((buf[:, 2, 2:] != 0).sum()) == 0                       # the tiled product writes two words
+    for a, b in zip(outs, ref_outs):
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+    assert torch.equal(C, C_ref)
+    assert rel_l2(dW, dW_ref) < 1e-6 and rel_l2(db, db_ref) < 1e-6    # (atomic flush: order dependent)
