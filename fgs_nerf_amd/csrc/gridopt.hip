@@ -348,6 +348,34 @@ FGS_API int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, in
   return 0;
 }
 
+namespace {
+// mask[i][j][k] = every index inside its axis' closed range; the six bounds are floats holding small integers (a row of the
+// schedule table): a captured iteration of the voxel-increment phase rebuilds the mask from them (model/nerf.py:1078-1088)
+__global__ __launch_bounds__(FGS_BLOCK) void k_box_mask_fill(unsigned char *__restrict__ mask, int X, int Y, int Z,
+                                                             const float *__restrict__ bounds) {
+  const int64_t n = (int64_t)X * Y * Z;
+  const int lo0 = (int)bounds[0], hi0 = (int)bounds[1], lo1 = (int)bounds[2], hi1 = (int)bounds[3], lo2 = (int)bounds[4],
+            hi2 = (int)bounds[5];
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(v % Z), j = (int)((v / Z) % Y), i = (int)(v / ((int64_t)Z * Y));
+    mask[v] = (i >= lo0 && i <= hi0 && j >= lo1 && j <= hi1 && k >= lo2 && k <= hi2) ? 1 : 0;
+  }
+}
+}  // namespace
+
+// The voxel-increment mask of one iteration (model/nerf.py:1078-1088, model/nerf_training.py:286-291) from six index bounds in
+// DEVICE memory {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z} (floats holding integers; lo > hi: empty axis): mask [X][Y][Z] bytes,
+// 1 inside.  The host derives the bounds from the reference's own linspace comparison (fgs_nerf_amd.nerf.inc_index_bounds).
+FGS_API int fgs_box_mask_fill(unsigned char *mask, int X, int Y, int Z, const float *bounds6_dev, fgs_stream_t stream) {
+  FGS_REQUIRE(mask && bounds6_dev && X > 0 && Y > 0 && Z > 0, FGS_E_INVALID, "fgs_box_mask_fill: bad argument");
+  const int64_t n = (int64_t)X * Y * Z;
+  const int64_t blocks = (n + FGS_BLOCK * 4 - 1) / (FGS_BLOCK * 4);
+  hipLaunchKernelGGL(k_box_mask_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(FGS_BLOCK), 0, fgs_s(stream), mask,
+                     X, Y, Z, bounds6_dev);
+  FGS_LAUNCH_OK("fgs_box_mask_fill");
+  return 0;
+}
+
 FGS_API int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream) {
   FGS_REQUIRE(offsets && flags && capacity >= 0 && n > 0, FGS_E_INVALID, "fgs_count_guard: bad argument");
   hipLaunchKernelGGL(k_count_guard, dim3(fgs_blocks(n)), dim3(FGS_BLOCK), 0, fgs_s(stream), offsets, n, capacity, flags, total);

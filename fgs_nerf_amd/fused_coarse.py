@@ -328,7 +328,10 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
         key = im                                   # the module itself: keeps it alive, so no id() reuse
         cached = model.__dict__.get('_fused_inc')
         if cached is None or cached[0] is not key:
-            world = im.mask.to(torch.uint8).contiguous()
+            # (a contiguous bool tensor is one byte per voxel already: share it, so that a captured iteration of the
+            # voxel-increment phase, which rewrites the mask in place -- fgs_box_mask_fill -- is seen here)
+            world = im.mask.view(torch.uint8) if (im.mask.dtype == torch.bool and im.mask.is_contiguous()) \
+                else im.mask.to(torch.uint8).contiguous()
             sc = im.xyz2ijk_scale.detach().cpu().float().tolist()
             sh = im.xyz2ijk_shift.detach().cpu().float().tolist()
             cached = (key, (world, tuple(int(s) for s in world.shape), (ctypes.c_float * 3)(*sc), (ctypes.c_float * 3)(*sh)))

@@ -50,6 +50,9 @@ class CapturedFineStep:
                        construct, capture and replay in lockstep (same variants, same order).
     exchange_capacity: bricks the k0 exchange buffer holds (the same number on every rank; default: the averager's
                        `suggested_capacity` from the host-counted exchanges of the warm-up steps, else 1/2 of the grid)
+    inc_bounds_of    : None, or iteration index -> the six index bounds of that iteration's voxel-increment mask
+                       (`model.inc_index_bounds(lower, upper)`; model/nerf_training.py:286-291): the mask of `model.inc_mask` (set
+                       before capture, never replaced afterwards) is rewritten in place by every replay
     variants         : None, or a list of dicts {'tv': ..., 'extra_loss': callable(model) -> scalar tensor or None}: one graph
                        per entry over the SAME static inputs, schedule table and counters, chosen per iteration by
                        `replay(batch, variant=k)` -- iterations of different SHAPE inside one window (the shipped fine config
@@ -59,7 +62,8 @@ class CapturedFineStep:
 
     def __init__(self, model, optimizer, loss_cfg: Dict, render_kwargs: Dict, n_rays: int, n_iters: int,
                  global_step_of: Callable[[int], int], lr_of: Callable[[int, Dict], float], tv=None,
-                 capacity: int = 131072, variants=None, averager=None, exchange_capacity: Optional[int] = None):
+                 capacity: int = 131072, variants=None, averager=None, exchange_capacity: Optional[int] = None,
+                 inc_bounds_of: Optional[Callable[[int], Sequence[int]]] = None):
         coarse = getattr(model, 'stage', 'fine') in ('coarse', 'geometry_searching')
         if not (fused.supports_coarse(model) if coarse else fused.supports(model)):
             raise RuntimeError("CapturedFineStep needs a model the fused path covers")
@@ -82,11 +86,15 @@ class CapturedFineStep:
         optimizer.ensure_state()
         base_step = [max([optimizer.state[p]['step'] for p in g['params'] if p in optimizer.state] or [0]) for g in groups]
         step_size = lib().fgs_adam_step_size
-        table = np.zeros((n_iters, 2 + len(groups)), dtype=np.float32)
+        # voxel-increment phase (model/nerf_training.py:286-291): six more columns, the index bounds of the iteration's mask
+        self.inc_col = 1 + len(groups) if inc_bounds_of is not None else None
+        table = np.zeros((n_iters, 2 + len(groups) + (6 if inc_bounds_of is not None else 0)), dtype=np.float32)
         for it in range(n_iters):
             s_val = model._s_val_for(global_step_of(it), True)
             table[it, 0] = np.float32(1.0) / np.float32(s_val)          # model/nerf.py:522: ones(1) / s_val in float32
             table[it, -1] = np.float32(s_val)                           # model/nerf.py:520: the s_val parameter's new value
+            if inc_bounds_of is not None:
+                table[it, self.inc_col:self.inc_col + 6] = np.asarray(inc_bounds_of(it), dtype=np.float32)
             for gi, g in enumerate(groups):
                 b1, b2 = g['betas']
                 table[it, 1 + gi] = step_size(base_step[gi] + it + 1, float(b1), float(b2), float(lr_of(it, g)))
@@ -106,6 +114,7 @@ class CapturedFineStep:
         self._exchange_state = None
         self._sdf_exchange_state = None
         self.sdf_exchange_capacity = None
+        self._inc_mask = None
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _enter(self):
@@ -178,6 +187,19 @@ class CapturedFineStep:
         call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
              self.n_cols - 1, ptr(self.model.s_val.data), stream())
         fo.stamps_begin_step()            # (bench.py's in-kernel timing of the matrix-core launches, when it is on)
+        if self.inc_col is not None:
+            # this iteration's voxel-increment mask, rebuilt in place from the row the tick just copied (the render below reads
+            # the same bytes through model.inc_mask)
+            im = self.model.inc_mask
+            if im is None or im.mask.dtype != torch.bool or not im.mask.is_contiguous():
+                raise RuntimeError("CapturedFineStep(inc_bounds_of=...): call model.set_inc_mask(...) before capture")
+            if self._inc_mask is None:
+                self._inc_mask = im
+            elif im is not self._inc_mask:
+                raise RuntimeError("CapturedFineStep: model.inc_mask was replaced after the first pass (the graphs hold the "
+                                   "address of the old mask)")
+            X, Y, Z = (int(v) for v in im.mask.shape)
+            call("fgs_box_mask_fill", ptr(im.mask), X, Y, Z, ptr(self.scalars[self.inc_col:self.inc_col + 6]), stream())
         # (global_step only selects the training branch here: 1/s comes from the device scalars)
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)

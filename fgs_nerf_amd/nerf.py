@@ -455,6 +455,24 @@ class nerf(torch.nn.Module):
     def unset_inc_mask(self):
         self.inc_mask = None
 
+    def inc_index_bounds(self, lower, upper):
+        """The mask of `set_inc_mask(lower, upper)` as six closed index ranges (lo_x, hi_x, lo_y, hi_y, lo_z, hi_z; lo > hi:
+        empty axis): the lattice is a per-axis linspace(0, 1, W) compared with the bounds (model/nerf.py:1081-1087), and a
+        monotone lattice makes each comparison a contiguous index range -- found with the same torch expressions, so the
+        device-side rebuild (fgs_box_mask_fill, a captured iteration) sets exactly the voxels `set_inc_mask` would."""
+        out = []
+        for a, w in enumerate(int(w) for w in self.world_size):
+            g = torch.linspace(0, 1, w)
+            inside = (g >= lower[a]) & (g <= upper[a])
+            idx = torch.nonzero(inside).flatten()
+            if idx.numel() == 0:
+                out += [1, 0]
+            else:
+                lo, hi = int(idx[0]), int(idx[-1])
+                assert int(inside.sum()) == hi - lo + 1
+                out += [lo, hi]
+        return tuple(out)
+
     # ------------------------------------------------------------------ sampling
     def _stepdist(self, stepsize):
         return float(stepsize * self.voxel_size)

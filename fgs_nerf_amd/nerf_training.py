@@ -300,8 +300,8 @@ class TrainStepper:
         to calling `step()` for each of them, one GPU.  The window is cut -- and captured anew -- wherever an iteration changes
         what the graphs were built from: a `pg_scale` rescale, a `decay_step_module` / `tv_updates` / `s_updates` /
         `smooth_updates` entry.  `ori_tv` (the coarse stages' autograd TV terms, every iteration in the shipped configs) is part of
-        the captured iteration.  Only the voxel-increment phase (`voxel_inc`, global_step <= inc_steps: a new mask per
-        iteration) and a TV term on k0 are refused.  Iterations with and without the TV schedule active (sdf TV add-grad +
+        the captured iteration, and so is the voxel-increment phase (`voxel_inc`, global_step <= inc_steps: the iteration's mask
+        is rebuilt on the device from index bounds in the schedule table).  Only a TV term on k0 is refused.  Iterations with and without the TV schedule active (sdf TV add-grad +
         the autograd smooth-gradient TV term, every `tv_every`-th iteration) are two graphs over the same state.  The learning-rate decay (model/nerf_training.py:389-436) and the NeuS s_val schedule
         become rows of the device-resident table.  Returns (losses [n_steps] device tensor, overflowed: bool); on overflow
         (more survivors than `capacity` in some iteration: that iteration's update was skipped) the caller re-runs with a
@@ -337,10 +337,16 @@ class TrainStepper:
         covered = fused.supports(model) if self.stage == 'fine' else fused.supports_coarse(model)
         if not covered or self.averager is not None:
             raise RuntimeError("run_captured covers the fused paths (fine, coarse, geometry_searching) on one GPU")
+        # voxel-increment phase (:286-291, global_step <= inc_steps: a new mask every iteration): the six index bounds of every
+        # iteration's mask become columns of the device table, the captured iteration rebuilds the mask in place from them
+        # (fgs_box_mask_fill) -- the voxels step()'s set_inc_mask would set, by the same linspace comparison (inc_index_bounds)
+        inc_bounds_of = None
         if ct.get('voxel_inc', False):
+            def inc_box(g):
+                w = min(g * 1.0 / ct.inc_steps, 1.0)
+                return (self.inc_lower_init - w * self.inc_lower_init, self.inc_upper_init + w * (1 - self.inc_upper_init))
             if any(g <= ct.inc_steps for g in steps):
-                raise RuntimeError("run_captured: the voxel-increment phase (global_step <= inc_steps) rebuilds the increment mask "
-                                   "every iteration; use step() for it")
+                inc_bounds_of = lambda it: model.inc_index_bounds(*inc_box(min(first_step + it, ct.inc_steps)))   # noqa: E731
         else:
             model.unset_inc_mask()
         if any(g in ct.get('pg_scale', []) for g in list(steps)[1:]):
@@ -388,12 +394,17 @@ class TrainStepper:
         base_lr = {id(g): g['lr'] for g in opt.param_groups}
         first = self._select_rays()
         if capacity is None:
+            if inc_bounds_of is not None:        # the mask grows through the window: size the buffers for its last iteration
+                model.set_inc_mask(*inc_box(min(first_step + n_steps - 1, ct.inc_steps)))
             with torch.no_grad():
                 probe = model(first[1], first[2], first[3], global_step=first_step, **self.render_kwargs)
             capacity = (int(probe['weights'].shape[0] * 1.5) + 4095) // 4096 * 4096
+        if inc_bounds_of is not None:
+            model.set_inc_mask(*inc_box(first_step))     # THE mask object of this window (rewritten in place by every replay)
         cap = CapturedFineStep(model, opt, ct, self.render_kwargs, ct.N_rand, n_iters=n_steps,
                                global_step_of=lambda it: first_step + it,
-                               lr_of=lambda it, g: base_lr[id(g)] * factors[it], capacity=capacity, variants=variants)
+                               lr_of=lambda it, g: base_lr[id(g)] * factors[it], capacity=capacity, variants=variants,
+                               inc_bounds_of=inc_bounds_of)
         batch = (first[1], first[2], first[3], first[0])           # (rays_o, rays_d, viewdirs, target)
         self.last_result = None          # (an earlier step()'s result would keep its autograd graph -- and the leaves'
         cap.capture(batch)               # AccumulateGrad nodes, bound to the default stream -- alive across the capture)

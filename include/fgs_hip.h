@@ -35,8 +35,8 @@ typedef void *fgs_stream_t;
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
- * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches. */
-#define FGS_ABI_VERSION 5
+ * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill. */
+#define FGS_ABI_VERSION 6
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -90,6 +90,10 @@ float fgs_adam_step_size(int step, float beta1, float beta2, float lr);      /* 
 int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
                           float *mirror_dst, fgs_stream_t stream);
 int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream);
+/* The voxel-increment mask of one iteration (model/nerf.py:1078-1088: linspace lattice compared with a growing box,
+ * model/nerf_training.py:286-291) rebuilt on the device from six index bounds {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z} in device
+ * memory (floats holding integers: columns of the schedule table; lo > hi = empty): mask [X][Y][Z] bytes, 1 inside. */
+int fgs_box_mask_fill(unsigned char *mask, int X, int Y, int Z, const float *bounds6_dev, fgs_stream_t stream);
 /* fgs_exclusive_scan_i64(in, n, out) + fgs_count_guard(out, n + 1, capacity, flags, total) as ONE launch (the survivor offsets
  * of a sync-free step: model/nerf.py:802-833's nonzero / cumsum without the host). */
 int fgs_exclusive_scan_guard_i64(const int64_t *in, int64_t n, int64_t *out, int64_t capacity, int *flags, int64_t *total,

@@ -135,10 +135,6 @@ def test_stepper_captured_window_matches_step_by_step(dev):
     assert not overflow and bool(torch.isfinite(losses).all())
     # windows the captured form does not cover are refused, not silently mis-run
     model = synth.build_model(32, synth.FINE_MODEL, device=dev)
-    st = nt.TrainStepper(model, dict(cfg, voxel_inc=True, inc_steps=100, x_mid=0.5, y_mid=0.5, z_mid=0.5, x_init_ratio=0.2,
-                                      y_init_ratio=0.2, z_init_ratio=0.2), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
-    with pytest.raises(RuntimeError, match="voxel-increment"):
-        st.run_captured(1, 6)                      # the increment mask is rebuilt every iteration up to inc_steps
     st = nt.TrainStepper(model, dict(cfg, weight_tv_k0=0.1), {}, synth.RENDER_KWARGS, target, *rays, stage='fine', seed=1)
     with pytest.raises(RuntimeError, match="k0"):
         st.run_captured(1, 6)
@@ -386,3 +382,54 @@ def test_captured_coarse_window_with_ori_tv_and_table_updates_matches_step_by_st
     assert float(((la - lb) / la).abs().max()) < 2e-3, (la, lb)
     for pa, pb in zip(runs["steps"][1], runs["captured"][1]):
         assert pa.shape == pb.shape and float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < 1e-2
+
+
+def test_captured_window_in_the_voxel_increment_phase_matches_step_by_step(dev):
+    """Coarse stage with `voxel_inc` (config/shiny_blender.py:51-58, model/nerf_training.py:286-291): every iteration up to
+    inc_steps renders through a larger increment mask.  The captured iteration rebuilds the mask on the device from index bounds in
+    its schedule table (fgs_box_mask_fill): the masks equal step()'s set_inc_mask voxel for voxel, the survivor totals, losses
+    and parameters follow; the window runs past inc_steps (the mask then stays what iteration inc_steps left)."""
+    from fgs_nerf_amd import nerf_training as nt
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd._lib import call, ptr, stream
+    cfg = dict(N_iters=15000, N_rand=512, lrate_k0=0.1, lrate_sdf=0.005, lrate_refnet=1e-3, lrate_decay=20,
+               ray_sampler='flatten', weight_main=1.0, weight_entropy_last=0.001, weight_rgbper=0.2, weight_tv_density=0.01,
+               weight_tv_k0=0.0, sigmoid_rgb_loss=0.1, weight_orientation=1e-4, tv_every=1, tv_from=0, tv_end=40000,
+               voxel_inc=True, inc_steps=8, x_mid=0.5, y_mid=0.45, z_mid=0.55, x_init_ratio=0.3, y_init_ratio=0.4,
+               z_init_ratio=0.35, pg_scale=[], scale_ratio=2.0, reset_iter=[], ori_tv=True,
+               tv_terms=dict(sdf_tv=0.1, smooth_grad_tv=0.05), tv_dense_before=20000, cosine_lr=True,
+               cosine_lr_cfg=dict(warm_up_iters=0, const_warm_up=True, warm_up_min_ratio=1.0), decay_step_module={},
+               skip_zero_grad_fields=['density', 'k0', 'k1'])
+    R, FIRST, N = 2048, 3, 8                       # iterations 3 .. 10: six inside the phase, two behind it
+    rays = tuple(r.to(dev) for r in synth.random_rays(R, seed=43))
+    target = torch.rand(R, 3, generator=torch.Generator().manual_seed(11)).to(dev)
+    runs = {}
+    for mode in ("steps", "captured"):
+        model = synth.build_model(32, synth.COARSE_MODEL, device=dev)
+        st = nt.TrainStepper(model, dict(cfg), {}, synth.RENDER_KWARGS, target, *rays, stage='coarse', seed=19)
+        if mode == "steps":
+            losses, masks = [], []
+            for g in range(FIRST, FIRST + N):
+                losses.append(st.step(g).detach())
+                masks.append(model.inc_mask.mask.clone())
+            losses = torch.stack(losses)
+            # the device-side rebuild sets the voxels set_inc_mask sets, iteration by iteration
+            for g, m in zip(range(FIRST, FIRST + N), masks):
+                w = min(min(g, cfg['inc_steps']) * 1.0 / cfg['inc_steps'], 1.0)
+                b = model.inc_index_bounds(st.inc_lower_init - w * st.inc_lower_init, st.inc_upper_init + w * (1 - st.inc_upper_init))
+                out = torch.full(m.shape, 7, dtype=torch.uint8, device=dev)
+                call("fgs_box_mask_fill", ptr(out), *m.shape, ptr(torch.tensor(b, dtype=torch.float32, device=dev)), stream())
+                assert torch.equal(out.bool(), m) and int(out.max()) <= 1, g
+            assert int(masks[0].sum()) < int(masks[3].sum()) < int(masks[5].sum()) == int(masks[-1].sum()) == masks[-1].numel()
+        else:
+            losses, overflow = st.run_captured(FIRST, N)
+            assert not overflow
+            assert bool(model.inc_mask.mask.all())               # the last iterations' mask: the whole grid
+        torch.cuda.synchronize()
+        runs[mode] = (losses.cpu(), [p.detach().clone() for p in model.parameters()])
+    la, lb = runs["steps"][0], runs["captured"][0]
+    assert abs(float(la[0]) - float(lb[0])) < 2e-6 * abs(float(la[0])), (la, lb)          # same mask, same parameters, same batch
+    assert float(((la - lb) / la).abs().max()) < 2e-3, (la, lb)
+    for pa, pb in zip(runs["steps"][1], runs["captured"][1]):
+        assert float((pa - pb).abs().max()) <= 2 * 0.1 * N + 1e-6
+        assert float((pa - pb).norm() / pa.norm().clamp_min(1e-30)) < (2e-2 if pa.dim() == 1 else 5e-3)
