@@ -249,6 +249,17 @@ def launch_ranks(n_gpus: int, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def replica_digest_spread(digests) -> float:
+    """Largest relative difference, over the parameter groups, between the ranks' digests (one scalar per group): MIN- and
+    MAX-reduced over the process group.  0.0 = the replicas are bit-identical as far as the digests can tell."""
+    import torch.distributed as dist
+    dg = torch.stack([d.reshape(()) for d in digests]).to(torch.float64)
+    lo, hi = dg.clone(), dg.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(((hi - lo) / hi.abs().clamp_min(1e-300)).max().item())
+
+
 def dry_rank(args) -> int:
     """FGS_BENCH_DRY=gloo: rehearse the launcher and the cross-rank reporting protocol on CPU (no device work, no timing
     claim): process group, barrier, MAX / SUM reductions, rank 0 prints the JSON line with the world size it saw."""
@@ -547,6 +558,12 @@ def main():
             roofline_note = (f"HIP events on the launch stream immediately around every MLP matrix-core launch, in {PROFILE_STEPS} eager steps "
                              "of the same loop run right behind the timed region (graph replays cannot carry timing events)")
 
+    # Several ranks: the replicas must have stayed bit-identical (same averaged gradients, same updates) -- each group's digest
+    # MIN- and MAX-reduced over the ranks; the line carries the verdict (`config.replicas_in_sync`).  This is the only place where
+    # the exchange is checked on REAL peers: the test suite has gloo ranks and a single-rank RCCL group.
+    replica_spread = None
+    if world > 1 or force_dist:            # (a forced single-rank group runs the same code: trivially in sync)
+        replica_spread = replica_digest_spread(digest_after)
     stats = torch.tensor([elapsed, float(samples)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[:1].clone()
@@ -573,6 +590,12 @@ def main():
         }
         if STEP_STATS.get("overflow"):
             line["config"]["capacity_overflow_on_rank0"] = True
+        if replica_spread is not None:
+            line["config"]["replicas_in_sync"] = bool(replica_spread == 0.0)
+            line["config"]["replica_digest_spread"] = replica_spread
+            if replica_spread != 0.0:
+                print(f"[bench] the ranks' parameters have drifted apart (relative digest spread {replica_spread:.3e}): the gradient "
+                      "exchange is not doing its job", file=sys.stderr, flush=True)
         from fgs_nerf_amd import fused as _fz
         if _fz._MLP_COLLAPSE and args.stage == "fine" and not args.composed:
             # a labelled mode, not the headline: less arithmetic than the reference's operation order (roofline books the FLOP

@@ -183,3 +183,26 @@ def test_sdf_gradient_brick_sparse_exchange_world2():
     out = mgr.dict()
     mp.spawn(_sdf_sparse_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] and out[1]
+
+
+def _spread_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        same = [torch.tensor(3.25, dtype=torch.float64), torch.tensor(1e6, dtype=torch.float64)]
+        drift = [torch.tensor(3.25, dtype=torch.float64), torch.tensor(1e6 + rank, dtype=torch.float64)]
+        out[rank] = (bench.replica_digest_spread(same), bench.replica_digest_spread(drift))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_replica_check_sees_drift():
+    """bench.py's end-of-run check that the ranks' parameters stayed identical (config.replicas_in_sync): 0.0 for equal digests,
+    the relative spread otherwise, the same number on every rank."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_spread_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1]
+    assert out[0][0] == 0.0 and abs(out[0][1] - 1.0 / (1e6 + 1)) < 1e-12
