@@ -79,12 +79,49 @@ __device__ __forceinline__ float loss_surv_term(const LossArgs &L, int64_t m) {
 
 // One launch for both index ranges (thread i: element i of the N*3 ray values AND survivor i): each launch of a captured
 // step costs ~5 us whatever it does.
-__global__ __launch_bounds__(FGS_BLOCK) void k_loss_fwd(LossArgs L, float *loss, int with_surv) {
+// `partials` != NULL: every block leaves its sum in partials[block] and the LAST block to arrive (a counter word that it
+// resets) adds them up in a fixed order and writes the scalar -- no zero fill in front of the launch (a node of its own in a
+// captured step), and the value no longer depends on the order in which the blocks' atomics land.
+__global__ __launch_bounds__(FGS_BLOCK) void k_loss_fwd(LossArgs L, float *loss, int with_surv, float *partials,
+                                                        unsigned *counter) {
   L.M = fgs_rows(L.M, L.m_dev);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float acc = loss_rays_term(L, i);
   if (with_surv) acc += loss_surv_term(L, i);
-  block_sum_to(acc, loss);
+  if (!partials) {
+    block_sum_to(acc, loss);
+    return;
+  }
+  __shared__ float part[FGS_BLOCK / FGS_WAVE];
+  __shared__ int is_last;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) s += part[w];
+    __hip_atomic_store(partials + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    is_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  float v = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += FGS_BLOCK)
+    v += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) s += part[w];
+    loss[0] = s;
+    *counter = 0u;                       // left as found: the next launch starts from zero again
+  }
 }
 
 __device__ __forceinline__ void loss_rays_bwd(const LossArgs &L, int64_t i, float go, float *__restrict__ g_rgb_marched,
@@ -160,21 +197,29 @@ int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const floa
 }  // namespace
 
 // weights5_host = {weight_main, weight_rgbper, weight_entropy_last, weight_orientation, sigmoid_rgb_loss}.
-// loss_out: device float, zeroed here (stream-ordered memset), then accumulated.
+// loss_out: device float.  scratch (optional): scratch_floats >= 1 + ceil(max(3 N, M) / 256) floats whose FIRST word is zero when
+// first handed in (the kernel leaves it zero): per-block sums + a fixed-order final sum by the last block -- a deterministic
+// scalar, one launch.  Without it (or too small): loss_out is zeroed by a stream-ordered memset and accumulated with atomics.
 FGS_API int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                               const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                               const int64_t *ray_id, const float *viewdirs, const float *weights5_host, float *loss_out,
-                              const fgs_dyn_t *dyn, fgs_stream_t stream) {
+                              float *scratch, int64_t scratch_floats, const fgs_dyn_t *dyn, fgs_stream_t stream) {
   LossArgs L;
   if (int e = fill(&L, N, M, rgb_marched, sigmoid_rgb, target, alphainv_cum, weights, normal, raw_rgb, ray_id, viewdirs,
                    weights5_host, dyn)) return e;
   FGS_REQUIRE(loss_out, FGS_E_INVALID, "fgs_fine_loss_fwd: null loss_out");
   hipStream_t st = fgs_s(stream);
-  hipError_t he = hipMemsetAsync(loss_out, 0, sizeof(float), st);
-  if (he != hipSuccess) return fgs_set_error((int)he, "fgs_fine_loss_fwd: %s", hipGetErrorString(he));
   const int with_surv = (M > 0 && (L.w_ori > 0.f || L.w_rgbper > 0.f)) ? 1 : 0;
   const int64_t n_thr = (with_surv && M > N * 3) ? M : N * 3;
-  hipLaunchKernelGGL(k_loss_fwd, dim3(fgs_blocks(n_thr)), dim3(FGS_BLOCK), 0, st, L, loss_out, with_surv);
+  const unsigned blocks = fgs_blocks(n_thr);
+  float *partials = nullptr;
+  if (scratch && scratch_floats >= (int64_t)blocks + 1) partials = scratch + 1;
+  if (!partials) {
+    hipError_t he = hipMemsetAsync(loss_out, 0, sizeof(float), st);
+    if (he != hipSuccess) return fgs_set_error((int)he, "fgs_fine_loss_fwd: %s", hipGetErrorString(he));
+  }
+  hipLaunchKernelGGL(k_loss_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, st, L, loss_out, with_surv, partials,
+                     reinterpret_cast<unsigned *>(scratch));
   FGS_LAUNCH_OK("fgs_fine_loss_fwd");
   return 0;
 }

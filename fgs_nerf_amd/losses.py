@@ -40,6 +40,20 @@ def _w5(cfg):
                                 float(cfg.get('sigmoid_rgb_loss', 0)))
 
 
+_SCRATCH = {}     # device index -> per-block partial sums of fgs_fine_loss_fwd (first word: its arrival counter).  One per device,
+                  # not per stream: a captured step must find the buffer its warm-up pass (another stream) allocated -- an
+                  # allocation inside the capture would put a zero fill into every replay.  (Two loss launches of one device in
+                  # flight at the same time on different streams would share it: not a pattern of this path.)
+
+
+def _loss_scratch(dev, need: int) -> torch.Tensor:
+    key = dev.index
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < need:
+        t = _SCRATCH[key] = torch.zeros(max(need, 2048), dtype=torch.float32, device=dev)
+    return t
+
+
 class _FineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_marched, sigmoid_rgb, alphainv_cum, normal, raw_rgb, weights, ray_id, ray_viewdirs, target, w5,
@@ -50,7 +64,9 @@ class _FineLoss(torch.autograd.Function):
                 weights.contiguous(), normal.contiguous(), raw_rgb.contiguous(), ray_id.contiguous(),
                 ray_viewdirs.contiguous())
         # (sync-free results carry the device address of their survivor count: their per-survivor arrays have CAPACITY rows)
-        call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), dyn(row_count=count_ptr), stream())
+        scratch = _loss_scratch(rgb_marched.device, (max(3 * N, M) + 255) // 256 + 1)
+        call("fgs_fine_loss_fwd", N, M, *(ptr(a) for a in args), w5, ptr(loss), ptr(scratch), scratch.numel(),
+             dyn(row_count=count_ptr), stream())
         ctx.save_for_backward(*args)
         ctx.w5, ctx.count_ptr = w5, count_ptr
         return loss

@@ -35,8 +35,8 @@ typedef void *fgs_stream_t;
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
- * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill. */
-#define FGS_ABI_VERSION 6
+ * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer. */
+#define FGS_ABI_VERSION 7
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -243,11 +243,14 @@ int fgs_brick_count_guard(int64_t *count_dev, int64_t capacity, int *flags, int 
  * model/nerf.py:469-478) and their gradients, two launches each instead of the ~40 of the autograd graph.
  * weights5_host = {weight_main, weight_rgbper, weight_entropy_last, weight_orientation, sigmoid_rgb_loss}.
  * viewdirs are per RAY [N,3] (the per-sample view direction is viewdirs[ray_id]).  loss_out / grad_out: device floats.
+ * fwd `scratch` (optional, NULL = atomics behind a memset): >= 1 + ceil(max(3 N, M) / 256) floats, first word zero when first
+ * handed in and left zero: per-block sums added up in a fixed order by the last block to arrive -- one launch, a scalar that
+ * does not depend on the order in which atomics land.
  * ------------------------------------------------------------------------------ */
 int fgs_fine_loss_fwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                       const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                       const int64_t *ray_id, const float *viewdirs, const float *weights5_host, float *loss_out,
-                      const fgs_dyn_t *dyn, fgs_stream_t stream);
+                      float *scratch, int64_t scratch_floats, const fgs_dyn_t *dyn, fgs_stream_t stream);
 int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
                       const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
                       const int64_t *ray_id, const float *viewdirs, const float *weights5_host, const float *grad_out,

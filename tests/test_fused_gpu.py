@@ -568,3 +568,31 @@ def test_learnable_s_val_through_the_fused_path(dev, oracle, stage):
     assert rel_l2(model.sdf.grid.grad, P['sdf'].grad) < 1e-3
     g_hip, g_ref = float(model.s_val.grad), float(P['s_param'].grad)
     assert g_ref != 0.0 and abs(g_hip - g_ref) <= 2e-4 * abs(g_ref), (g_hip, g_ref)
+
+
+def test_fused_loss_scalar_is_deterministic_and_matches_the_torch_form(dev):
+    """fgs_fine_loss_fwd with its scratch buffer: per-block sums added in a fixed order by the last block to arrive -- the same
+    bits on every call (the atomic form differed in the last place from run to run), equal to losses.render_losses (the torch
+    statement of model/nerf_training.py:308-327) to float32 rounding, the counter word left zero, and the atomic fallback (no
+    scratch) within an ulp of it."""
+    import ctypes
+    from fgs_nerf_amd import losses, synth
+    from fgs_nerf_amd._lib import call, ptr, stream
+    model = synth.build_model(48, synth.FINE_MODEL, device=dev)
+    ro, rd, vd = (t.to(dev) for t in synth.random_rays(2048, seed=9))
+    target = torch.rand(2048, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    with torch.no_grad():
+        res = model(ro, rd, vd, global_step=1000, **synth.RENDER_KWARGS)
+    vals = [losses.fused_render_losses(res, target, synth.FINE_LOSS, model) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(v, vals[0]) for v in vals)
+    ref = losses.render_losses(res, target, synth.FINE_LOSS, model)
+    assert abs(float(vals[0]) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert int(losses._SCRATCH[dev.index].view(torch.int32)[0]) == 0
+    # the form without a scratch buffer (memset + atomics)
+    N, M = res['rgb_marched'].shape[0], res['weights'].shape[0]
+    args = (res['rgb_marched'], res['sigmoid_rgb'], target, res['alphainv_cum'], res['weights'], res['normal'], res['raw_rgb'],
+            res['ray_id'], res['ray_viewdirs'])
+    out = torch.full((), 7.0, device=dev)
+    call("fgs_fine_loss_fwd", N, M, *(ptr(a.contiguous()) for a in args), losses._w5(synth.FINE_LOSS), ptr(out), None, 0, None, stream())
+    assert abs(float(out) - float(vals[0])) <= 2e-6 * abs(float(vals[0]))
