@@ -153,6 +153,7 @@ class GradAverager:
             h['event'].record()
         pts.record_stream(h['stream'])
         h['armed'] = True
+        h['unordered'] = True      # (its all-reduce ran on `self.group` from a stream of its own: see average())
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _dense(self, g: torch.Tensor, async_op: bool, group=None):
@@ -485,6 +486,14 @@ class GradAverager:
         if self.world_size == 1 and not self.force:
             return
         inv = 1.0 / self.world_size
+        # Collectives of ONE communicator must start in the same order on every rank.  Synchronous collectives sit on the stream
+        # they are issued from (and, in a captured step, on that stream's graph branch: scripts/diag/rccl_capture_order_probe.py);
+        # the occupancy all-reduce of hint_touched() used `self.group` on a side stream, and the collectives below use
+        # `self.group` from this one.  RCCL chains the launches of a communicator itself, but the order is cheaper to state than
+        # to rely on: this stream waits for that all-reduce first (an event that completed a whole backward pass ago).
+        for h in self._hints.values():
+            if h.pop('unordered', False) and os.environ.get("FGS_DIST_ORDER_EDGE", "1") == "1":
+                torch.cuda.current_stream().wait_event(h['event'])
         handles, small, sparse_later = [], [], []
         owner = {}
         early = self.__dict__.get('_early')
