@@ -5,6 +5,7 @@ The GPU path uses the same code with backend "nccl" (RCCL over xGMI); the collec
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -67,13 +68,13 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_grad_averager_world2_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_grad_averager_world2_matches_single_process(world):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    assert out[0] and out[1]
+    assert all(out[r] for r in range(world))
 
 
 def test_shard_rays_partitions_the_batch():
@@ -176,13 +177,13 @@ def _sdf_sparse_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sdf_gradient_brick_sparse_exchange_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sdf_gradient_brick_sparse_exchange_world2(world):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_sdf_sparse_worker, args=(world, port, out), nprocs=world, join=True)
-    assert out[0] and out[1]
+    assert all(out[r] for r in range(world))
 
 
 def _spread_worker(rank, world, port, out):
