@@ -494,7 +494,7 @@ class GradAverager:
         for h in self._hints.values():
             if h.pop('unordered', False) and os.environ.get("FGS_DIST_ORDER_EDGE", "1") == "1":
                 torch.cuda.current_stream().wait_event(h['event'])
-        handles, small, sparse_later = [], [], []
+        handles, small, sparse_later, dense_big = [], [], [], []
         owner = {}
         early = self.__dict__.get('_early')
         skip = set()
@@ -515,9 +515,18 @@ class GradAverager:
                     sparse_later.append(g)
                     owner[id(g)] = p
                 else:
-                    handles.append(self._dense(g, async_op=True))
+                    dense_big.append(g)
             else:
                 small.append(g)
+        # one dense grid (the sdf gradient of a fine-stage step): a synchronous collective on THIS stream -- the asynchronous form
+        # goes through the process group's internal stream, i.e. two cross-queue joins (~10 us of idle device each in a captured
+        # step) around a collective that has nothing to overlap with here; several: asynchronous, so that they overlap each other
+        for g in dense_big:
+            if len(dense_big) == 1 and g.is_cuda and os.environ.get("FGS_DIST_DENSE_SYNC", "1") == "1":
+                _, flat = self._dense(g, async_op=False)
+                self._post_scale(flat, inv)
+            else:
+                handles.append(self._dense(g, async_op=True))
         if small:
             n = sum(g.numel() for g in small)
             if self._bucket is None or self._bucket.numel() != n or self._bucket.device != small[0].device:
