@@ -402,6 +402,14 @@ def main():
     if use_graph and (world > 1 or force_dist) and not rccl_graph_selftest(dev):
         use_graph = False
         print("[bench] collectives inside a hipGraph are not usable here: running the eager form", file=sys.stderr, flush=True)
+    # N > 1: the form of the sdf.grad exchange (dense all-reduce, or brick-sparse like k0's) is decided by timing both on THESE
+    # ranks -- 16 MB dense against ~7 MB + the occupancy all-reduce + five extra launches at 160^3 is a question of the node's
+    # all-reduce latency and bandwidth, which a one-GPU build cannot answer (FGS_SDF_TUNE=0: the shape threshold, 256^3, stays)
+    sdf_tune = None
+    if (world > 1 or force_dist) and use_graph and args.stage == "fine" and os.environ.get("FGS_SDF_TUNE", "1") == "1":
+        sdf_tune = averager.tune_sparse_1ch(model.sdf.grid)
+        if rank == 0:
+            print(f"[bench] sdf.grad exchange tuned on {world} ranks: {sdf_tune}", file=sys.stderr, flush=True)
     STEP_STATS["max_survivors"] = 0
     for i in range(args.warmup):
         train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
@@ -590,6 +598,8 @@ def main():
         }
         if STEP_STATS.get("overflow"):
             line["config"]["capacity_overflow_on_rank0"] = True
+        if sdf_tune is not None and sdf_tune.get("tuned"):
+            line["config"]["sdf_exchange_tuning"] = sdf_tune
         if replica_spread is not None:
             line["config"]["replicas_in_sync"] = bool(replica_spread == 0.0)
             line["config"]["replica_digest_spread"] = replica_spread

@@ -381,6 +381,63 @@ class GradAverager:
                 and g.numel() >= self.sparse_1ch_min_numel and not (g.shape[2] % BRICK or g.shape[3] % BRICK or g.shape[4] % BRICK)
                 and g.is_contiguous())
 
+    def tune_sparse_1ch(self, param, fill_estimate: float = 0.3, kernel_overhead_us: float = 35.0, reps: int = 7) -> dict:
+        """Decide by MEASUREMENT on the ranks at hand whether the 1-channel grid `param` (the sdf gradient) is exchanged
+        brick-sparse or dense, and set `sparse_1ch_min_numel` accordingly -- the same on every rank (rank 0's verdict is
+        broadcast).  Timed, eagerly, with this group's collectives: the dense all-reduce of the whole grid against the occupancy
+        all-reduce (one int per brick) plus the all-reduce of an exchange buffer of 1.5 x `fill_estimate` x the bricks, plus
+        `kernel_overhead_us` for the five extra launches of the sparse form (flags, compact, guard, gather, scatter: measured
+        35 us at 160^3).  With one rank there is nothing to measure: the shape threshold stays.  Returns what it measured."""
+        out = dict(tuned=False)
+        if (self.world_size == 1 and not self.force) or not (param.dim() == 5 and param.shape[1] == 1):
+            return out
+        _, _, X, Y, Z = param.shape
+        if X % BRICK or Y % BRICK or Z % BRICK:
+            return out
+        total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
+        cap = min(total, (int(1.5 * fill_estimate * total) + 255) // 256 * 256)
+        dev = param.device
+        dense = torch.zeros(param.numel(), dtype=torch.float32, device=dev)
+        flags = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+        buf = torch.zeros(cap * BRICK ** 3, dtype=torch.float32, device=dev)
+
+        import time
+        on_gpu = param.is_cuda
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            ts = []
+            for _ in range(reps):
+                dist.barrier(group=self.group)
+                if on_gpu:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(dev)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+                else:                       # (host tensors: the gloo tests walk the same protocol)
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append((time.perf_counter() - t0) * 1e6)
+            return sorted(ts)[len(ts) // 2]
+
+        t_dense = timed(lambda: dist.all_reduce(dense, op=self._op(), group=self.group))
+        t_flags = timed(lambda: dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group))
+        t_buf = timed(lambda: dist.all_reduce(buf, op=self._op(), group=self.group))
+        t_sparse = t_flags + t_buf + kernel_overhead_us
+        verdict = torch.tensor([1 if t_sparse < 0.9 * t_dense else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(verdict, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        sparse = bool(int(verdict.item()))
+        self.sparse_1ch_min_numel = min(self.sparse_1ch_min_numel or (1 << 62), param.numel()) if sparse \
+            else max(self.sparse_1ch_min_numel or 0, param.numel() + 1)
+        out.update(tuned=True, sparse=sparse, dense_us=round(t_dense, 1), flags_us=round(t_flags, 1), buffer_us=round(t_buf, 1),
+                   kernel_overhead_us=kernel_overhead_us, buffer_bricks=cap, dense_bytes=4 * param.numel(),
+                   buffer_bytes=4 * cap * BRICK ** 3)
+        return out
+
     def _disarm(self, param) -> None:
         h = self._hints.get(id(param)) if param is not None else None
         if h is not None:

@@ -207,3 +207,31 @@ def test_bench_replica_check_sees_drift():
     mp.spawn(_spread_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] == out[1]
     assert out[0][0] == 0.0 and abs(out[0][1] - 1.0 / (1e6 + 1)) < 1e-12
+
+
+def _tune_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fgs_nerf_amd.dist import GradAverager
+        sdf = torch.nn.Parameter(torch.zeros(1, 1, 32, 32, 32))
+        av = GradAverager([sdf], sparse_1ch_min_numel=1 << 24)
+        # an absurd overhead figure forces "dense" on every rank, a negative one "sparse": the verdict is rank 0's either way
+        r_dense = av.tune_sparse_1ch(sdf, kernel_overhead_us=1e9, reps=3)
+        thr_dense = av.sparse_1ch_min_numel
+        r_sparse = av.tune_sparse_1ch(sdf, kernel_overhead_us=-1e9, reps=3)
+        thr_sparse = av.sparse_1ch_min_numel
+        out[rank] = (r_dense['tuned'], r_dense['sparse'], thr_dense > sdf.numel(), r_sparse['sparse'], thr_sparse <= sdf.numel(),
+                     av._sparse_1ch(sdf.detach()), r_sparse['buffer_bricks'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sdf_exchange_form_is_tuned_identically_on_every_rank():
+    """GradAverager.tune_sparse_1ch: times the dense and the brick-sparse exchange of the sdf gradient with the group's own
+    collectives and moves the shape threshold -- the same decision on every rank (rank 0's verdict is broadcast)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_tune_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] == (True, False, True, True, True, True, out[0][6]) and 0 < out[0][6] <= 512
