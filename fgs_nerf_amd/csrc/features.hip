@@ -21,7 +21,7 @@ struct FeatLayout {
   float disp[MAXK];
   int off_k0, off_xyz, off_view, off_sdf, off_feat, off_hgrad, off_grad, x0_cols, ldx0;
   int dx_ld, dx_gap;     // dX0 as the backward kernels read it: row pitch, and what to subtract from a column behind the k0
-                         // block (fgs_set_dx0_compact: the xyz / view-direction encodings -- functions of the fixed ray inputs,
+                         // block (fgs_dyn_t.dx0_compact: the xyz / view-direction encodings -- functions of the fixed ray inputs,
                          // no gradient needed -- are left out of dX0: 12 + 40 of 106 columns at the fine stage)
   int off_ref, z_cols, ldz;
   // coarse stages (model/nerf.py:993-1009): ONE operand buffer [k0, xyz_emb, reflect_emb, normal, viewdirs_emb];
@@ -30,7 +30,7 @@ struct FeatLayout {
 };
 
 struct SurvArgs {
-  int64_t M;  // survivors (the capacity of the buffers when m_dev is set: fgs_set_row_count_ptr)
+  int64_t M;  // survivors (the capacity of the buffers when m_dev is set: fgs_dyn_t.row_count)
   const int64_t *m_dev;
   const int64_t *ray_id;
   const float *pts, *sdf, *gradient, *viewdirs;  // pts/sdf/gradient per survivor, viewdirs per ray
@@ -739,7 +739,7 @@ int fill_layout_coarse(const int *li, FeatLayout *L, int compact = 0) {
   L->off_view = c; c += L->use_viewdir ? 3 + 6 * L->n_viewfreq : 0;
   L->off_sdf = L->off_feat = L->off_hgrad = c;
   L->x0_cols = c;
-  // compact dX0 (fgs_set_dx0_compact): [k0 | reflect_emb | normal] -- the xyz encoding between k0 and the reflection block and
+  // compact dX0 (fgs_dyn_t.dx0_compact): [k0 | reflect_emb | normal] -- the xyz encoding between k0 and the reflection block and
   // the view-direction encoding at the end are functions of the fixed ray inputs
   L->dx_gap = compact ? L->off_ref - L->off_xyz : 0;
   L->dx_ld = compact ? (L->off_view - L->dx_gap + 3) / 4 * 4 : L->ldx0;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void fgs_setprio(int p) {
   else if (p >= 3) __builtin_amdgcn_s_setprio(3);
 }
 
-// Rows a kernel really has to process: the host count, or -- under fgs_set_row_count_ptr -- the device count clamped to
+// Rows a kernel really has to process: the host count, or -- under fgs_dyn_t.row_count -- the device count clamped to
 // the capacity the host count then stands for.  A wave-uniform scalar load.
 __device__ __forceinline__ int64_t fgs_rows(int64_t host_or_capacity, const int64_t *__restrict__ count_dev) {
   if (!count_dev) return host_or_capacity;

@@ -31,7 +31,7 @@ constexpr int TILE_FLOATS = 128 * LDK;  // >= 32 * LDI
 
 struct GemmArgs {
   int64_t M, N, K;
-  const int64_t *m_dev;       // fgs_set_row_count_ptr (NT / NN only): M is the capacity, the kernel clamps to *m_dev
+  const int64_t *m_dev;       // fgs_dyn_t.row_count (NT / NN only): M is the capacity, the kernel clamps to *m_dev
   const float *A; int64_t lda;
   const float *B; int64_t ldb;
   float *C; int64_t ldc;
@@ -585,12 +585,12 @@ FGS_API int fgs_gemm_f32(int op, int64_t M, int64_t N, int64_t K, const float *A
 
   GemmArgs g = make_args(M, N, K, A, lda, B, ldb, C, ldc, bias, relu, mask, ldm, colsum);
   hipStream_t st = fgs_s(stream);
-  // device-side row count (fgs_set_row_count_ptr): supported by the one-tile-per-workgroup NT / NN form (rows = M); the
+  // device-side row count (fgs_dyn_t.row_count): supported by the one-tile-per-workgroup NT / NN form (rows = M); the
   // split-K reduction over the rows (TN) and the stream-K grid take their partition from the host count
   if (fgs_dyn_rows(dyn)) {
     FGS_REQUIRE(op != FGS_GEMM_TN && !workspace, FGS_E_INVALID,
-                "fgs_gemm_f32: TN / stream-K are not available under fgs_set_row_count_ptr (use fgs_mlp_wgrad)");
-    FGS_REQUIRE(!colsum, FGS_E_INVALID, "fgs_gemm_f32: colsum is not available under fgs_set_row_count_ptr");
+                "fgs_gemm_f32: TN / stream-K are not available under fgs_dyn_t.row_count (use fgs_mlp_wgrad)");
+    FGS_REQUIRE(!colsum, FGS_E_INVALID, "fgs_gemm_f32: colsum is not available under fgs_dyn_t.row_count");
     g.m_dev = fgs_dyn_rows(dyn);
   }
   g.stamps = fgs_dyn_stamps(dyn);

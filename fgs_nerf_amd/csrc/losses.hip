@@ -14,7 +14,7 @@ namespace {
 
 struct LossArgs {
   int64_t N, M;
-  const int64_t *m_dev;   // fgs_set_row_count_ptr: M is then the capacity
+  const int64_t *m_dev;   // fgs_dyn_t.row_count: M is then the capacity
   const float *rgb_marched, *sigmoid_rgb, *target, *alphainv_cum;  // per ray
   const float *weights, *normal, *raw_rgb;                         // per survivor
   const int64_t *ray_id;

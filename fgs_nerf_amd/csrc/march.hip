@@ -27,7 +27,7 @@ struct MarchArgs {
   const float *sdf;
   float dist;    // stepsize * voxel_size (fp32), model/nerf.py:795
   float inv_s;   // 1 / s_val (fp32 division), model/nerf.py:522
-  const float *inv_s_dev;   // fgs_set_inv_s_ptr: read inv_s from the device (schedule table of a captured step)
+  const float *inv_s_dev;   // fgs_dyn_t.inv_s: read inv_s from the device (schedule table of a captured step)
   float thres;   // fast_color_thres
   // optional mask cache (model/nerf.py:1192-1209): max-pooled sdf_mask grid with its own bbox
   const float *mask_grid;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_march_fine_fwd(MarchArgs A) {
 // ---- survivor list: position t in [0, M_s) -> (ray, record) and the per-survivor arrays of the result dict --------
 struct CompactArgs {
   int64_t n_rays, n_surv_total;
-  const int64_t *m_dev;     // fgs_set_row_count_ptr: n_surv_total is then the capacity of the output arrays
+  const int64_t *m_dev;     // fgs_dyn_t.row_count: n_surv_total is then the capacity of the output arrays
   const int64_t *surv_off;  // [n_rays + 1] exclusive scan of n_surv
   int max_steps;
   const int *surv_slot, *a_step;

@@ -347,7 +347,7 @@ int fgs_mlp_fwd_f32(int64_t M, int n_layers, const float *X0, int64_t ldx0, int 
  *                         whose input gradient this is); NULL: none
  *   image_ws            : scratch for the packed weight images, fgs_mlp_rc_image_floats() floats, 16-byte aligned (its last
  *                         2 KB are a sink that lanes without a sample store into; never read)
- * Honours fgs_set_row_count_ptr (M = capacity).  The reduction order of a sum differs from fgs_gemm_f32's (pairs (k, k+4));
+ * Honours fgs_dyn_t.row_count (M = capacity).  The reduction order of a sum differs from fgs_gemm_f32's (pairs (k, k+4));
  * results are deterministic but not bit-identical to the LDS-resident chain. */
 typedef struct fgs_rc_layer {
   const float *W; int64_t ldw; int n_out, n_in;
@@ -363,7 +363,7 @@ int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t
  *   dW[n_out, n_in] += dY[M, n_out]^T . X[M, n_in]      dbias[n_out] += column sums of dY   (dbias may be NULL)
  * with fp32 atomics (zero-initialise dW / dbias).  The samples are split over the chip, a workgroup holds a 256 x 256 block
  * of one dW in its accumulators and streams dY / X rows straight into MFMA operands.  n_out <= 256; n_in any (blocks of 256
- * columns); all matrices row-major, 4-byte aligned.  Honours fgs_set_row_count_ptr (M = capacity). */
+ * columns); all matrices row-major, 4-byte aligned.  Honours fgs_dyn_t.row_count (M = capacity). */
 typedef struct fgs_wgrad_item {
   const float *dY; int64_t ld_dy; int n_out;
   const float *X; int64_t ld_x; int n_in;
@@ -398,7 +398,7 @@ int fgs_pad_cols_multi(int n, const float *const *src, const int *rows, const in
                        float *const *dst, const int64_t *ld_dst, fgs_stream_t stream);
 /* The same with the number of columns WRITTEN per destination row given apart from the pitch (cols[i] <= width[i] <= ld_dst[i];
  * NULL: the pitch): destinations may be column ranges of one wider matrix, i.e. a gather of column ranges in one launch (the
- * first rgbnet layer's weights without the columns of the xyz / view-direction encodings, see fgs_set_dx0_compact). */
+ * first rgbnet layer's weights without the columns of the xyz / view-direction encodings, see fgs_dyn_t.dx0_compact). */
 int fgs_copy_cols_multi(int n, const float *const *src, const int *rows, const int *cols, const int64_t *ld_src,
                         float *const *dst, const int64_t *ld_dst, const int *width, fgs_stream_t stream);
 /* Diagnostics: one matrix copied with the index expression fgs_pad_cols_multi's kernel had before fgs_copy_cols_multi existed
