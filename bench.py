@@ -233,20 +233,179 @@ def rccl_graph_selftest(dev, timeout_s: float = 20.0) -> bool:
     return bool(int(flag.item()))
 
 
-def launch_ranks(n_gpus: int, argv) -> int:
-    """One process per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port); returns the children's
-    exit status (non-zero if any rank failed: torchrun tears the others down)."""
+# ---- N > 1: a run that cannot end without a line -------------------------------------------------------------------------
+# The process a launcher (the driver's torch.distributed.run, or launch_ranks below) starts per GPU is a SUPERVISOR: it never
+# initialises HIP, talks to its peers over gloo (CPU) and runs the real rank -- the WORKER -- as a child process with a
+# rendezvous port of its own.  Attempt 1 is the default form (captured step, collectives inside the hipGraph, two
+# communicators, the sdf exchange tuned on the node).  If any worker exits non-zero, prints no line or passes the deadline, every
+# supervisor kills its worker's process group and all of them start a FRESH set of workers in the conservative form
+# (DESIGN section 8.4's switch list), and the line says so (`config.launcher`, `config.fallback_reason`).  Nothing that has
+# touched the GPU is ever re-exec'ed or reused: children only.
+ATTEMPTS = (
+    {"label": "default", "argv": [], "env": {}},
+    {"label": "conservative: host-driven step (--mode eager: no collective inside a hipGraph), one communicator "
+              "(FGS_DIST_ONE_COMM=1), untuned sdf exchange (FGS_SDF_TUNE=0)",
+     "argv": ["--mode", "eager"], "env": {"FGS_DIST_ONE_COMM": "1", "FGS_SDF_TUNE": "0"}},
+)
+
+
+def _free_ports(n):
     import socket
+    socks = [socket.socket() for _ in range(n)]
+    try:
+        for s_ in socks:
+            s_.bind(("127.0.0.1", 0))
+        return [s_.getsockname()[1] for s_ in socks]
+    finally:
+        for s_ in socks:
+            s_.close()
+
+
+def _kill_group(proc, grace_s=5.0):
+    """SIGTERM, then SIGKILL, to the worker's whole process group (it was started as a session leader)."""
+    import signal
+    if proc.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait)
+            return
+        except Exception:      # noqa: BLE001  (subprocess.TimeoutExpired)
+            continue
+
+
+def _tail(path, n_lines=6, n_chars=600):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - 8192))
+            txt = f.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+    return "\n".join(txt.strip().splitlines()[-n_lines:])[-n_chars:]
+
+
+def _json_line(path):
+    try:
+        with open(path) as f:
+            lines = [ln for ln in f.read().splitlines() if ln.strip()]
+    except OSError:
+        return None
+    for ln in reversed(lines):
+        if ln.lstrip().startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def supervise_rank(args, argv) -> int:
+    """See the block comment above.  Returns the exit status of this (supervisor) process: 0 when a line with a number was
+    written, 3 when both attempts failed (rank 0 still writes a line, `value` null, saying why)."""
+    import datetime
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import tempfile
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    deadline_s = float(os.environ.get("FGS_BENCH_ATTEMPT_DEADLINE_S", "240"))
+    if "WORLD_SIZE" not in os.environ:       # (forced single-rank rehearsal: no launcher set the rendezvous up)
+        os.environ.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": str(_free_ports(1)[0])})
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=max(180.0, 2 * deadline_s)))
+    box = [_free_ports(len(ATTEMPTS)) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ports = box[0]
+    tmp = tempfile.mkdtemp(prefix=f"fgs_bench_r{rank}_", dir=os.environ.get("TMPDIR", "/tmp"))
+    history, line, used = [], None, None
+    for k, att in enumerate(ATTEMPTS, start=1):
+        env = {k_: v for k_, v in os.environ.items() if not k_.startswith("TORCHELASTIC_")}
+        env.update(att["env"])
+        env.update({"FGS_BENCH_WORKER": "1", "FGS_BENCH_ATTEMPT": str(k), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(ports[k - 1]),
+                    "RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": os.environ.get("LOCAL_RANK", str(rank))})
+        env.setdefault("FGS_BENCH_PG_TIMEOUT_S", str(int(min(120.0, max(10.0, deadline_s / 2)))))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out_p, err_p = os.path.join(tmp, f"a{k}.out"), os.path.join(tmp, f"a{k}.err")
+        with open(out_p, "wb") as fo, open(err_p, "wb") as fe:
+            proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv, *att["argv"]], env=env, stdout=fo, stderr=fe,
+                                    start_new_session=True)
+        t0 = time.perf_counter()
+        while True:
+            rc = proc.poll()
+            mine = torch.tensor([int(rc is not None and rc != 0), int(rc is None), int(time.perf_counter() - t0 > deadline_s)],
+                                dtype=torch.int32)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX)          # one decision for all supervisors, every half second
+            any_failed, any_running, any_late = (int(v) for v in mine.tolist())
+            if any_failed or not any_running or any_late:
+                break
+            time.sleep(0.5)
+        rc = proc.poll()
+        _kill_group(proc)
+        got = _json_line(out_p) if rank == 0 else None
+        # a line with a number means the timed region and the cross-rank reductions behind it completed on every rank: it
+        # stands even if some rank then died or hung in teardown (its exit status is recorded next to it)
+        ok = [bool(got is not None and got.get("value") is not None) if rank == 0 else None]
+        dist.broadcast_object_list(ok, src=0)
+        with open(err_p, "rb") as fe:            # the worker's stderr, after the fact (kept in a file so that its tail can be quoted)
+            sys.stderr.write(fe.read().decode("utf-8", "replace"))
+            sys.stderr.flush()
+        report = [None] * world
+        dist.all_gather_object(report, {"rank": rank, "exit": rc, "stderr_tail": "" if rc == 0 else _tail(err_p)})
+        history.append({"attempt": k, "form": att["label"], "ok": ok[0], "hit_deadline_s": deadline_s if any_late and any_running else None,
+                        "ranks": [r for r in report if r["exit"] != 0][:3]})
+        if ok[0]:
+            line, used = got, k
+            break
+        if rank == 0:
+            print(f"[bench] attempt {k} ({att['label']}) did not produce a line: {history[-1]}", file=sys.stderr, flush=True)
+    if rank == 0:
+        if line is None:
+            line = {"metric": f"M ray-samples/sec (fwd+bwd), {args.grid}^3 grid, {args.rays}-ray batch", "value": None,
+                    "unit": "M ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "configs[1]"}, "broken": "every attempt of the multi-GPU run failed (config.launcher)"}
+        cfg = line.setdefault("config", {})
+        cfg["launcher"] = {"supervised": True, "attempt_used": used, "attempt_deadline_s": deadline_s, "attempts": history}
+        if used is not None and used > 1:
+            first = history[0]
+            why = ("deadline of %.0f s passed" % deadline_s) if first["hit_deadline_s"] else "a rank exited non-zero or printed no line"
+            cfg["fallback_reason"] = (f"attempt 1 ({first['form']}) failed: {why}; "
+                                      + " | ".join(f"rank {r['rank']} exit {r['exit']}: {r['stderr_tail'][-300:]}" for r in first["ranks"]))
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return 0 if used is not None else 3
+
+
+def launch_ranks(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` with no launcher around it: one supervisor per GPU through torch.distributed.run (rendezvous
+    on 127.0.0.1, a free port).  This parent never initialises HIP; it gives the whole run a deadline of its own (both
+    attempts + start-up) and kills the launcher's process group if that passes.  Returns the launcher's exit status."""
+    import subprocess
+    port = _free_ports(1)[0]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    overall = len(ATTEMPTS) * float(os.environ.get("FGS_BENCH_ATTEMPT_DEADLINE_S", "240")) + 180.0
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=overall)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the launcher did not finish within {overall:.0f} s: killing it", file=sys.stderr, flush=True)
+        _kill_group(proc)
+        return 124
 
 
 def replica_digest_spread(digests) -> float:
@@ -261,13 +420,24 @@ def replica_digest_spread(digests) -> float:
 
 
 def dry_rank(args) -> int:
-    """FGS_BENCH_DRY=gloo: rehearse the launcher and the cross-rank reporting protocol on CPU (no device work, no timing
-    claim): process group, barrier, MAX / SUM reductions, rank 0 prints the JSON line with the world size it saw."""
+    """FGS_BENCH_DRY=gloo: rehearse the launcher, the supervisors and the cross-rank reporting protocol on CPU (no device work, no
+    timing claim): process group, barrier, MAX / SUM reductions, rank 0 prints the JSON line with the world size it saw.
+    FGS_BENCH_DRY_FAIL=exit|hang makes rank FGS_BENCH_DRY_FAIL_RANK (default: the last) fail that way in attempt 1 only."""
+    import datetime
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    fail = os.environ.get("FGS_BENCH_DRY_FAIL") if os.environ.get("FGS_BENCH_ATTEMPT", "1") == "1" else None
+    fail_rank = int(os.environ.get("FGS_BENCH_DRY_FAIL_RANK", str(world - 1)))
     if world > 1:
-        dist.init_process_group(backend=os.environ["FGS_BENCH_DRY"])
+        dist.init_process_group(backend=os.environ["FGS_BENCH_DRY"],
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("FGS_BENCH_PG_TIMEOUT_S", "120"))))
         dist.barrier()
+    if fail and rank == fail_rank:
+        if fail == "hang":
+            print(f"[dry] rank {rank}: hanging on purpose", file=sys.stderr, flush=True)
+            time.sleep(3600)
+        print(f"[dry] rank {rank}: failing on purpose", file=sys.stderr, flush=True)
+        os._exit(17)
     stats = torch.tensor([1.0 + rank, 100.0], dtype=torch.float64)
     tmax, ssum = stats[:1].clone(), stats[1:].clone()
     if world > 1:
@@ -278,8 +448,10 @@ def dry_rank(args) -> int:
         print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launcher rehearsal, no device work)", "value": None, "n_gpus": seen,
-                          "steps": args.steps, "warmup": args.warmup, "max_elapsed": float(tmax), "sum_units": float(ssum)}),
+        print(json.dumps({"metric": "dry run (launcher rehearsal, no device work)", "value": 0.0, "n_gpus": seen,
+                          "steps": args.steps, "warmup": args.warmup, "max_elapsed": float(tmax), "sum_units": float(ssum),
+                          "config": {"step_mode": f"dry ({args.mode})", "one_comm": os.environ.get("FGS_DIST_ONE_COMM"),
+                                     "sdf_tune": os.environ.get("FGS_SDF_TUNE")}}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -313,6 +485,11 @@ def main():
     # in this process touches the GPU (the parent never initialises HIP and never replaces itself with another program).
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # N > 1 under a launcher (the driver's torch.distributed.run, or ours): this process supervises, a child is the rank
+    # (FGS_BENCH_SUPERVISE=force: also at --gpus 1, the one-GPU rehearsal of this machinery with FGS_FORCE_DIST=1; =0: off)
+    sup = os.environ.get("FGS_BENCH_SUPERVISE", "1")
+    if (args.gpus > 1 and sup != "0" or sup == "force") and os.environ.get("FGS_BENCH_WORKER") != "1":
+        sys.exit(supervise_rank(args, sys.argv[1:]))
     if os.environ.get("FGS_BENCH_DRY"):
         sys.exit(dry_rank(args))
 
@@ -351,9 +528,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+        # RCCL over xGMI.  The timeout bounds rendezvous AND every collective (the watchdog aborts the process past it): a rank
+        # that lost its peers ends within two minutes and the supervisor above starts the conservative attempt
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=dev,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("FGS_BENCH_PG_TIMEOUT_S", "120"))))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("FGS_BENCH_FAIL_ATTEMPT1") and os.environ.get("FGS_BENCH_ATTEMPT") == "1":
+        # test switch: a rank that dies AFTER it has initialised the GPU and joined the group (tests/test_bench_gpu.py)
+        torch.zeros(1, device=dev)
+        print(f"[bench] rank {rank}: failing on purpose (FGS_BENCH_FAIL_ATTEMPT1)", file=sys.stderr, flush=True)
+        os._exit(17)
 
     model = synth.build_model(GRID, synth.FINE_MODEL if args.stage == "fine" else synth.COARSE_MODEL, device=dev,
                               fused=False if args.composed else None)
@@ -678,6 +864,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or force_dist:
+        dist.barrier()                # (the line is out before any rank starts tearing its communicators down)
         if captured is not None:
             captured.release()        # graphs holding RCCL nodes go before the communicator does
         dist.destroy_process_group()

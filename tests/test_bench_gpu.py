@@ -49,3 +49,14 @@ def test_forced_single_rank_group_runs_the_captured_exchange(dev):
     assert "gradient exchange included" in d["config"]["step_mode"] and "broken" not in d
     assert d["config"]["replicas_in_sync"] is True and d["config"]["replica_digest_spread"] == 0.0
     assert d["config"]["k0_exchange"]["bytes_per_step"] > 0
+
+
+def test_supervised_run_falls_back_to_fresh_conservative_children(dev):
+    """The N > 1 safety net on the GPU box (single-rank RCCL group): the supervisor -- which never touches the GPU -- sees its
+    worker die after HIP and RCCL initialisation, starts a fresh one with the conservative switches and forwards ITS line."""
+    d = _bench({"FGS_FORCE_DIST": "1", "FGS_BENCH_SUPERVISE": "force", "FGS_BENCH_FAIL_ATTEMPT1": "1", "FGS_BENCH_ATTEMPT_DEADLINE_S": "200"},
+               "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-pmc")
+    cfg = d["config"]
+    assert cfg["launcher"]["attempt_used"] == 2 and "exit 17" in cfg["fallback_reason"]
+    assert "eager launches" in cfg["step_mode"] and cfg["replicas_in_sync"] is True and "broken" not in d
+    assert d["value"] > 50 and d["roofline"]["frac"] > 0.3
