@@ -54,6 +54,13 @@ __device__ __forceinline__ unsigned long long *fgs_stamp_base(const FgsStamps &s
   if (!s.p) return nullptr;
   return s.step ? s.p + (*s.step % s.slots) * s.stride : s.p;
 }
+// The 8-word record of THIS workgroup inside a launch's region of FGS_STAMP_WGS * 8 words (the size include/fgs_hip.h states);
+// workgroups beyond it do not stamp (a grid larger than the CU count would otherwise write into the next launch's region).
+constexpr unsigned FGS_STAMP_WGS = 256;
+__device__ __forceinline__ unsigned long long *fgs_stamp_wg(const FgsStamps &s) {
+  unsigned long long *b = fgs_stamp_base(s);
+  return (b && blockIdx.x < FGS_STAMP_WGS) ? b + 8 * blockIdx.x : nullptr;
+}
 #endif
 
 constexpr int FGS_WAVE = 64;      // gfx950 wavefront

@@ -443,10 +443,10 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   const int64_t nb = (M + RC_BLOCK - 1) / RC_BLOCK;
   if ((int64_t)blockIdx.x >= nb) return;
   const int64_t my_blocks = (nb - blockIdx.x + gridDim.x - 1) / gridDim.x;
-  unsigned long long *const stamps = fgs_stamp_base(a.stamps);
+  unsigned long long *const stamps = fgs_stamp_wg(a.stamps);
   if (stamps && tid == 0) {
-    stamps[8 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
-    stamps[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    stamps[0] = __builtin_amdgcn_s_memtime();
+    stamps[1] = __builtin_amdgcn_s_memrealtime();
   }
   RcState s;
   s.a = &a; s.ring = ring; s.issued = 0; s.total_steps = __builtin_amdgcn_readfirstlane((int)(my_blocks * a.total_chunks));
@@ -521,10 +521,10 @@ __global__ __launch_bounds__(RC_THREADS, 1) void k_mlp_rc(RcArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (stamps && tid == 0) {
-    stamps[8 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
-    stamps[8 * blockIdx.x + 4] = s.t_init; stamps[8 * blockIdx.x + 5] = s.t_chunks;
-    stamps[8 * blockIdx.x + 6] = s.t_epi; stamps[8 * blockIdx.x + 7] = s.t_load;
+    stamps[2] = __builtin_amdgcn_s_memtime();
+    stamps[3] = __builtin_amdgcn_s_memrealtime();
+    stamps[4] = s.t_init; stamps[5] = s.t_chunks;
+    stamps[6] = s.t_epi; stamps[7] = s.t_load;
   }
 }
 

@@ -322,8 +322,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
   const WgBlock &b = a.B[blk];
   const int j = (int)blockIdx.x - b.wg0;
   if (j >= b.n_wg) return;
-  unsigned long long *stamps = fgs_stamp_base(a.stamps);
-  if (stamps) stamps += 8 * blockIdx.x;
+  unsigned long long *stamps = fgs_stamp_wg(a.stamps);
   if (stamps && threadIdx.x == 0) {
     stamps[0] = __builtin_amdgcn_s_memtime(); stamps[1] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)blk;
   }

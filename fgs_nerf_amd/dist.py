@@ -391,10 +391,16 @@ class GradAverager:
         out = dict(tuned=False)
         if (self.world_size == 1 and not self.force) or not (param.dim() == 5 and param.shape[1] == 1):
             return out
+        if self.sparse_1ch_min_numel is None:        # "always dense", asked for explicitly: nothing to decide
+            return out
         _, _, X, Y, Z = param.shape
         if X % BRICK or Y % BRICK or Z % BRICK:
             return out
         total = (X // BRICK) * (Y // BRICK) * (Z // BRICK)
+        seen = self.max_union_bricks.get(id(param))      # a union count measured on this grid beats the estimate
+        if seen:
+            fill_estimate = seen / total
+            out['fill_measured'] = round(fill_estimate, 4)
         cap = min(total, (int(1.5 * fill_estimate * total) + 255) // 256 * 256)
         dev = param.device
         dense = torch.zeros(param.numel(), dtype=torch.float32, device=dev)
@@ -461,6 +467,11 @@ class GradAverager:
         self.params = [p for p in params if p.requires_grad]
         self._hints.clear()
         self._deferred.clear()
+        # everything keyed by id(param): the old grids are freed and a new parameter may get a recycled id -- a stale capacity
+        # (sized from the smaller grid's union count) would overflow at once, a stale dense_sources entry would suppress hints
+        self._static.clear()
+        self.max_union_bricks.clear()
+        self.dense_sources.clear()
 
     def attach_optimizer(self, optimizer) -> None:
         """Let the optimizer wait for an early exchange only when it reaches that parameter (MaskedAdam.before_param):

@@ -367,9 +367,14 @@ class CapturedFineStep:
         return fused.sync_free_state(self.model)
 
     def exchange_overflowed(self) -> bool:
-        """The union of touched k0 bricks exceeded `exchange_capacity` in some replay (one device->host read).  The replicas
-        are still identical -- every rank skipped every update from that step on -- but the persistent gradient buffer holds
-        leftovers: call fused.reset_grid_grad(model), then capture again with a larger capacity."""
+        """The union of touched k0 (or sdf) bricks exceeded its exchange capacity in some replay (one device->host read).  The
+        replicas are still identical -- every rank skipped every update from that step on -- but the persistent gradient buffer
+        holds leftovers: call fused.reset_grid_grad(model), then capture again with a larger capacity.
+        One exception to "every update": k0's Adam pass runs inside the backward pass, behind k0's own exchange, BEFORE the sdf
+        exchange's occupancy guard exists (sdf.grad is only final at the end of the backward pass).  In the iteration in which the
+        SDF exchange overflows, k0 has therefore already stepped while sdf and the MLPs are skipped: one torn iteration, the same
+        on every rank (the union count is all-reduced), after which everything is frozen.  A caller that must not keep it restores
+        parameters and optimizer state from its last checkpoint before the logging window in which the flag was raised."""
         return any(bool(int(st['sticky'].cpu()[0])) for st in (self._exchange_state, self._sdf_exchange_state) if st is not None)
 
 

@@ -46,10 +46,16 @@ _SCRATCH = {}     # device index -> per-block partial sums of fgs_fine_loss_fwd 
                   # flight at the same time on different streams would share it: not a pattern of this path.)
 
 
+_SCRATCH_RETIRED = []     # outgrown buffers are kept, never freed: a hipGraph captured while one of them was current holds its raw
+                          # address, and its replays keep writing block sums and the arrival counter there (a few KB each)
+
+
 def _loss_scratch(dev, need: int) -> torch.Tensor:
     key = dev.index
     t = _SCRATCH.get(key)
     if t is None or t.numel() < need:
+        if t is not None:
+            _SCRATCH_RETIRED.append(t)
         t = _SCRATCH[key] = torch.zeros(max(need, 2048), dtype=torch.float32, device=dev)
     return t
 

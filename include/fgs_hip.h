@@ -68,7 +68,7 @@ typedef struct fgs_dyn {
   /* Measurement only (no effect on results; NULL = off), honoured by the matrix-core entries fgs_mlp_rc_chain, fgs_mlp_wgrad and
    * fgs_gemm_f32: the launch writes 100 MHz wall-clock readings (s_memrealtime) of its workgroups into
    * stamps + (*stamp_step % stamp_slots) * stamp_stride (uint64 units; stamp_step NULL: slot 0) -- the chain and weight-gradient
-   * kernels 8 words per workgroup (word 1 = start, word 3 resp. 5 = end; >= 2048 words), the tiled product two words
+   * kernels 8 words per workgroup (word 1 = start, word 3 resp. 5 = end; a region of 2048 words: workgroups >= 256 do not stamp), the tiled product two words
    * (~min start, max end, by atomicMax: zero-initialise).  A captured step thereby times its own launches: bench.py's roofline
    * figure comes from the replays of the timed region itself (a graph replay cannot carry HIP events). */
   unsigned long long *stamps;
