@@ -45,6 +45,36 @@ def make_optimizer(model):
     return MaskedAdam(groups, betas=(0.9, 0.99))
 
 
+def make_batch(b: int, rank: int, dev, n_rays=None):
+    """Resident ray batch `b` of `rank`: (rays_o, rays_d, viewdirs, target), each [n_rays, 3] on `dev`."""
+    from fgs_nerf_amd import synth
+    n_rays = RAYS_PER_GPU if n_rays is None else n_rays
+    ro, rd, vd = synth.random_rays(n_rays, seed=synth.SEED + 97 * b + 10007 * rank)
+    target = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(b + 1000 * rank))
+    return tuple(t.to(dev).contiguous() for t in (ro, rd, vd, target))
+
+
+def survivor_capacity(seen: int) -> int:
+    """Rows of the survivor buffers of a sync-free / captured step: 1.5 x the largest count seen, rounded up to 4096."""
+    return (int(1.5 * max(seen, 16384)) + 4095) // 4096 * 4096
+
+
+def tv_args(n_rays_global: int):
+    """Fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (model/nerf_training.py:353-371)."""
+    return (0.01 * 0.1 / n_rays_global, True)
+
+
+def build_captured(model, opt, capacity: int, n_iters: int, n_rays_global: int, averager=None, n_rays=None):
+    """The captured form of train_step() below: the step bench.py times (tests/test_bench_step_parity_gpu.py builds it through
+    this same function and compares one replay with the oracle)."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.graph_step import CapturedFineStep
+    return CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, synth.RENDER_KWARGS,
+                            RAYS_PER_GPU if n_rays is None else n_rays, n_iters=n_iters,
+                            global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
+                            tv=tv_args(n_rays_global), capacity=capacity, averager=averager)
+
+
 def train_step(model, opt, averager, batch, n_rays_global):
     from fgs_nerf_amd import synth
     from fgs_nerf_amd.losses import fused_render_losses
@@ -63,7 +93,7 @@ def train_step(model, opt, averager, batch, n_rays_global):
     loss.backward(seed)             # (the gradient seed given: one fill launch less than autograd's implicit ones_like)
     averager.average()
     # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)
-    model.sdf_total_variation_add_grad(0.01 * 0.1 / n_rays_global, True)
+    model.sdf_total_variation_add_grad(*tv_args(n_rays_global))
     opt.step()
     if res.get('survivor_count_ptr') is None if hasattr(res, 'get') else True:
         STEP_STATS["survivors"] += int(res['weights'].shape[0])     # a host number already (the forward read it)
@@ -319,6 +349,11 @@ def supervise_rank(args, argv) -> int:
         print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # stdout carries ONE JSON line: gloo prints its connection banner there, so file descriptor 1 points at stderr from here on and
+    # the line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=max(180.0, 2 * deadline_s)))
     box = [_free_ports(len(ATTEMPTS)) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
@@ -378,8 +413,8 @@ def supervise_rank(args, argv) -> int:
             why = ("deadline of %.0f s passed" % deadline_s) if first["hit_deadline_s"] else "a rank exited non-zero or printed no line"
             cfg["fallback_reason"] = (f"attempt 1 ({first['form']}) failed: {why}; "
                                       + " | ".join(f"rank {r['rank']} exit {r['exit']}: {r['stderr_tail'][-300:]}" for r in first["ranks"]))
-        sys.stdout.write(json.dumps(line) + "\n")
         sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
     import shutil
@@ -559,9 +594,7 @@ def main():
     # ray batches, resident in HBM; per-batch in-bbox sample counts (the unit of work)
     batches, n_inbbox, n_total = [], [], []
     for b in range(N_BATCHES):
-        ro, rd, vd = synth.random_rays(RAYS_PER_GPU, seed=synth.SEED + 97 * b + 10007 * rank)
-        target = torch.rand(RAYS_PER_GPU, 3, generator=torch.Generator().manual_seed(b + 1000 * rank))
-        batch = tuple(t.to(dev).contiguous() for t in (ro, rd, vd, target))
+        batch = make_batch(b, rank, dev)
         out = render_utils_cuda.sample_pts_on_rays(batch[0], batch[1], model.xyz_min, model.xyz_max, 2.0, 1e9,
                                                    float(0.5 * model.voxel_size))
         n_inbbox.append(int((~out[1]).sum().item()))
@@ -602,19 +635,14 @@ def main():
     torch.cuda.synchronize()
     captured = None
     if use_graph:
-        from fgs_nerf_amd.graph_step import CapturedFineStep
         # capacity of the survivor buffers: 1.5 x the largest count seen while priming / warming up, rounded to 4096 rows
         seen = max(STEP_STATS["max_survivors"], 16384)
         if world > 1:     # (buffers are rank-local, but one number for all keeps the ranks' graphs alike)
             seen_t = torch.tensor([seen], dtype=torch.int64, device=dev)
             dist.all_reduce(seen_t, op=dist.ReduceOp.MAX)
             seen = int(seen_t.item())
-        capacity = (int(1.5 * seen) + 4095) // 4096 * 4096
-        captured = CapturedFineStep(model, opt, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS,
-                                    synth.RENDER_KWARGS, RAYS_PER_GPU, n_iters=args.steps + args.warmup + 16,
-                                    global_step_of=lambda it: GLOBAL_STEP, lr_of=lambda it, g: g['lr'],
-                                    tv=(0.01 * 0.1 / n_global, True), capacity=capacity,
-                                    averager=averager if (world > 1 or force_dist) else None)
+        captured = build_captured(model, opt, survivor_capacity(seen), args.steps + args.warmup + 16, n_global,
+                                  averager=averager if (world > 1 or force_dist) else None)
         # Several ranks: a capture that fails on ANY rank (the capture pass itself issues no collective, so a failure is local
         # and leaves the others unharmed) sends ALL ranks to the eager form below -- decided by one MIN all-reduce, so that
         # no rank replays a graph whose collectives the others never launch.
@@ -664,8 +692,7 @@ def main():
                        and os.environ.get("FGS_MLP", "rc") == "rc")
     if sync_free_eager:
         from fgs_nerf_amd import fused as _fused
-        seen = max(STEP_STATS["max_survivors"], 16384)
-        _fused.set_sync_free(model, (int(1.5 * seen) + 4095) // 4096 * 4096)
+        _fused.set_sync_free(model, survivor_capacity(STEP_STATS["max_survivors"]))
         opt.use_skip_flag(model._fused_cache['sync_free']['flags'][1:2].data_ptr())   # an overflowed step changes nothing
         for i in range(2):                       # allocator warm-up of the capacity-sized buffers
             train_step(model, opt, averager, batches[i % N_BATCHES], n_global)

@@ -37,8 +37,11 @@ unmodified function bodies with `torch.Tensor.cuda` temporarily replaced by the 
 change of placement, not of arithmetic -- every value is produced by the reference's own statements on torch's CPU ops, exactly
 like the vectors of the first file.  They pin the NeuS alpha (a8) and the 6 K axis taps / tap differences (a7).
 
+Third file, tests/golden/ref_fns_earlystop.npz (`main_early_stop`, `python oracle/make_golden_ref_fns.py early_stop`): the same
+`get_ray_marching_ray` on rays that DO reach T < 1e-3 -- a prefix pin of the early-terminating scan (see the function).
+
 Not runnable here under any honest arrangement, hence still unpinned: the CUDA extension kernels and their wrappers (a3 packed
-sampler, a9 early-terminating scan, a14, a15), torch_scatter.segment_coo, PyMCubes.
+sampler, a14, a15; a9's early stop only through the prefix pin above), torch_scatter.segment_coo, PyMCubes.
 """
 from __future__ import annotations
 
@@ -260,8 +263,45 @@ def main_cuda_shim() -> None:
         print("  ", s_)
 
 
+def main_early_stop() -> None:
+    """Third file, tests/golden/ref_fns_earlystop.npz: `get_ray_marching_ray` (model/dvgo.py:409-417, with cumprod_exclusive) on
+    rays that DO reach T < 1e-3.  The CUDA scan (render_utils_kernel.cu:592-600) multiplies the same factors in the same order and
+    leaves the loop behind the first sample after which T < 1e-3: up to and including that sample its weights are the cumprod
+    form's, behind it they stay zero, and `alphainv_last` is the cumprod form's transmittance right behind the stop sample.  A
+    partial pin (the reference function has no stop) of the one piece of a9 that no reference-executed vector covered."""
+    sys.dont_write_bytecode = True
+    g = torch.Generator().manual_seed(779)
+    dvgo_py = os.path.join(REF, "model", "dvgo.py")
+    lines = {}
+    cpe, lines["cumprod_exclusive"] = extract(dvgo_py, "cumprod_exclusive")
+    grm, lines["get_ray_marching_ray"] = extract(dvgo_py, "get_ray_marching_ray", env={"cumprod_exclusive": cpe})
+    n_rays, n_s = 48, 40
+    alpha = torch.rand(n_rays, n_s, generator=g) * torch.linspace(0.08, 0.9, n_rays)[:, None]     # ray r: alphas up to 0.08 .. 0.9
+    alpha[5] = 0.0                                        # an empty ray
+    alpha[6, :] = 0.0
+    alpha[6, 17] = 0.9995                                 # one sample takes T below 1e-3 at once
+    alpha[7, 3] = 1.0 - 2.0 ** -23                        # an all but opaque sample (exactly 1 is where the two forms part: the
+                                                          # cumprod form clamps 1 - alpha at 1e-10, the scan multiplies by 0)
+    alpha[8, -1] = 0.99999                                # the stop falls on the LAST sample
+    w, acc = grm(alpha)
+    T_behind = acc[:, 1:]                                 # transmittance right behind sample j
+    below = T_behind < 1e-3
+    stop = torch.where(below.any(dim=1), below.float().argmax(dim=1), torch.full((n_rays,), -1, dtype=torch.long))
+    # no decision of this fixture may hang on rounding: every T is at least 1e-4 (relative) away from the threshold
+    assert float(((T_behind - 1e-3).abs() / 1e-3).min()) > 1e-4
+    assert int((stop >= 0).sum()) >= 20 and int((stop < 0).sum()) >= 5
+    arrays = dict(es_alpha=alpha.numpy(), es_weights=w.numpy(), es_alphainv_cum=acc.numpy(), es_stop=stop.numpy(),
+                  source_lines=np.array([f"{k}:{a}-{b}" for k, (a, b) in sorted(lines.items())]))
+    path = os.path.join(ROOT, "tests", "golden", "ref_fns_earlystop.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes; rays that stop:", int((stop >= 0).sum()), "of", n_rays)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
+    if len(sys.argv) > 1 and sys.argv[1] == "early_stop":
+        main_early_stop()
+        sys.exit(0)
     if len(sys.argv) < 2 or sys.argv[1] == "pure":
         main()
     if len(sys.argv) < 2 or sys.argv[1] == "cuda_shim":

@@ -67,9 +67,17 @@ def test_captured_step_matches_eager_steps(dev):
     for a, b in zip(losses_g, losses_e):
         assert abs(a - b) < 2e-4 * abs(b), (losses_g, losses_e)
     assert not torch.equal(model2.k0.grid, p0)
-    for pa, pb in zip(model.parameters(), model2.parameters()):
+    # element by element (conftest.adam_drift_report): both runs are the same kernels, apart only in the order of float atomics
+    from conftest import adam_drift_report
+    lr_of = {id(p): _lr_schedule(0, dict(g, lr=b)) for g, b in zip(opt.param_groups, base) for p in g['params']}
+    print()
+    for (name, pa), pb in zip(model.named_parameters(), model2.parameters()):
+        if pa not in opt.state:
+            continue
+        adam_drift_report(name, pb, pa, lr_of[id(pa)], ITERS, tight=1e-4, max_frac_tight=0.0, max_frac_tenth=0.0, max_frac_lr=0.0,
+                          max_worst_lr=0.02)      # (measured: no element beyond the first bar, worst 1e-3 lr)
         da = float((pa.detach() - pb.detach()).norm() / pa.detach().norm().clamp_min(1e-30))
-        assert da < 2e-3, da
+        assert da < 1e-4, da
     assert all(st['step'] == ITERS for st in opt2.state.values())
 
 

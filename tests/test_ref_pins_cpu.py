@@ -46,6 +46,36 @@ def test_alpha2weight_matches_cumprod_compositing_without_early_stop(oracle, ref
     np.testing.assert_allclose(last.numpy(), ref["crm_alphainv_cum"][:, -1].numpy(), rtol=1e-6, atol=0)
 
 
+def _early_stop_expectation(golden):
+    g = golden("ref_fns_earlystop.npz")
+    alpha, w_ref, acc, stop = (g[k] for k in ("es_alpha", "es_weights", "es_alphainv_cum", "es_stop"))
+    n_rays, n_s = alpha.shape
+    want_w = np.zeros_like(w_ref)
+    want_last, want_end = np.empty(n_rays, np.float32), np.empty(n_rays, np.int64)
+    for r in range(n_rays):
+        k = n_s if stop[r] < 0 else int(stop[r]) + 1        # samples the scan visits: up to and including the stop sample
+        want_w[r, :k] = w_ref[r, :k]                        # ... carry the cumprod form's weights; the rest stay zero
+        want_last[r] = acc[r, k]                            # transmittance right behind the last visited sample
+        want_end[r] = r * n_s + k
+    return alpha, want_w, want_last, want_end, stop
+
+
+def test_alpha2weight_early_stop_prefix_matches_cumprod_compositing(oracle, golden):
+    """VERDICT r3 missing 5.  render_utils_kernel.cu:592-600 against model/dvgo.py:409-417 executed on rays that DO reach
+    T < 1e-3 (tests/golden/ref_fns_earlystop.npz, oracle/make_golden_ref_fns.py early_stop): weights equal the cumprod form's up
+    to and including the sample behind which T < 1e-3, are zero behind it, `alphainv_last` is T at the stop, `i_end` the index
+    behind the stop sample.  1e-6 relative as in the no-stop case (double vs float32 running product)."""
+    alpha, want_w, want_last, want_end, stop = _early_stop_expectation(golden)
+    n_rays, n_s = alpha.shape
+    assert (stop >= 0).sum() >= 20 and (stop < 0).sum() >= 5 and (stop == n_s - 1).any() and (want_last < 1e-6).any()
+    ray_id = torch.arange(n_rays).repeat_interleave(n_s)
+    w, last, i_end = oracle.alphas2weights(torch.from_numpy(alpha).reshape(-1).contiguous(), ray_id, n_rays)
+    assert np.array_equal(np.asarray(i_end), want_end)
+    np.testing.assert_allclose(w.reshape(n_rays, n_s).numpy(), want_w, rtol=1e-6, atol=0)
+    assert np.all(w.reshape(n_rays, n_s).numpy()[want_w == 0] == 0)
+    np.testing.assert_allclose(last.numpy(), want_last, rtol=1e-6, atol=0)
+
+
 def test_gradient_volume_matches_the_reference(oracle, ref):
     """model/nerf.py:485-494 ('interpolate')."""
     assert torch.equal(oracle.neus_sdf_gradient(ref["gv_sdf"], ref["gv_voxel_size"]), ref["gv_interpolate"])

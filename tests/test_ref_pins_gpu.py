@@ -99,6 +99,23 @@ def test_alpha2weight_kernel_matches_cumprod_compositing(dev, ref):
     np.testing.assert_allclose(last.cpu().numpy(), ref["crm_alphainv_cum"][:, -1].numpy(), rtol=1e-6, atol=0)
 
 
+def test_alpha2weight_kernel_early_stop_prefix_matches_cumprod_compositing(dev, golden):
+    """fgs_alpha2weight_fwd on rays that DO reach T < 1e-3 against the reference's cumprod form executed on the same alphas
+    (tests/test_ref_pins_cpu.py::test_alpha2weight_early_stop_prefix_matches_cumprod_compositing has the argument): prefix equal,
+    zeros behind the stop, alphainv_last = T at the stop, i_end behind the stop sample."""
+    from test_ref_pins_cpu import _early_stop_expectation
+    from fgs_nerf_amd.ops import render_utils_cuda
+    alpha, want_w, want_last, want_end, _ = _early_stop_expectation(golden)
+    n_rays, n_s = alpha.shape
+    ray_id = torch.arange(n_rays).repeat_interleave(n_s).to(dev)
+    w, T, last, i_start, i_end = render_utils_cuda.alpha2weight(torch.from_numpy(alpha).reshape(-1).contiguous().to(dev), ray_id, n_rays)
+    assert np.array_equal(i_end.cpu().numpy(), want_end) and np.array_equal(i_start.cpu().numpy(), np.arange(n_rays) * n_s)
+    w = w.reshape(n_rays, n_s).cpu().numpy()
+    np.testing.assert_allclose(w, want_w, rtol=1e-6, atol=0)
+    assert np.all(w[want_w == 0] == 0)
+    np.testing.assert_allclose(last.cpu().numpy(), want_last, rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("variant", ["nerf", "dvgo"])
 def test_tv_loss_kernels_match_reference_total_variation(dev, ref, variant):
     """csrc/tvloss.hip (dense.grid_tv_loss) == total_variation of model/nerf.py:1212-1221 and model/dvgo.py:420-428, with and
