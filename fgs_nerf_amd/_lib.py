@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -55,6 +55,7 @@ _SIGNATURES = {
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, I32, F32, F32, F32, F32, I32, P, P],
     "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, P, P, F32, F32, F32, P, P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P, P],
+    "fgs_mlp_rc2_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P, P],
     "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P, P],
@@ -122,6 +123,12 @@ class RcLayer(ctypes.Structure):
                 ("ext", c_void_p), ("ld_ext", c_int64), ("ext_cols", c_int)]
 
 
+class Rc2Layer(ctypes.Structure):
+    """fgs_rc2_layer_t (include/fgs_hip.h): one layer of a feature-split MLP chain (csrc/mlp_rc2.hip); `side` marks a narrow
+    product of the current carried input that only goes to `out`."""
+    _fields_ = RcLayer._fields_ + [("side", c_int)]
+
+
 class WgradItem(ctypes.Structure):
     """fgs_wgrad_item_t (include/fgs_hip.h): one weight-gradient product dW += dY^T X (+ bias gradient)."""
     _fields_ = [("dY", c_void_p), ("ld_dy", c_int64), ("n_out", c_int),
@@ -157,7 +164,7 @@ def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
                                           "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats",
-                                          "fgs_adam_step_size"])
+                                          "fgs_mlp_rc2_image_floats", "fgs_adam_step_size"])
 
 
 def lib() -> ctypes.CDLL:
@@ -188,6 +195,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_adam_step_size.argtypes = [c_int, c_float, c_float, c_float]
         handle.fgs_mlp_rc_image_floats.restype = c_int64
         handle.fgs_mlp_rc_image_floats.argtypes = [c_int, c_int, c_void_p]
+        handle.fgs_mlp_rc2_image_floats.restype = c_int64
+        handle.fgs_mlp_rc2_image_floats.argtypes = [c_int, c_int, c_void_p]
         handle.fgs_mc_num_blocks.restype = c_int64
         handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

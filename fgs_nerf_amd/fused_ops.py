@@ -206,14 +206,16 @@ def rc_mask_bits(M: int, device) -> torch.Tensor:
 
 
 def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None,
-             rows_dev=None) -> None:
-    """Register-resident MLP chain (include/fgs_hip.h fgs_mlp_rc_chain).  `layers`: list of dicts with W (the nn.Linear
-    weight [n_out, >= n_in], any leading dimension) and optional n_in (default W.shape[1]), bias, relu, mask_bits (int32
-    buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext ([M, >= ext_cols] view) / ext_cols."""
+             rows_dev=None, form: int = 1) -> None:
+    """One-launch MLP chain.  form 1: register-resident activations (include/fgs_hip.h fgs_mlp_rc_chain); form 2: the waves split
+    the features, the slab's activations in LDS (fgs_mlp_rc2_chain: width 256 only, no round quantisation, `side` layers).
+    `layers`: list of dicts with W (the nn.Linear weight [n_out, >= n_in], any leading dimension) and optional n_in (default
+    W.shape[1]), bias, relu, mask_bits (int32 buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext
+    ([M, >= ext_cols] view) / ext_cols, side (form 2)."""
     import ctypes
-    from ._lib import RcLayer
+    from ._lib import Rc2Layer, RcLayer
     n = len(layers)
-    arr = (RcLayer * n)()
+    arr = ((Rc2Layer if form == 2 else RcLayer) * n)()
     for i, l in enumerate(layers):
         W = l['W']
         arr[i].W, arr[i].ldw, arr[i].n_out = ptr(W), W.stride(0), W.shape[0]
@@ -226,18 +228,22 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, f
         ext = l.get('ext')
         arr[i].ext, arr[i].ld_ext = ptr(ext), (0 if ext is None else ext.stride(0))
         arr[i].ext_cols = int(l.get('ext_cols', 0 if ext is None else ext.shape[1]))
-    need = int(lib().fgs_mlp_rc_image_floats(int(backward), n, ctypes.cast(arr, ctypes.c_void_p)))
+        if form == 2:
+            arr[i].side = int(bool(l.get('side', False)))
+    image_floats = lib().fgs_mlp_rc2_image_floats if form == 2 else lib().fgs_mlp_rc_image_floats
+    need = int(image_floats(int(backward), n, ctypes.cast(arr, ctypes.c_void_p)))
     if need < 0:
         raise RuntimeError("rc_chain: bad layer list")
-    key = (in0.device.index, stream(), bool(backward))
+    key = (in0.device.index, stream(), bool(backward), form)
     ws = _RC_IMAGES.get(key)
     if ws is None or ws.numel() < need:
         ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
-    label = label or ("k_mlp_rc backward chain (+ k_rc_pack)" if backward else "k_mlp_rc forward chain (+ k_rc_pack)")
+    kern, pack = ("k_mlp_rc2", "k_rc2_pack") if form == 2 else ("k_mlp_rc", "k_rc_pack")
+    label = label or (f"{kern} backward chain (+ {pack})" if backward else f"{kern} forward chain (+ {pack})")
     d = dyn(row_count=rows_dev, stamps=_stamp_arg(label, flop, "rc"))
     _timed(label, flop,
-           lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),
-                        in0_cols, ptr(ws), ws.numel(), d, stream()))
+           lambda: call("fgs_mlp_rc2_chain" if form == 2 else "fgs_mlp_rc_chain", int(backward), M, n,
+                        ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0), in0_cols, ptr(ws), ws.numel(), d, stream()))
 
 
 def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:

@@ -35,8 +35,8 @@ typedef void *fgs_stream_t;
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
- * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer. */
-#define FGS_ABI_VERSION 7
+ * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain. */
+#define FGS_ABI_VERSION 8
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -359,6 +359,27 @@ typedef struct fgs_rc_layer {
 int64_t fgs_mlp_rc_image_floats(int backward, int n_layers, const fgs_rc_layer_t *layers);
 int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t *layers, const float *in0, int64_t ld_in0,
                      int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, fgs_stream_t stream);
+/* The same chains, second form (csrc/mlp_rc2.hip; width 256 only): the four waves of a workgroup SPLIT a layer's output features
+ * (64 each) over a slab of up to 4 x 32 samples whose activations live in LDS, so a CU that is dealt 7 sample tiles costs 7
+ * tile-times where the register-resident form costs 8 (its unit of work per SIMD is a whole 32-sample tile: 1.73 rounds cost 2 at the
+ * bench's 57 K survivors).  Weights go from L2 straight into matrix-core operand registers in fragment order (no LDS ring).
+ * Arguments as fgs_mlp_rc_chain, plus SIDE layers: `side` != 0 marks a narrow product (<= 64 output columns, no bias / activation)
+ * of the CURRENT carried input that is written to `out` only and leaves the carried input alone -- the backward chain's
+ * reflection-encoding columns of dZ and the compact dX0, which the first form left to fgs_gemm_f32.  Main layers store all 256
+ * output columns (n_store = 256) or none.  mask_bits: one 32-bit word per (32-sample tile, wave, lane), [ceil(M / 32)][4][64] --
+ * the same size as the first form's buffer, another layout (private to the two chains of one step).  Deterministic; not
+ * bit-identical to the first form (another k order). */
+typedef struct fgs_rc2_layer {
+  const float *W; int64_t ldw; int n_out, n_in;
+  const float *bias; int relu;
+  void *mask_bits;
+  float *out; int64_t ldo; int n_store;
+  const float *ext; int64_t ld_ext; int ext_cols;
+  int side;
+} fgs_rc2_layer_t;
+int64_t fgs_mlp_rc2_image_floats(int backward, int n_layers, const fgs_rc2_layer_t *layers);
+int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_rc2_layer_t *layers, const float *in0, int64_t ld_in0,
+                      int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, fgs_stream_t stream);
 /* Every weight and bias gradient of the MLPs in ONE launch (csrc/mlp_wgrad.hip): for each item
  *   dW[n_out, n_in] += dY[M, n_out]^T . X[M, n_in]      dbias[n_out] += column sums of dY   (dbias may be NULL)
  * with fp32 atomics (zero-initialise dW / dbias).  The samples are split over the chip, a workgroup holds a 256 x 256 block
