@@ -147,12 +147,64 @@ __device__ __forceinline__ void r2_group(floatx16 (&acc)[2][R2_SMAX], const floa
 // idle cycles per layer for it).
 struct R2Stream {
   r2_lptr lds;          // this lane's 16 bytes of the wave's next row in X
-  float *g;             // ... and where they go
+  float *g;             // ... and where they go (rows 4 i + wave of the slab)
+  float *sink;          // this lane's 16 bytes of the sink: where a row beyond M goes (same instruction stream)
   int64_t g_step;       // floats between two rows of this wave (4 ldo)
-  int n;                // rows left (uniform)
+  int valid;            // rows of this wave that exist (uniform)
+  int i;                // next row
+  bool on;              // a copy is pending (uniform)
 };
 
-template <int NF, int NS, bool ST>
+__device__ __forceinline__ void r2_stream_put(R2Stream &st, const floatx4 &v) {      // row st.i - 1, read a group ago
+  float *dst = (st.i - 1 < st.valid) ? st.g : st.sink;      // uniform select: scalar registers
+  *reinterpret_cast<__attribute__((address_space(1))) floatx4 *>((uintptr_t)dst) = v;
+  st.g += st.g_step;
+}
+__device__ __forceinline__ floatx4 r2_stream_get(R2Stream &st) {
+  const floatx4 v = *st.lds;
+  st.lds += 4 * (R2_P / 4);
+  ++st.i;
+  return v;
+}
+
+// G k-groups (a multiple of 4) of the reduction.  STR: every group also moves one row of the pending output copy.
+template <int NF, int NS, bool STR>
+__device__ __forceinline__ void r2_groups(floatx16 (&acc)[2][R2_SMAX], floatx4 (&a)[4][2], floatx4 (&b)[2][R2_SMAX], r2_gptr (&Ap)[2],
+                                          r2_lptr (&xp)[R2_SMAX], int G, R2Stream &st, floatx4 &sv) {
+  for (int g = 0; g < G; g += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) a[(u + 2) & 3][f] = Ap[f][u * 64];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) b[(u + 1) & 1][n] = xp[n][2 * u];
+      if (STR) {
+        if (g + u > 0) r2_stream_put(st, sv);      // (g + u > 0: compile-time for u > 0, one scalar test for u = 0)
+        sv = r2_stream_get(st);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      r2_group<NF, NS>(acc, a[u & 3], b[u & 1]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) Ap[f] += 4 * 64;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) xp[n] += 8;
+  }
+}
+
+// The reduction of one layer for this wave: NF feature tiles (fragment streams A[f], 256 floats per k-group) x NS sample tiles
+// (B rows xb[n] in LDS).  `k8` groups, a multiple of 4.  The A operands run two groups ahead of the MFMAs (L2 latency), the B
+// operands one (LDS latency); `pre` holds the fragments of groups 0 and 1 on entry.  sched_barrier(0) pins "this group's loads,
+// then the previous group's MFMAs": left alone, hipcc sinks every load to its use and waits for it there (vmcnt(0) eight MFMAs
+// after the issue); with the order pinned its own counted waits (vmcnt(2 NF), lgkmcnt(NS)) are exactly right.
+// The last groups fetch beyond the layer (the next feature tile's / layer's fragments, the sink behind the image; the next
+// sample's columns in LDS): valid memory, never used -- branch-free.
+// The HBM copy of the PREVIOUS layer's output (what X holds while this layer reduces over it) leaves from inside this loop:
+// a wave stores whole 1 KB rows -- one ds_read_b128 + one global_store_dwordx4 per k-group, fully coalesced -- instead of the
+// epilogue's 32-byte pieces (a 128 KB burst of those per layer and workgroup is store-issue bound: the first form measured ~12 K
+// idle cycles per layer for it).  NROWS rows per wave (8 per sample tile of the slab) go out during the first NROWS groups.
+template <int NF, int NS, int NROWS>
 __device__ __forceinline__ void r2_reduce(floatx16 (&acc)[2][R2_SMAX], const float *const (&A)[2], const float *const (&xb)[R2_SMAX],
                                           int k8, floatx4 (&pre)[2][2], R2Stream &st) {
   floatx4 a[4][2], b[2][R2_SMAX];
@@ -165,41 +217,38 @@ __device__ __forceinline__ void r2_reduce(floatx16 (&acc)[2][R2_SMAX], const flo
 #pragma unroll
   for (int n = 0; n < NS; ++n) b[0][n] = *r2_l(xb[n]);
   floatx4 sv = {0.f, 0.f, 0.f, 0.f};
-  bool sv_full = false;
-  for (int g = 0; g < k8; g += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) a[(u + 2) & 3][f] = Ap[f][u * 64];
-#pragma unroll
-      for (int n = 0; n < NS; ++n) b[(u + 1) & 1][n] = xp[n][2 * u];
-      if (ST) {      // the row read a group ago goes out, the next one is read (uniform branches on scalar counters)
-        if (sv_full) { *reinterpret_cast<__attribute__((address_space(1))) floatx4 *>((uintptr_t)st.g) = sv; st.g += st.g_step; }
-        sv_full = st.n > 0;
-        if (sv_full) { sv = *st.lds; st.lds += 4 * (R2_P / 4); --st.n; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      r2_group<NF, NS>(acc, a[u & 3], b[u & 1]);
-    }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) Ap[f] += 4 * 64;
-#pragma unroll
-    for (int n = 0; n < NS; ++n) xp[n] += 8;
+  if (NROWS > 0 && st.on && k8 >= NROWS) {
+    r2_groups<NF, NS, true>(acc, a, b, Ap, xp, NROWS, st, sv);
+    __builtin_amdgcn_sched_barrier(0);
+    r2_stream_put(st, sv);
+    st.on = false;
+    if (k8 > NROWS) r2_groups<NF, NS, false>(acc, a, b, Ap, xp, k8 - NROWS, st, sv);
+  } else {
+    r2_groups<NF, NS, false>(acc, a, b, Ap, xp, k8, st, sv);
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (ST && sv_full) { *reinterpret_cast<__attribute__((address_space(1))) floatx4 *>((uintptr_t)st.g) = sv; st.g += st.g_step; }
 }
 
-// what is left of a row-store stream, at once (behind the last main layer of a slab; a reduction that had fewer groups than rows)
-__device__ __forceinline__ void r2_stream_flush(R2Stream &st) {
-  while (st.n > 0) {
-    *reinterpret_cast<__attribute__((address_space(1))) floatx4 *>((uintptr_t)st.g) = *st.lds;
-    st.g += st.g_step; st.lds += 4 * (R2_P / 4); --st.n;
+// a pending output copy that no reduction carried (behind the last main layer of a slab): all rows at once
+__device__ __forceinline__ void r2_stream_flush(R2Stream &st, int n_rows) {
+  if (!st.on) return;
+  for (int i = 0; i < n_rows; ++i) {
+    const floatx4 v = r2_stream_get(st);
+    r2_stream_put(st, v);
   }
+  st.on = false;
 }
+
+#ifdef FGS_RC2_PHASE_STAMPS
+#define R2_T(x) (x) = __builtin_amdgcn_s_memtime()
+#define R2_ACC(dst, t0) (dst) += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define R2_T(x) (void)0
+#define R2_ACC(dst, t0) (void)0
+#endif
 
 struct R2Wave {
+  unsigned long long t_load, t_init, t_red, t_epi;      // diagnostics (-DFGS_RC2_PHASE_STAMPS): shader cycles per phase
   int wave, lane, j, h;
   int64_t tile0;             // first sample tile of the slab
   int S;
@@ -241,6 +290,8 @@ template <bool BWD, int S>
 __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2Wave &w) {
   const int tid = w.wave * 64 + w.lane;
   const int64_t row0 = w.tile0 * 32;
+  unsigned long long tp = 0; (void)tp;
+  R2_T(tp);
   // ---- the slab's input -> X (and the appended columns -> E).  Every wave has left the previous slab's last reduction (and its
   // own LDS writes -- the zero fill at kernel start -- have landed: s_barrier alone does not wait for them).
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -248,49 +299,60 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
   floatx4 pre[2][2];
   r2_prefetch(a, 0, w, pre);
   {
+    // 16 bytes per thread and step, row = idx / 64, column group = idx % 64; loads in batches of 8 (one exposed memory latency
+    // per batch: issued one by one, each float4 waited ~1.5 K cycles for its own round trip -- 60 K cycles per slab)
     const int c4 = a.in0_cols >> 2, z4 = a.in0_zero_to >> 2;
-    for (int idx = tid; idx < S * 32 * 64; idx += R2_THREADS) {
-      const int r = idx >> 6, c = idx & 63;
-      if (c >= z4) continue;
-      int64_t row = row0 + r;
-      if (row >= w.M) row = w.M - 1;                       // padding samples compute on a valid row; their results are dropped
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < c4) {
-        v = *reinterpret_cast<const float4 *>(a.in0 + row * a.ld_in0 + 4 * c);
-        const int col = 4 * c;                             // padding columns of the buffer may hold anything
-        if (col + 3 >= a.in0_valid) {
-          if (col + 1 >= a.in0_valid) v.y = 0.f;
-          if (col + 2 >= a.in0_valid) v.z = 0.f;
-          v.w = 0.f;
-          if (col >= a.in0_valid) v.x = 0.f;
-        }
+    const int c = tid & 63;
+    const bool c_in = c < c4, c_wr = c < z4;
+    const int col = 4 * c;
+    float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);         // padding columns of the buffer may hold anything: select, not multiply
+    const bool k0 = col < a.in0_valid, k1 = col + 1 < a.in0_valid, k2 = col + 2 < a.in0_valid, k3 = col + 3 < a.in0_valid;
+    (void)keep;
+    for (int r0 = tid >> 6; r0 < S * 32; r0 += 32) {      // 8 rows per batch: r0, r0 + 4, ...
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int64_t row = row0 + r0 + 4 * k;
+        if (row >= w.M) row = w.M - 1;                     // padding samples compute on a valid row; their results are dropped
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c_in) v[k] = *reinterpret_cast<const float4 *>(a.in0 + row * a.ld_in0 + col);
       }
-      *reinterpret_cast<float4 *>(X + r * R2_P + 4 * c) = v;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float4 o = v[k];
+        o.x = k0 ? o.x : 0.f; o.y = k1 ? o.y : 0.f; o.z = k2 ? o.z : 0.f; o.w = k3 ? o.w : 0.f;
+        if (c_wr) *reinterpret_cast<float4 *>(X + (r0 + 4 * k) * R2_P + col) = o;
+      }
     }
     if (!BWD && a.ext) {
       const int e4 = a.ext_cols >> 2;
-      for (int idx = tid; idx < S * 32 * 16; idx += R2_THREADS) {
-        const int r = idx >> 4, c = idx & 15;
-        if (c >= R2_PE / 4) continue;
-        int64_t row = row0 + r;
-        if (row >= w.M) row = w.M - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < e4) {
-          v = *reinterpret_cast<const float4 *>(a.ext + row * a.ld_ext + 4 * c);
-          const int col = 4 * c;
-          if (col + 3 >= a.ext_valid) {
-            if (col + 1 >= a.ext_valid) v.y = 0.f;
-            if (col + 2 >= a.ext_valid) v.z = 0.f;
-            v.w = 0.f;
-            if (col >= a.ext_valid) v.x = 0.f;
-          }
+      const int ce = tid & 15;
+      const bool e_in = ce < e4, e_wr = ce < R2_PE / 4;
+      const int ecol = 4 * ce;
+      const bool e0 = ecol < a.ext_valid, e1 = ecol + 1 < a.ext_valid, e2 = ecol + 2 < a.ext_valid, e3 = ecol + 3 < a.ext_valid;
+      for (int r0 = tid >> 4; r0 < S * 32; r0 += 128) {     // 16 rows per step, 8 steps per batch
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + 16 * k;
+          int64_t row = row0 + (r < S * 32 ? r : 0);
+          if (row >= w.M) row = w.M - 1;
+          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e_in) v[k] = *reinterpret_cast<const float4 *>(a.ext + row * a.ld_ext + ecol);
         }
-        *reinterpret_cast<float4 *>(E + r * R2_PE + 4 * c) = v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + 16 * k;
+          float4 o = v[k];
+          o.x = e0 ? o.x : 0.f; o.y = e1 ? o.y : 0.f; o.z = e2 ? o.z : 0.f; o.w = e3 ? o.w : 0.f;
+          if (e_wr && r < S * 32) *reinterpret_cast<float4 *>(E + r * R2_PE + ecol) = o;
+        }
       }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  R2_ACC(w.t_load, tp);
 
   // this lane's B rows (sample j of each tile, columns 4 h ..)
   const float *xrow[R2_SMAX], *erow[R2_SMAX];
@@ -307,7 +369,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
     st_rows = __builtin_amdgcn_readfirstlane(st_rows);
   }
   R2Stream st;
-  st.n = 0; st.lds = r2_l(X); st.g = a.sink; st.g_step = 0;
+  st.on = false; st.i = 0; st.valid = 0; st.lds = r2_l(X); st.g = a.sink; st.sink = a.sink + 4 * w.lane; st.g_step = 0;
 
   for (int l = 0; l < a.n_layers; ++l) {
     const R2Layer &L = a.L[l];
@@ -316,6 +378,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
     if (!L.side) {
       // ---------------------------------------------------------------- main layer: features 64 w .. 64 w + 63, all S tiles
       const int ftb = 2 * w.wave;
+      R2_T(tp);
       // accumulators start from the bias (row 8 (r >> 2) + 4 h + (r & 3) of each feature tile); no bias: the zeros behind the image
       {
         const float *bias = (!BWD && L.bias) ? L.bias : a.zeros;
@@ -332,17 +395,19 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
         }
       }
       const float *const A[2] = {r2_frag(a, L, ftb, w.lane), r2_frag(a, L, ftb + 1, w.lane)};
+      R2_ACC(w.t_init, tp); R2_T(tp);
       {
         const float *const xb[R2_SMAX] = {xrow[0], xrow[1], xrow[2], xrow[3]};
-        r2_reduce<2, S, true>(acc, A, xb, k8x, pre, st);
+        r2_reduce<2, S, 8 * S>(acc, A, xb, k8x, pre, st);
       }
-      r2_stream_flush(st);      // (a reduction shorter than the rows to copy: the first layer of the forward chain has no stream)
+      r2_stream_flush(st, 8 * S);      // (a reduction with fewer groups than rows to copy: not in the shipped chains)
       if (k8e > 0) {      // the appended columns: the fragment stream simply continues
         const float *const A2[2] = {A[0] + (int64_t)k8x * 256, A[1] + (int64_t)k8x * 256};
         floatx4 pre2[2][2] = {{r2_ldg(A2[0]), r2_ldg(A2[1])}, {r2_ldg(A2[0] + 256), r2_ldg(A2[1] + 256)}};
         const float *const eb[R2_SMAX] = {erow[0], erow[1], erow[2], erow[3]};
-        r2_reduce<2, S, false>(acc, A2, eb, k8e, pre2, st);
+        r2_reduce<2, S, 0>(acc, A2, eb, k8e, pre2, st);
       }
+      R2_ACC(w.t_red, tp); R2_T(tp);
       // every wave has read X for the last time in this layer
       __builtin_amdgcn_s_barrier();
       r2_prefetch(a, l + 1, w, pre);
@@ -388,12 +453,13 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
         if (!BWD) mw[mi[n]] = bits;
       }
       // the copy of this output: rows 4 i + wave of the slab, from X
-      st.n = st_rows;
+      st.on = true; st.i = 0; st.valid = st_rows;
       st.lds = r2_l(X + w.wave * R2_P + 4 * w.lane);
       st.g = L.out + (row0 + w.wave) * L.ldo + 4 * w.lane;
       st.g_step = 4 * L.ldo;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes have landed before anybody is released
       __builtin_amdgcn_s_barrier();
+      R2_ACC(w.t_epi, tp);
     } else {
       // ---------------------------------------------------------------- side layer: (feature tile, sample tiles) per wave
       int ft, n0, ns;
@@ -406,9 +472,9 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
       const float *const A[2] = {r2_frag(a, L, ft, w.lane), r2_frag(a, L, ft, w.lane)};
       const float *x0 = X + (n0 * 32 + w.j) * R2_P + 4 * w.h;
       const float *const xb[R2_SMAX] = {x0, x0 + 32 * R2_P, x0, x0};
-      if (ns == 2) r2_reduce<1, 2, true>(acc, A, xb, k8x, pre, st);
-      else if (ns == 1) r2_reduce<1, 1, true>(acc, A, xb, k8x, pre, st);
-      r2_stream_flush(st);
+      if (ns == 2) r2_reduce<1, 2, 8 * S>(acc, A, xb, k8x, pre, st);
+      else if (ns == 1) r2_reduce<1, 1, 8 * S>(acc, A, xb, k8x, pre, st);
+      r2_stream_flush(st, 8 * S);
       r2_prefetch(a, l + 1, w, pre);
       __builtin_amdgcn_sched_barrier(0);
       const int n_store = __builtin_amdgcn_readfirstlane(L.n_store);
@@ -428,7 +494,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
       }
     }
   }
-  r2_stream_flush(st);       // the last main layer's output (X is not touched again before the next slab's opening barrier)
+  r2_stream_flush(st, 8 * S);       // the last main layer's output (X is not touched again before the next slab's opening barrier)
 }
 
 template <bool BWD>
@@ -440,6 +506,7 @@ __global__ __launch_bounds__(R2_THREADS, 1) void k_mlp_rc2(R2Args a) {
   w.lane = tid & 63;
   w.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   w.j = w.lane & 31; w.h = w.lane >> 5;
+  w.t_load = w.t_init = w.t_red = w.t_epi = 0;
   w.M = fgs_rows(a.M, a.m_dev);
   const int64_t T = (w.M + 31) / 32;
   const int64_t t0 = (int64_t)blockIdx.x * T / gridDim.x, t1 = ((int64_t)blockIdx.x + 1) * T / gridDim.x;
@@ -469,7 +536,7 @@ __global__ __launch_bounds__(R2_THREADS, 1) void k_mlp_rc2(R2Args a) {
   if (stamps && tid == 0) {
     stamps[2] = __builtin_amdgcn_s_memtime();
     stamps[3] = __builtin_amdgcn_s_memrealtime();
-    stamps[4] = stamps[5] = stamps[6] = stamps[7] = 0;
+    stamps[4] = w.t_init; stamps[5] = w.t_red; stamps[6] = w.t_epi; stamps[7] = w.t_load;
   }
 }
 

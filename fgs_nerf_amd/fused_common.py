@@ -227,6 +227,18 @@ def _linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=None, colsum=None, logica
 
 
 
+# FGS_MLP_FORM: which of the two one-launch chain kernels the fine stage uses when both cover the model (width 256): 2 (default) =
+# csrc/mlp_rc2.hip, the waves split the features and a CU is dealt whole sample tiles (no round quantisation; the two narrow
+# backward products ride along as side layers); 1 = csrc/mlp_rc.hip, activations resident in registers (every other width).
+_MLP_FORM = int(os.environ.get("FGS_MLP_FORM", "2"))
+
+
+def _rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
+    """Shapes the feature-split chains cover: 256-wide trunks, <= 52 appended columns, <= 10 layers incl. the side layers."""
+    return (_MLP_FORM == 2 and _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and rw == 256 and fw == 256 and ldz - rw <= 52
+            and n_rgb + n_ref - 1 <= 8)
+
+
 def _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
     """Shapes the register-resident chains cover (a function of the model only: identical on every rank)."""
     return (_MLP_IMPL == "rc" and rw == fw and rw % 32 == 0 and rw <= 256 and ldx0 <= 256 and 0 < ldz - rw <= 64 and
@@ -603,7 +615,7 @@ def roofline_report(pmc=None, flop_scale: float = 1.0, stamped=None):
     if stamped is not None:
         # fused_ops.stamps_read(): the launches of a captured step timed by their own workgroups (wall-clock readings), one
         # duration per replay of the timed region
-        ev = [(None, None, None, label.replace(" (+ k_rc_pack)", ""), len(durs), fl * len(durs), sum(durs) * 1e3)
+        ev = [(None, None, None, label.replace(" (+ k_rc_pack)", "").replace(" (+ k_rc2_pack)", ""), len(durs), fl * len(durs), sum(durs) * 1e3)
               for label, fl, durs in stamped if durs]
     else:
         ev = [e + (None,) for e in PROFILE["gemm_events"] + fo.TIMING["events"]]
@@ -641,9 +653,10 @@ def roofline_report(pmc=None, flop_scale: float = 1.0, stamped=None):
     elif pmc and pmc.get("error"):
         detail = {"error": pmc["error"]}
     out = {"bound": "mfma",
-           "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_rc (forward chain / backward data-gradient "
-                     "chain, activations resident in registers, one launch each), k_mlp_wgrad (all weight and bias gradients, "
-                     "one launch), k_gemm (the two first-layer data gradients)",
+           "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_rc2 (forward chain / backward data-gradient "
+                     "chain incl. the two narrow first-layer products, one launch each: the waves split the features, a CU is "
+                     "dealt whole 32-sample tiles; FGS_MLP_FORM=1 or other widths: k_mlp_rc + k_gemm), k_mlp_wgrad (all weight "
+                     "and bias gradients, one launch)",
            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the MLP launches of a step",
            "traffic_detail": detail,

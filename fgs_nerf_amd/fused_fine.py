@@ -123,6 +123,8 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     bits = S['relu_bits']
     Wc_full = S.get('Wc_full')
     collapse = Wc_full is not None
+    form = S.get('rc_form') or 1
+    z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
     layers = []
     dY_ref = [None] * (n_ref - 1)            # dY_ref[i]: gradient w.r.t. the pre-activation output of refnet layer i
     dY_ref[n_ref - 2] = dY
@@ -131,6 +133,12 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         layers.append(dict(W=ref_w[i], mask_bits=bits[n_rgb + i - 1], out=out, n_store=fw))
         dY_ref[i - 1] = out
     dZ = torch.empty(M, ldz, dtype=F32, device=dev)
+    flop_side = 0.0
+    if form == 2:
+        # side layer: the reflection-encoding columns of dZ = dY_ref[0] . V0[:, rw:], from the carried gradient BEFORE the next
+        # main layer replaces it (the first form leaves this product and dX0 to k_gemm launches behind the chain)
+        layers.append(dict(W=S['V0p'][:, rw:], out=dZ[:, rw:], n_store=ldz - rw, side=True))
+        flop_side += 2.0 * M * fw * (z_cols - rw)
     dY_rgb = [None] * n_rgb                  # dY_rgb[i]: gradient w.r.t. the output of rgbnet layer i
     if collapse:
         # dY_ref[0] . (V0a W3), masked by the ReLU of rgbnet layer n_rgb - 2: straight to that layer's output gradient
@@ -149,13 +157,25 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     flop_chain = 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
     if collapse:
         flop_chain -= 2.0 * M * rw * rw
-    fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain, rows_dev=_rows(run))
+    if form == 2 and S.get('W0c') is not None and S['W0c'].shape[1] <= 64:
+        # ... and dX0 in compact form (fgs_dyn_t.dx0_compact) as the chain's last (side) layer
+        W0c = S['W0c']
+        dX0 = torch.empty(M, W0c.shape[1], dtype=F32, device=dev)
+        layers.append(dict(W=W0c, out=dX0, n_store=W0c.shape[1], side=True))
+        flop_side += 2.0 * M * rw * run.dx0_cols[2]
+        run.dx0_compact = True
+        fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=2)
+    else:
+        fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=form)
+        dX0 = None
     # narrow products: the reflection-encoding columns of dZ (dY_ref[0] . V0[:, rw:]) and dX0 (dY_rgb[0] . W0).  (As one-layer
     # register-resident chains of 4 row tiles they measured 63 us each against 47 for the tiled GEMM: with 64 MFMAs per chunk
     # the chain's per-chunk barrier / DMA and its uncoalesced input load dominate.)
-    z_cols, x_cols = ref_w[0].shape[1], rgb_w[0].shape[1]
-    _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw), rows_dev=_rows(run))
-    if S.get('W0c') is not None:
+    if form != 2:
+        _gemm(fo.GEMM_NN, dY_ref[0], S['V0p'][:, rw:], dZ[:, rw:], M, ldz - rw, fw, logical=(M, z_cols - rw, fw), rows_dev=_rows(run))
+    if dX0 is not None:
+        pass
+    elif S.get('W0c') is not None:
         # dX0 in compact form (fgs_dyn_t.dx0_compact): only the columns somebody differentiates through
         W0c = S['W0c']
         dX0 = torch.empty(M, W0c.shape[1], dtype=F32, device=dev)
@@ -315,7 +335,8 @@ class _FusedFine(torch.autograd.Function):
             flop_fwd = 2.0 * M * (rw * sum(w.shape[1] for w in rgb_w) + fw * sum(w.shape[1] for w in ref_w[:-1]))
             if collapse:
                 flop_fwd -= 2.0 * M * rw * rgb_w[-1].shape[1]
-            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run))
+            rc_form = 2 if (_rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and not collapse) else 1
+            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run), form=rc_form)
         elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
@@ -378,7 +399,7 @@ class _FusedFine(torch.autograd.Function):
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
                                    acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, WT=WT, relu_bits=relu_bits,
-                                   Wc_full=(Wc_full if use_rc else None),
+                                   Wc_full=(Wc_full if use_rc else None), rc_form=(rc_form if use_rc else None),
                                    pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,

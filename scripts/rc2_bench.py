@@ -34,7 +34,7 @@ def timed(fn, reps=20, warm=5):
 def main():
     from test_mlp_rc_gpu import _fine_setup
     dev = torch.device("cuda:0")
-    Ms = [int(a) for a in sys.argv[1:]] or [50000, 56700, 57600, 64075, 65536]
+    Ms = [int(a) for a in sys.argv[1:] if not a.startswith('-')] or [50000, 56700, 57600, 64075, 65536]
     spin = torch.randn(8192, 8192, device=dev)
     for _ in range(30):           # clocks up
         spin @ spin
@@ -82,6 +82,26 @@ def main():
         for (what, form), (med, best) in res.items():
             fl = flop_f if what == "fwd" else flop_b + (flop_n if what == "bwd" else 0)
             print(f"    {what:<14} form {form}: median {med:7.1f} us  best {best:7.1f} us   {fl / med / 1e6:6.1f} TFLOP/s (incl. pack launch)")
+    if "--phases" in sys.argv or os.environ.get("RC2_PHASES"):
+        # (make -C fgs_nerf_amd/csrc rc2-stamps): wave 0 of every workgroup: shader cycles per phase, shader / wall clock
+        import numpy as np
+        M = Ms[-1]
+        for what, backward, layers, in0, cols in (("fwd", False, fwd, X0, 108), ("bwd", True, bwd2, dY, 256)):
+            buf = torch.zeros(1, fo.STAMP_LAUNCHES, fo.STAMP_WORDS, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                fo.STAMPS.update(buf=buf, counter=None)
+                fo.stamps_begin_step()
+                fo.rc_chain(backward, M, in0, cols, layers, form=2)
+                torch.cuda.synchronize()
+            fo.STAMPS.update(buf=None, counter=None)
+            wds = buf[0, 0].cpu().numpy().astype(np.uint64).reshape(-1, 8)
+            wds = wds[wds[:, 1] > 0]
+            cyc = (wds[:, 2] - wds[:, 0]).astype(np.float64)
+            wall = (wds[:, 3] - wds[:, 1]).astype(np.float64) / 100.0      # us
+            print(f"    {what} form 2, M = {M}: {len(wds)} workgroups, in-kernel {np.median(wall):.1f} us (max {wall.max():.1f}), "
+                  f"clock {np.median(cyc / wall) / 1e3:.2f} GHz; cycles of wave 0 (median): total {np.median(cyc):.0f} = slab input "
+                  f"{np.median(wds[:, 7]):.0f} + accumulator init {np.median(wds[:, 4]):.0f} + reductions {np.median(wds[:, 5]):.0f} + "
+                  f"epilogues and barriers {np.median(wds[:, 6]):.0f} + rest")
     print("done")
 
 

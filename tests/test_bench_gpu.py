@@ -39,9 +39,10 @@ def test_default_line_has_the_contract(dev):
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None            # (--no-pmc: never a number from another run)
     assert "s_memrealtime" in r["timing"] and "timed region itself" in r["timing"]
-    # every MLP launch of every timed replay was stamped: 6 forward chains, 6 backward chains, 6 weight-gradient launches, 12 products
-    assert sorted(c["launches"] for c in r["chains"].values()) == [6, 6, 6, 12]
-    assert r["launches"] == 30
+    # every MLP launch of every timed replay was stamped: 6 forward chains, 6 backward chains (the two narrow products ride in them
+    # as side layers), 6 weight-gradient launches
+    assert sorted(c["launches"] for c in r["chains"].values()) == [6, 6, 6] and any("k_mlp_rc2" in k for k in r["chains"])
+    assert r["launches"] == 18
 
 
 def test_forced_single_rank_group_runs_the_captured_exchange(dev):
