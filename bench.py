@@ -728,6 +728,8 @@ def main():
         else:
             train_step(model, opt, averager, batches[i % N_BATCHES], n_global)
         samples += n_inbbox[i % N_BATCHES]
+    if captured is not None:
+        captured.flush()              # (the last replay's k0 update, which the next replay's head would have applied: inside the clock)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -50,6 +50,7 @@ _SIGNATURES = {
     "fgs_copy_cols_multi": [I32, P, P, P, P, P, P, P, P],
     "fgs_debug_pad_cols_old_indexing": [P, I32, I32, I64, P, I64, P],
     "fgs_step_scalars_tick": [P, I32, I32, P, P, I32, P, P],
+    "fgs_step_scalars_tick2": [P, I32, I32, P, P, I32, P, I32, P, P, P, P],
     "fgs_count_guard": [P, I64, I64, P, P, P],
     "fgs_box_mask_fill": [P, I32, I32, I32, P, P],
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, I32, F32, F32, F32, F32, I32, P, P],

@@ -159,6 +159,38 @@ class MaskedAdam(torch.optim.Optimizer):
         gb['clean'] = True
         return True
 
+    @torch.no_grad()
+    def voxel_update_from_buffer(self, p, gb, ss_ptr, skip_ptr) -> None:
+        """The masked update of a feature grid straight from fused.py's persistent gradient buffer `gb` (its recorded voxels:
+        fgs_adam_upd_voxels), step size and skip flag read from device memory -- the form graph_step.CapturedFineStep issues at
+        the HEAD of an iteration for the gradient the previous iteration left (nothing pending: a no-op).  Consumes what it
+        applies: gradient zeroed, voxel flags cleared."""
+        from ._lib import ptr
+        group = next(gr for gr in self.param_groups if any(q is p for q in gr['params']))
+        st = self._state_of(p)
+        self._check_layout(p, st)
+        b1, b2 = group['betas']
+        call("fgs_adam_upd_voxels", ptr(p), ptr(gb['buf']), ptr(st['exp_avg']), ptr(st['exp_avg_sq']), *gb['dims'], ptr(gb['flags']),
+             int(st['step']), float(b1), float(b2), float(group['lr']), float(group['eps']), ss_ptr, skip_ptr, stream())
+
+    def defer_update(self, p, grad) -> bool:
+        """Called from inside the backward pass in place of early_update(): the gradient of `p` stays in the persistent buffer,
+        step() leaves the parameter alone, and the caller (CapturedFineStep) applies the update later with
+        voxel_update_from_buffer().  False: the record does not describe this gradient (see _bricks) -- update now instead."""
+        group = next((gr for gr in self.param_groups if any(q is p for q in gr['params'])), None)
+        t = getattr(p, '_fgs_touched', None)
+        if group is None or t is None:
+            return False
+        gb = t['state']
+        if not (t['valid'] and group['skip_zero_grad'] and grad.data_ptr() == t['grad_ptr'] and gb['buf']._version == t['version']
+                and tuple(p.shape) == gb['key'][0] and p.stride() == gb['key'][1] and t['idx'] is None and not t['exchange']
+                and not (self.per_lr is not None and p.shape == self.per_lr.shape)):
+            return False
+        p._fgs_touched = None
+        gb['clean'] = True           # (a promise: the deferred pass zeroes what it consumes before the buffer is scattered into again)
+        self._early[id(p)] = None    # step() skips the parameter
+        return True
+
     def _big(self, p, g, st, group, ss_ptr, skip) -> None:
         """One launch for one big tensor: the reference's per-tensor rule (model/adam.py:205-221) -- per-voxel lr if a
         same-shape table is set, else masked if the group says skip_zero_grad, else dense."""

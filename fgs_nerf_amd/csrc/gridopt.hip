@@ -307,7 +307,16 @@ FGS_API float fgs_adam_step_size(int step, float beta1, float beta2, float lr) {
 
 namespace {
 __global__ void k_scalars_tick(const float *__restrict__ table, int n_rows, int n_cols, int64_t *__restrict__ counter,
-                               float *__restrict__ out, int mirror_col, float *__restrict__ mirror_dst) {
+                               float *__restrict__ out, int mirror_col, float *__restrict__ mirror_dst, int latch_col,
+                               float *__restrict__ latch_dst, const int *__restrict__ latch_flag_src,
+                               int *__restrict__ latch_flag_dst) {
+  // the PREVIOUS iteration's value of one column and of one flag, kept for an update of that iteration that is issued at the head
+  // of this one (graph_step.CapturedFineStep: k0's Adam pass beside the next forward march)
+  if (threadIdx.x == 0) {
+    if (latch_dst) *latch_dst = out[latch_col];
+    if (latch_flag_dst) *latch_flag_dst = *latch_flag_src;
+  }
+  __syncthreads();
   int64_t row = *counter;
   if (row > n_rows - 1) row = n_rows - 1;
   if (row < 0) row = 0;
@@ -343,8 +352,20 @@ FGS_API int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, in
   FGS_REQUIRE(table && counter && out && n_rows > 0 && n_cols > 0 && (!mirror_dst || (mirror_col >= 0 && mirror_col < n_cols)),
               FGS_E_INVALID, "fgs_step_scalars_tick: bad argument");
   hipLaunchKernelGGL(k_scalars_tick, dim3(1), dim3(64), 0, fgs_s(stream), table, n_rows, n_cols, counter, out, mirror_col,
-                     mirror_dst);
+                     mirror_dst, 0, (float *)nullptr, (const int *)nullptr, (int *)nullptr);
   FGS_LAUNCH_OK("fgs_step_scalars_tick");
+  return 0;
+}
+
+FGS_API int fgs_step_scalars_tick2(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
+                                   float *mirror_dst, int latch_col, float *latch_dst, const int *latch_flag_src,
+                                   int *latch_flag_dst, fgs_stream_t stream) {
+  FGS_REQUIRE(table && counter && out && n_rows > 0 && n_cols > 0 && (!mirror_dst || (mirror_col >= 0 && mirror_col < n_cols)) &&
+                  (!latch_dst || (latch_col >= 0 && latch_col < n_cols)) && (!latch_flag_dst || latch_flag_src),
+              FGS_E_INVALID, "fgs_step_scalars_tick2: bad argument");
+  hipLaunchKernelGGL(k_scalars_tick, dim3(1), dim3(64), 0, fgs_s(stream), table, n_rows, n_cols, counter, out, mirror_col,
+                     mirror_dst, latch_col, latch_dst, latch_flag_src, latch_flag_dst);
+  FGS_LAUNCH_OK("fgs_step_scalars_tick2");
   return 0;
 }
 

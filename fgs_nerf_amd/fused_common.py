@@ -418,6 +418,12 @@ def _take_grid_grad(cache, k0_grid):
     gb = _grid_grad_state(cache, k0_grid, create=True)
     if gb is None:
         return _zeros_like_strided(k0_grid), None
+    owner = gb.get('pending')
+    if owner is not None and not cache.get('sync_free'):
+        # a captured step left its last k0 gradient in the buffer for the head of its next replay (CapturedFineStep, deferred
+        # Adam pass): an eager backward pass in between would scatter on top of it
+        raise RuntimeError("the persistent k0 gradient buffer holds the pending update of a captured step: call its flush() "
+                           "(or check()) before an eager training step")
     if not _grid_grad_idle(gb):
         # somebody still holds the old buffer (last step's p.grad before zero_grad, a gradient being accumulated): it is
         # theirs now; a fresh zero-filled tensor becomes the persistent buffer

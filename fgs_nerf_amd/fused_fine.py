@@ -295,6 +295,9 @@ class _FusedFine(torch.autograd.Function):
         Z = torch.empty(M, ldz, dtype=F32, device=dev)
         normal = torch.empty(M, 3, dtype=F32, device=dev)
         kC, kX, kY, kZ, ksC, ksX, ksY, ksZ = grid_strides(k0_grid)
+        k0_join = run.cache.pop('pre_k0_read', None)      # (CapturedFineStep: the previous iteration's k0 update, issued beside the
+        if k0_join is not None:                           #  march kernel on a side branch, joins here: first reader of k0)
+            k0_join()
         call("fgs_feat_fine_fwd", M, ptr(ray_id), ptr(pts), ptr(sdf), ptr(gradient), ptr(run.viewdirs), g.lo_c, g.hi_c,
              g.X, g.Y, g.Z, g.voxel_size, run.layout_i, run.displace, ptr(sdf_grid), ptr(k0_grid), ksC, ksX, ksY, ksZ,
              ptr(X0), ptr(Z), ptr(normal), dyn(row_count=_rows(run)), st)

@@ -31,6 +31,12 @@ from ._lib import call, lib, ptr, stream
 from .losses import fused_render_losses
 
 
+def variant_allows_defer(var) -> bool:
+    """k0's deferred Adam pass needs an iteration in which nothing but the trilinear scatter writes k0.grad: no autograd term on the
+    grid (an `extra_loss` may hold one -- the shipped fine config's only acts on sdf, but the step cannot know)."""
+    return var.get('extra_loss') is None
+
+
 class CapturedFineStep:
     """One captured iteration (fine stage, or a coarse stage: same kernels behind the same device-side row count).
 
@@ -115,6 +121,26 @@ class CapturedFineStep:
         self._sdf_exchange_state = None
         self.sdf_exchange_capacity = None
         self._inc_mask = None
+        # ---- k0's Adam pass one iteration late (one GPU, fine stage; FGS_K0_ADAM_DEFER=1; default 0: in place, inside the backward
+        # pass -- MEASURED SLOWER, round 4: 1.702 against 1.686 ms / step on one box.  Without that memory-bound kernel beside it the
+        # sdf scatter kernel meets the weight-gradient launch in full swing and takes 285 us instead of 113 -- the branch ends where
+        # it ended before -- and the march kernel of the next forward pass takes 74 us instead of 54 beside the deferred pass, plus
+        # 11 us for the join: profiles/r04_fine_graph_step_timeline_k0_adam_deferred.txt.  Kept, tested, off.)
+        # Inside the backward pass it runs beside the weight-gradient launch (161 us there, 35 alone) at the end of a scatter branch
+        # that outlives that launch by ~76 us.  Nothing reads k0 before the NEXT iteration's feature lookup, 76 us into that
+        # iteration, and the march kernel in front of it reads only sdf: the pass is issued at the head of the next replay on a side
+        # branch that joins in front of the lookup (fused_fine: 'pre_k0_read').  Same arithmetic on the same gradient with the same
+        # step size (the tick latches the previous iteration's before it overwrites it): bit-identical parameters once flush()
+        # has applied the last iteration's update -- check() / release() do, and so must anybody who reads k0 in between.
+        self.defer_k0 = (os.environ.get("FGS_K0_ADAM_DEFER", "0") == "1" and self.averager is None and not coarse)
+        self._k0_group = next((gi for gi, g in enumerate(groups) if any(p is model.k0.grid for p in g['params'])), None)
+        if self._k0_group is None:
+            self.defer_k0 = False
+        self._latch_ss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._latch_skip = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._defer_stream = None
+        self._k0_pending = False
+        self._deferred_in_graph = [False] * len(self.variants)
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _enter(self):
@@ -184,9 +210,28 @@ class CapturedFineStep:
     def _body(self, update: bool, variant: int = 0):
         # (the warm-up pass ticks too, so that it renders with a real 1/s; capture() rewinds the counter.)  The tick also
         # writes this iteration's s_val into the model's parameter (model/nerf.py:520 refreshes it in every forward).
-        call("fgs_step_scalars_tick", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
-             self.n_cols - 1, ptr(self.model.s_val.data), stream())
+        cache = self.model.__dict__.setdefault('_fused_cache', {})
+        flags = cache['sync_free']['flags']
+        gi = self._k0_group
+        call("fgs_step_scalars_tick2", ptr(self.table), self.n_iters, self.n_cols, ptr(self.counter), ptr(self.scalars),
+             self.n_cols - 1, ptr(self.model.s_val.data), 1 + (gi or 0), ptr(self._latch_ss) if gi is not None else None,
+             ptr(flags[1:2]), ptr(self._latch_skip), stream())
         fo.stamps_begin_step()            # (bench.py's in-kernel timing of the matrix-core launches, when it is on)
+        gb = cache.get('k0_grad')
+        head = update and self.defer_k0 and gb is not None and cache.get('opt_hook') is not None
+        defer = head and variant_allows_defer(self.variants[variant])
+        if head:
+            # the previous iteration's k0 update (whichever variant ran it: every graph opens with this pass; nothing pending: a
+            # no-op): beside the march kernel, joined in front of the first reader of k0
+            if self._defer_stream is None:
+                self._defer_stream = torch.cuda.Stream(device=self.dev)
+            side, cur = self._defer_stream, torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.opt.voxel_update_from_buffer(self.model.k0.grid, gb, self._latch_ss.data_ptr(), self._latch_skip.data_ptr())
+                done = torch.cuda.Event()
+                done.record(side)
+            cache['pre_k0_read'] = lambda: torch.cuda.current_stream().wait_event(done)
         if self.inc_col is not None:
             # this iteration's voxel-increment mask, rebuilt in place from the row the tick just copied (the render below reads
             # the same bytes through model.inc_mask)
@@ -215,8 +260,20 @@ class CapturedFineStep:
         self.opt.zero_grad(set_to_none=True)
         # An update issued from inside the backward pass (fused.enable_early_update: k0's Adam pass) belongs to the update: the
         # warm-up pass (update=False) must not apply it, and no record of an earlier pass may make this one skip it.
-        cache = self.model.__dict__.setdefault('_fused_cache', {})
         hook = None if update else cache.pop('opt_hook', None)
+        inline_hook = None
+        if defer:
+            # ... and THIS iteration's gradient stays in the persistent buffer for the next replay's head (defer_update() declines
+            # when the record does not describe the gradient: the in-place update then runs as before)
+            inline_hook = cache['opt_hook']
+            k0 = self.model.k0.grid
+
+            def _defer(p, g, _opt=self.opt, _inline=inline_hook, _k0=k0):
+                if p is _k0 and _opt.defer_update(p, g):
+                    self._deferred_in_graph[variant] = True
+                    return True
+                return _inline(p, g)
+            cache['opt_hook'] = _defer
         after = None
         if av is not None and not update:
             after, av.after_early = av.after_early, None
@@ -227,6 +284,9 @@ class CapturedFineStep:
         finally:
             if hook is not None:
                 cache['opt_hook'] = hook
+            if inline_hook is not None:
+                cache['opt_hook'] = inline_hook
+            cache.pop('pre_k0_read', None)        # (a forward that never reached the join: nothing may outlive this body)
             if after is not None:
                 av.after_early = after
         if av is not None:
@@ -316,6 +376,11 @@ class CapturedFineStep:
         self._check_static_buffers()
         self.graphs[variant].replay()
         self.iteration += 1
+        if self._deferred_in_graph[variant]:
+            self._k0_pending = True
+            gb = self.model.__dict__.get('_fused_cache', {}).get('k0_grad')
+            if gb is not None:
+                gb['pending'] = self
         for p in self._updated[variant]:                   # host mirror of the step counters (state_dict, schedules): the
             st = self.opt.state.get(p)                     # parameters this variant's captured body updated
             if st:
@@ -346,10 +411,26 @@ class CapturedFineStep:
             raise RuntimeError("CapturedFineStep.replay: the persistent k0 gradient buffer holds an unconsumed gradient (an eager "
                                "backward pass without optimizer step): call fused.reset_grid_grad(model) first")
 
+    def flush(self) -> None:
+        """Apply the k0 update the last replay left pending (deferred Adam pass; a no-op otherwise).  Anybody who reads k0 -- or
+        trains eagerly -- between two replays calls this first; check() and release() do."""
+        if not self._k0_pending:
+            return
+        cache = self.model.__dict__.get('_fused_cache', {})
+        gb = cache.get('k0_grad')
+        buf = cache.get('sync_free_buffers')
+        if gb is not None and buf is not None:
+            # (the scalars still hold the last iteration's row -- the tick of the next replay has not run -- and flags[1] its skip flag)
+            self.opt.voxel_update_from_buffer(self.model.k0.grid, gb, self.scalars[1 + self._k0_group:2 + self._k0_group].data_ptr(),
+                                              buf['flags'][1:2].data_ptr())
+            gb['pending'] = None
+        self._k0_pending = False
+
     def release(self) -> None:
         """Drop the captured graphs (and their memory pool).  With an averager, call this BEFORE
         torch.distributed.destroy_process_group(): destroying an RCCL communicator whose collectives are still nodes of a live
         hipGraph aborts the process (seen on ROCm 7.0 / RCCL 2.26: SIGABRT inside destroy_process_group, no message)."""
+        self.flush()
         self.graphs = [None] * len(self.variants)
         self.losses = [None] * len(self.variants)
         self._pinned = None
@@ -363,7 +444,9 @@ class CapturedFineStep:
     def check(self):
         """(overflowed, survivors processed since the last clear) -- one device->host read; not for every step.  `overflowed`
         covers both capacities: a survivor list that did not fit (that step's update was skipped, on every rank) and, with an
-        averager, a k0 exchange that did not fit (`exchange_overflowed()`: every update since then was skipped)."""
+        averager, a k0 exchange that did not fit (`exchange_overflowed()`: every update since then was skipped).  Applies a pending
+        k0 update first (flush())."""
+        self.flush()
         return fused.sync_free_state(self.model)
 
     def exchange_overflowed(self) -> bool:

@@ -35,8 +35,9 @@ typedef void *fgs_stream_t;
  * value the library was BUILT with; a host binding compares it with the value it was written against and refuses a stale
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
- * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain. */
-#define FGS_ABI_VERSION 8
+ * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
+ * 9 = fgs_step_scalars_tick2. */
+#define FGS_ABI_VERSION 9
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -89,6 +90,12 @@ typedef struct fgs_dyn {
 float fgs_adam_step_size(int step, float beta1, float beta2, float lr);      /* adam_upd_kernel.cu:72, all-float */
 int fgs_step_scalars_tick(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
                           float *mirror_dst, fgs_stream_t stream);
+/* The same, and BEFORE the row is copied: *latch_dst = out[latch_col] and *latch_flag_dst = *latch_flag_src -- the previous
+ * iteration's value of one scalar (an Adam step size) and of one flag (the skip flag), for an update of that iteration that the
+ * caller issues at the head of this one (the feature grid's Adam pass beside the next forward march).  NULL: not latched. */
+int fgs_step_scalars_tick2(const float *table, int n_rows, int n_cols, int64_t *counter, float *out, int mirror_col,
+                           float *mirror_dst, int latch_col, float *latch_dst, const int *latch_flag_src, int *latch_flag_dst,
+                           fgs_stream_t stream);
 int fgs_count_guard(int64_t *offsets, int64_t n, int64_t capacity, int *flags, int64_t *total, fgs_stream_t stream);
 /* The voxel-increment mask of one iteration (model/nerf.py:1078-1088: linspace lattice compared with a growing box,
  * model/nerf_training.py:286-291) rebuilt on the device from six index bounds {lo_x, hi_x, lo_y, hi_y, lo_z, hi_z} in device
