@@ -134,13 +134,6 @@ __device__ __forceinline__ void r2_group(floatx16 (&acc)[2][R2_SMAX], const floa
         acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[f][i], b[n][i], acc[f][n], 0, 0, 0);
 }
 
-// The reduction of one layer for this wave: NF feature tiles (fragment streams A[f], 256 floats per k-group) x NS sample tiles
-// (B rows xb[n] in LDS).  `k8` groups, a multiple of 4.  The A operands run two groups ahead of the MFMAs (L2 latency), the B
-// operands one (LDS latency); `pre` holds the fragments of groups 0 and 1 on entry.  sched_barrier(0) pins "this group's loads,
-// then the previous group's MFMAs": left alone, hipcc sinks every load to its use and waits for it there (vmcnt(0) eight MFMAs
-// after the issue); with the order pinned its own counted waits (vmcnt(2 NF), lgkmcnt(NS)) are exactly right.
-// The last groups fetch beyond the layer (the next feature tile's / layer's fragments, the sink behind the image; the next
-// sample's columns in LDS): valid memory, never used -- branch-free.
 // The HBM copy of the PREVIOUS layer's output (what X holds while this layer reduces over it) leaves from inside this loop:
 // a wave stores whole 1 KB rows -- one ds_read_b128 + one global_store_dwordx4 per k-group, fully coalesced -- instead of the
 // epilogue's 32-byte pieces (a 128 KB burst of those per layer and workgroup is store-issue bound: the first form measured ~12 K
@@ -183,8 +176,20 @@ __device__ __forceinline__ void r2_groups(floatx16 (&acc)[2][R2_SMAX], floatx4 (
         if (g + u > 0) r2_stream_put(st, sv);      // (g + u > 0: compile-time for u > 0, one scalar test for u = 0)
         sv = r2_stream_get(st);
       }
-      __builtin_amdgcn_sched_barrier(0);
       r2_group<NF, NS>(acc, a[u & 3], b[u & 1]);
+      // Schedule of the group: its memory instructions are dealt ONE AT A TIME between its MFMAs.  Issued in one run in front of
+      // the group they cost ~130 cycles of matrix-pipe idle (6 % of the reduction); in the 64-cycle shadow of a running MFMA
+      // they are free.  hipcc's own counted waits (vmcnt / lgkmcnt) stay exact.
+      constexpr int MF = 4 * NF * NS, MEM = NF + NS + (STR ? 2 : 0), PER = MF / MEM > 0 ? MF / MEM : 1;
+#pragma unroll
+      for (int k = 0; k < MEM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                              // PER MFMAs
+        if (k < NF) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    // a fragment load (VMEM read)
+        else if (k < NF + NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // an activation read (DS read)
+        else if (k == NF + NS) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);         // the copy's store (VMEM write)
+        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                           // the copy's row read (DS read)
+      }
+      if (MF - PER * MEM > 0) __builtin_amdgcn_sched_group_barrier(0x008, MF - PER * MEM > 0 ? MF - PER * MEM : 1, 0);
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) Ap[f] += 4 * 64;
@@ -308,17 +313,18 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
     float4 keep = make_float4(1.f, 1.f, 1.f, 1.f);         // padding columns of the buffer may hold anything: select, not multiply
     const bool k0 = col < a.in0_valid, k1 = col + 1 < a.in0_valid, k2 = col + 2 < a.in0_valid, k3 = col + 3 < a.in0_valid;
     (void)keep;
-    for (int r0 = tid >> 6; r0 < S * 32; r0 += 32) {      // 8 rows per batch: r0, r0 + 4, ...
-      float4 v[8];
+    {      // ALL of the thread's 8 S rows (r0, r0 + 4, ...) are requested before the first one is written: one memory round trip
+      const int r0 = tid >> 6;
+      float4 v[8 * S];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 8 * S; ++k) {
         int64_t row = row0 + r0 + 4 * k;
         if (row >= w.M) row = w.M - 1;                     // padding samples compute on a valid row; their results are dropped
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c_in) v[k] = *reinterpret_cast<const float4 *>(a.in0 + row * a.ld_in0 + col);
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 8 * S; ++k) {
         float4 o = v[k];
         o.x = k0 ? o.x : 0.f; o.y = k1 ? o.y : 0.f; o.z = k2 ? o.z : 0.f; o.w = k3 ? o.w : 0.f;
         if (c_wr) *reinterpret_cast<float4 *>(X + (r0 + 4 * k) * R2_P + col) = o;
