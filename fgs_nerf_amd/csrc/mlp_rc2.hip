@@ -277,10 +277,11 @@ __device__ __forceinline__ void r2_side_share(int n_ft, int S, int wave, int &ft
 }
 
 // fragments of groups 0 and 1 of layer `l` (the ones its reduction starts from) for this wave; layer index beyond the chain: none
+template <int NFT>
 __device__ __forceinline__ void r2_prefetch(const R2Args &a, int l, const R2Wave &w, floatx4 (&pre)[2][2]) {
   if (l >= a.n_layers) return;
   const R2Layer &L = a.L[l];
-  int ft0 = 2 * w.wave, ft1 = 2 * w.wave + 1;
+  int ft0 = (NFT == 8 ? 2 : 1) * w.wave, ft1 = NFT == 8 ? ft0 + 1 : ft0;
   if (L.side) {
     int n0, ns;
     r2_side_share(L.n_ft, w.S, w.wave, ft0, n0, ns);
@@ -291,8 +292,12 @@ __device__ __forceinline__ void r2_prefetch(const R2Args &a, int l, const R2Wave
   pre[0][1] = r2_ldg(A1); pre[1][1] = r2_ldg(A1 + 256);
 }
 
-template <bool BWD, int S>
+// NFT: feature tiles of the chain's main layers -- 8 (width 256: two per wave), 6 (192: one per wave + tiles 4, 5 dealt by
+// (tile, sample tile) like a side layer: 2 S pairs over four waves) or 4 (128: one per wave).
+template <bool BWD, int S, int NFT>
 __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2Wave &w) {
+  constexpr int NF = NFT == 8 ? 2 : 1;
+  constexpr bool REM = NFT == 6;
   const int tid = w.wave * 64 + w.lane;
   const int64_t row0 = w.tile0 * 32;
   unsigned long long tp = 0; (void)tp;
@@ -302,7 +307,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   floatx4 pre[2][2];
-  r2_prefetch(a, 0, w, pre);
+  r2_prefetch<NFT>(a, 0, w, pre);
   {
     // 16 bytes per thread and step, row = idx / 64, column group = idx % 64; loads in batches of 8 (one exposed memory latency
     // per batch: issued one by one, each float4 waited ~1.5 K cycles for its own round trip -- 60 K cycles per slab)
@@ -382,41 +387,63 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
     const int k8x = __builtin_amdgcn_readfirstlane(L.k8x), k8e = __builtin_amdgcn_readfirstlane(L.k8e);
     floatx16 acc[2][R2_SMAX];
     if (!L.side) {
-      // ---------------------------------------------------------------- main layer: features 64 w .. 64 w + 63, all S tiles
-      const int ftb = 2 * w.wave;
+      // ---------------------------------------------------------------- main layer: feature tiles NF w .. of all S sample tiles
+      // (+ for 6 tiles: tile 4 + (w & 1) of the sample tiles r2_side_share deals to this wave)
+      const int ftb = NF * w.wave;
+      floatx16 accR[2][R2_SMAX];
+      int ftr = 0, n0r = 0, nsr = 0;
+      if (REM) {
+        r2_side_share(2, S, w.wave, ftr, n0r, nsr);
+        ftr += 4;
+        n0r = __builtin_amdgcn_readfirstlane(n0r); nsr = __builtin_amdgcn_readfirstlane(nsr);
+      }
       R2_T(tp);
       // accumulators start from the bias (row 8 (r >> 2) + 4 h + (r & 3) of each feature tile); no bias: the zeros behind the image
       {
         const float *bias = (!BWD && L.bias) ? L.bias : a.zeros;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NF + (REM ? 1 : 0); ++f) {
+          const int ft = f < NF ? ftb + f : ftr;
           floatx16 b0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const floatx4 bq = r2_ldg(bias + 32 * (ftb + f) + 8 * q + 4 * w.h);
+            const floatx4 bq = r2_ldg(bias + 32 * ft + 8 * q + 4 * w.h);
             b0[4 * q] = bq[0]; b0[4 * q + 1] = bq[1]; b0[4 * q + 2] = bq[2]; b0[4 * q + 3] = bq[3];
           }
+          if (f < NF) {
 #pragma unroll
-          for (int n = 0; n < S; ++n) acc[f][n] = b0;
+            for (int n = 0; n < S; ++n) acc[f][n] = b0;
+          } else {
+            accR[0][0] = b0; accR[0][1] = b0;
+          }
         }
       }
-      const float *const A[2] = {r2_frag(a, L, ftb, w.lane), r2_frag(a, L, ftb + 1, w.lane)};
+      const float *const A[2] = {r2_frag(a, L, ftb, w.lane), r2_frag(a, L, ftb + (NF == 2 ? 1 : 0), w.lane)};
       R2_ACC(w.t_init, tp); R2_T(tp);
       {
         const float *const xb[R2_SMAX] = {xrow[0], xrow[1], xrow[2], xrow[3]};
-        r2_reduce<2, S, 8 * S>(acc, A, xb, k8x, pre, st);
+        r2_reduce<NF, S, 8 * S>(acc, A, xb, k8x, pre, st);
       }
       r2_stream_flush(st, 8 * S);      // (a reduction with fewer groups than rows to copy: not in the shipped chains)
-      if (k8e > 0) {      // the appended columns: the fragment stream simply continues
+      if (NFT == 8 && k8e > 0) {      // the appended columns: the fragment stream simply continues
         const float *const A2[2] = {A[0] + (int64_t)k8x * 256, A[1] + (int64_t)k8x * 256};
         floatx4 pre2[2][2] = {{r2_ldg(A2[0]), r2_ldg(A2[1])}, {r2_ldg(A2[0] + 256), r2_ldg(A2[1] + 256)}};
         const float *const eb[R2_SMAX] = {erow[0], erow[1], erow[2], erow[3]};
-        r2_reduce<2, S, 0>(acc, A2, eb, k8e, pre2, st);
+        r2_reduce<NF, S, 0>(acc, A2, eb, k8e, pre2, st);
+      }
+      if (REM && nsr > 0) {           // tiles 4, 5 of a 192-wide layer: this wave's (tile, sample tiles) share
+        const float *Ar = r2_frag(a, L, ftr, w.lane);
+        const float *const A2[2] = {Ar, Ar};
+        floatx4 pre2[2][2] = {{r2_ldg(Ar), r2_ldg(Ar)}, {r2_ldg(Ar + 256), r2_ldg(Ar + 256)}};
+        const float *x0 = X + (n0r * 32 + w.j) * R2_P + 4 * w.h;
+        const float *const xr[R2_SMAX] = {x0, x0 + 32 * R2_P, x0, x0};
+        if (nsr == 2) r2_reduce<1, 2, 0>(accR, A2, xr, k8x, pre2, st);
+        else r2_reduce<1, 1, 0>(accR, A2, xr, k8x, pre2, st);
       }
       R2_ACC(w.t_red, tp); R2_T(tp);
       // every wave has read X for the last time in this layer
       __builtin_amdgcn_s_barrier();
-      r2_prefetch(a, l + 1, w, pre);
+      r2_prefetch<NFT>(a, l + 1, w, pre);
       __builtin_amdgcn_sched_barrier(0);
       // ---- epilogue, straight-line: ReLU / mask, sign bits, the new activations over X; their HBM copy leaves from inside the
       // next reduction (R2Stream), the sign bits here (one word per sample tile)
@@ -436,9 +463,17 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
 #pragma unroll
       for (int n = 0; n < S; ++n) {
         unsigned bits = 0u;
+        const bool rem_here = REM && n >= n0r && n < n0r + nsr;      // (uniform)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          floatx16 v = acc[f][n];
+          if (f >= NF && !REM) { if (!BWD) bits <<= 16; continue; }   // (one tile per wave: the word's second half stays empty)
+          floatx16 v;
+          if (f < NF) v = acc[f][n];
+          else {
+            if (!rem_here) { if (!BWD) bits <<= 16; continue; }
+            v = (n - n0r == 0) ? accR[0][0] : accR[0][1];
+          }
+          const int ft = f < NF ? ftb + f : ftr;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (!BWD) {
@@ -453,7 +488,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const floatx4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            *(__attribute__((address_space(3))) floatx4 *)r2_l(X + (n * 32 + w.j) * R2_P + 32 * (ftb + f) + 8 * q + 4 * w.h) = o;
+            *(__attribute__((address_space(3))) floatx4 *)r2_l(X + (n * 32 + w.j) * R2_P + 32 * ft + 8 * q + 4 * w.h) = o;
           }
         }
         if (!BWD) mw[mi[n]] = bits;
@@ -461,8 +496,11 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
       // the copy of this output: rows 4 i + wave of the slab, from X
       st.on = true; st.i = 0; st.valid = st_rows;
       st.lds = r2_l(X + w.wave * R2_P + 4 * w.lane);
-      st.g = L.out + (row0 + w.wave) * L.ldo + 4 * w.lane;
-      st.g_step = 4 * L.ldo;
+      {   // (a row is 32 NFT floats: the lanes beyond it keep storing into the sink)
+        const bool lane_ok = 4 * w.lane < 32 * NFT;
+        st.g = lane_ok ? L.out + (row0 + w.wave) * L.ldo + 4 * w.lane : st.sink;
+        st.g_step = lane_ok ? 4 * L.ldo : 0;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes have landed before anybody is released
       __builtin_amdgcn_s_barrier();
       R2_ACC(w.t_epi, tp);
@@ -481,7 +519,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
       if (ns == 2) r2_reduce<1, 2, 8 * S>(acc, A, xb, k8x, pre, st);
       else if (ns == 1) r2_reduce<1, 1, 8 * S>(acc, A, xb, k8x, pre, st);
       r2_stream_flush(st, 8 * S);
-      r2_prefetch(a, l + 1, w, pre);
+      r2_prefetch<NFT>(a, l + 1, w, pre);
       __builtin_amdgcn_sched_barrier(0);
       const int n_store = __builtin_amdgcn_readfirstlane(L.n_store);
 #pragma unroll
@@ -503,7 +541,7 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
   r2_stream_flush(st, 8 * S);       // the last main layer's output (X is not touched again before the next slab's opening barrier)
 }
 
-template <bool BWD>
+template <bool BWD, int NFT>
 __global__ __launch_bounds__(R2_THREADS, 1) void k_mlp_rc2(R2Args a) {
   __shared__ __attribute__((aligned(16))) float lds[R2_X_FLOATS + R2_E_FLOATS];
   float *X = lds, *E = lds + R2_X_FLOATS;
@@ -531,10 +569,10 @@ __global__ __launch_bounds__(R2_THREADS, 1) void k_mlp_rc2(R2Args a) {
     const int S = (int)(left >= 7 ? 4 : left >= 5 ? 3 : left);
     w.tile0 = tb; w.S = S;
     switch (S) {
-      case 4: r2_slab<BWD, 4>(a, X, E, w); break;
-      case 3: r2_slab<BWD, 3>(a, X, E, w); break;
-      case 2: r2_slab<BWD, 2>(a, X, E, w); break;
-      default: r2_slab<BWD, 1>(a, X, E, w); break;
+      case 4: r2_slab<BWD, 4, NFT>(a, X, E, w); break;
+      case 3: r2_slab<BWD, 3, NFT>(a, X, E, w); break;
+      case 2: r2_slab<BWD, 2, NFT>(a, X, E, w); break;
+      default: r2_slab<BWD, 1, NFT>(a, X, E, w); break;
     }
     tb += S;
   }
@@ -553,7 +591,7 @@ int r2_pad4(int v) { return (v + 3) / 4 * 4; }
 void r2_geometry(int backward, const fgs_rc2_layer_t &U, int &n_ft, int &k8x, int &k8e) {
   const int rows = backward ? U.n_in : U.n_out, k = backward ? U.n_out : U.n_in;
   const int ext = backward ? 0 : U.ext_cols;
-  n_ft = U.side ? (rows + 31) / 32 : 8;
+  n_ft = (rows + 31) / 32;
   if (ext > 0) { k8x = 32; k8e = r2_pad4((k - 256 + 7) / 8); }
   else { k8x = r2_pad4((k + 7) / 8); k8e = 0; }
 }
@@ -593,6 +631,7 @@ FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_r
   a.ext = nullptr; a.ld_ext = 0; a.ext_cols = 0; a.ext_valid = 0;
   p.n_layers = n_layers; p.transpose = backward ? 1 : 0; p.img = image_ws; p.zeros = const_cast<float *>(a.zeros);
   int carried = in0_cols;            // columns of the carried input (what X holds)
+  int main_rows = 0;                 // width of the chain's main layers
   int64_t base = 0;
   for (int l = 0; l < n_layers; ++l) {
     const fgs_rc2_layer_t &U = layers[l];
@@ -609,9 +648,11 @@ FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_r
       FGS_REQUIRE(rows <= 64 && U.out && !U.bias && !U.relu && !U.mask_bits, FGS_E_INVALID,
                   "fgs_mlp_rc2_chain: side layer %d: <= 64 output columns, an output, no bias / activation", l);
     else
-      FGS_REQUIRE(rows == 256 && U.out && U.n_store == 256, FGS_E_INVALID,
-                  "fgs_mlp_rc2_chain: layer %d produces %d columns (stores %d): main layers are 256 wide and their output is "
-                  "stored whole (other widths: fgs_mlp_rc_chain)", l, rows, U.n_store);
+      FGS_REQUIRE((rows == 256 || rows == 192 || rows == 128) && (main_rows == 0 || rows == main_rows) && U.out &&
+                      U.n_store == rows && (rows == 256 || ext_cols == 0), FGS_E_INVALID,
+                  "fgs_mlp_rc2_chain: layer %d produces %d columns (stores %d): the main layers of one chain are all 256, "
+                  "192 or 128 wide, their output is stored whole, appended columns need 256", l, rows, U.n_store);
+    if (!U.side) main_rows = rows;
     FGS_REQUIRE(!U.out || ((U.ldo % 4) == 0 && r2_aligned16(U.out) && (U.n_store % 4) == 0 && U.n_store <= (U.side ? 64 : 256) &&
                            U.ldo >= U.n_store), FGS_E_INVALID, "fgs_mlp_rc2_chain: layer %d: bad output", l);
     FGS_REQUIRE((!U.bias || r2_aligned16(U.bias)) && (!U.mask_bits || (reinterpret_cast<uintptr_t>(U.mask_bits) & 3) == 0),
@@ -631,7 +672,7 @@ FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_r
     P2Layer &P = p.L[l];
     P.W = U.W; P.ldw = U.ldw; P.n_out = U.n_out; P.n_in = U.n_in; P.n_ft = L.n_ft; P.k8 = L.k8x + L.k8e; P.f4_begin = base / 4;
     base += (int64_t)L.n_ft * (L.k8x + L.k8e) * 256;
-    if (!U.side) carried = 256;
+    if (!U.side) carried = rows;
   }
   if (a.in0_zero_to < in0_cols) a.in0_zero_to = in0_cols;
   p.f4_total = base / 4;
@@ -644,8 +685,11 @@ FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_r
     cus = 256;
   const int64_t T = (M + 31) / 32;
   const unsigned grid = (unsigned)(T < cus ? T : cus);
-  if (backward) hipLaunchKernelGGL((k_mlp_rc2<true>), dim3(grid), dim3(R2_THREADS), 0, st, a);
-  else hipLaunchKernelGGL((k_mlp_rc2<false>), dim3(grid), dim3(R2_THREADS), 0, st, a);
+  FGS_REQUIRE(main_rows > 0, FGS_E_INVALID, "fgs_mlp_rc2_chain: a chain needs a main layer");
+#define R2_LAUNCH(B, N) hipLaunchKernelGGL((k_mlp_rc2<B, N>), dim3(grid), dim3(R2_THREADS), 0, st, a)
+  if (backward) { if (main_rows == 256) R2_LAUNCH(true, 8); else if (main_rows == 192) R2_LAUNCH(true, 6); else R2_LAUNCH(true, 4); }
+  else { if (main_rows == 256) R2_LAUNCH(false, 8); else if (main_rows == 192) R2_LAUNCH(false, 6); else R2_LAUNCH(false, 4); }
+#undef R2_LAUNCH
   FGS_LAUNCH_OK("fgs_mlp_rc2_chain");
   return 0;
 }

@@ -121,9 +121,15 @@ class _FusedCoarse(torch.autograd.Function):
         if use_rc:       # widths 192 (coarse) and 128 (geometry_searching): the same register-resident chain as the fine stage
             relu_bits = torch.empty(n_ref - 1, fo.rc_mask_bits(M, dev).numel(), dtype=torch.int32, device=dev)
             acts += [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]
+            # (FGS_MLP_FORM_COARSE=2: the feature-split form, csrc/mlp_rc2.hip -- 6 / 4 feature tiles at widths 192 / 128.  Measured,
+            # round 4, bench.py --stage coarse on one box: forward chain 159 us against 130, backward chain with the compact dX0 as a
+            # side layer 131 against 100 + 48, step 1.1245 against 1.1142 ms -- with 12 sample tiles per CU neither form is
+            # quantised here, and 16 + 8 MFMAs per k-group (one tile per wave + the dealt remainder) carry the same per-group and
+            # per-layer fixed costs as the fine stage's 32: the register-resident form stays the default)
+            rc_form = 2 if (os.environ.get("FGS_MLP_FORM_COARSE", "1") == "2" and fw in (128, 192, 256) and n_ref - 1 <= 8) else 1
             fo.rc_chain(False, M, X0, ldx0, [dict(W=ref_w[i].detach(), bias=ref_b[i].detach(), relu=True, mask_bits=relu_bits[i],
                                                    out=acts[i + 1], n_store=fw) for i in range(n_ref - 1)],
-                        flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), rows_dev=_rows(run))
+                        flop=2.0 * M * fw * sum(w.shape[1] for w in ref_w[:-1]), rows_dev=_rows(run), form=rc_form)
             a = acts[-1]
         else:
             for i in range(n_ref - 1):
@@ -148,7 +154,7 @@ class _FusedCoarse(torch.autograd.Function):
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev), pre_k0)
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, gradient=gradient, weights=weights, rgb=rgb, X0=X0, acts=acts,
-                                   V0p=V0p, V0c=V0c, relu_bits=relu_bits, pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
+                                   V0p=V0p, V0c=V0c, relu_bits=relu_bits, rc_form=(rc_form if use_rc else None), pre_rgb=pre_rgb, pre_sig=pre_sig, alphainv_last=alphainv_last,
                                    k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,
                           n_inbbox=ws['n_inbbox'])
@@ -232,9 +238,20 @@ class _FusedCoarse(torch.autograd.Function):
                 out = torch.empty(M, fw, dtype=F32, device=dev)
                 layers.append(dict(W=ref_w[i], mask_bits=bits[i - 1], out=out, n_store=fw))
                 dYs[i - 1] = out
+            form = S.get('rc_form') or 1
+            flop_b = 2.0 * M * fw * fw * len(layers)
+            if form == 2 and layers and S.get('V0c') is not None and S['V0c'].shape[1] <= 64:
+                # the compact dX0 rides in the chain as its last (side) layer
+                V0c = S['V0c']
+                dX0 = torch.empty(M, V0c.shape[1], dtype=F32, device=dev)
+                layers.append(dict(W=V0c, out=dX0, n_store=V0c.shape[1], side=True))
+                flop_b += 2.0 * M * fw * run.dx0_cols[2]
+                dx0_compact = True
             if layers:
-                fo.rc_chain(True, M, dY, fw, layers, flop=2.0 * M * fw * fw * len(layers), rows_dev=_rows(run))
-            if S.get('V0c') is not None:     # compact dX0 (fgs_dyn_t.dx0_compact)
+                fo.rc_chain(True, M, dY, fw, layers, flop=flop_b, rows_dev=_rows(run), form=form)
+            if dX0 is not None:
+                pass
+            elif S.get('V0c') is not None:     # compact dX0 (fgs_dyn_t.dx0_compact)
                 V0c = S['V0c']
                 dX0 = torch.empty(M, V0c.shape[1], dtype=F32, device=dev)
                 _gemm(fo.GEMM_NN, dYs[0], V0c, dX0, M, V0c.shape[1], fw, logical=(M, run.dx0_cols[2], fw), rows_dev=_rows(run))

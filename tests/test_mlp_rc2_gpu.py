@@ -119,3 +119,34 @@ def test_rc2_is_deterministic_and_close_to_the_first_form(dev):
     for x, y, z in zip(a, b, c):
         assert torch.equal(x[:, :256], y[:, :256])
         assert rel_l2(x[:, :256], z[:, :256]) < 1e-6
+
+
+@pytest.mark.parametrize("width,n_in,M,compact", [(192, 90, 777, 48), (192, 90, 40000, 48), (128, 72, 513, 36), (128, 72, 30000, 36)])
+def test_rc2_coarse_widths(dev, width, n_in, M, compact):
+    """The coarse (90 -> 192 -> 192) and geometry_searching (72 -> 128 -> 128) refnet trunks: 6 feature tiles (one per wave plus
+    tiles 4, 5 dealt by (tile, sample tile)) and 4 (one per wave); forward, and backward with the compact dX0 as a side layer."""
+    from fgs_nerf_amd import fused_ops as fo
+    g = torch.Generator().manual_seed(width + M)
+    ld = (n_in + 3) // 4 * 4
+    X0 = torch.randn(M, ld, generator=g).to(dev)
+    X0[:, n_in:] = float('nan')
+    W0, W1 = (torch.randn(width, n_in, generator=g) * 0.1).to(dev), (torch.randn(width, width, generator=g) * 0.08).to(dev)
+    b0, b1 = (torch.randn(width, generator=g) * 0.1).to(dev), (torch.randn(width, generator=g) * 0.1).to(dev)
+    o0, o1 = (torch.full((M, width), float('nan'), device=dev) for _ in range(2))
+    m0, m1 = fo.rc_mask_bits(M, dev), fo.rc_mask_bits(M, dev)
+    fo.rc_chain(False, M, X0, ld, [dict(W=W0, bias=b0, relu=1, mask_bits=m0, out=o0, n_store=width),
+                                   dict(W=W1, bias=b1, relu=1, mask_bits=m1, out=o1, n_store=width)], form=2)
+    r0 = torch.relu(X0[:, :n_in].double() @ W0.double().T + b0.double())
+    r1 = torch.relu(r0 @ W1.double().T + b1.double())
+    assert bool(torch.isfinite(o0).all()) and bool(torch.isfinite(o1).all())
+    assert rel_l2(o0, r0) < 2e-6 and rel_l2(o1, r1) < 2e-6
+    dY = torch.randn(M, width, generator=g).to(dev)
+    d0 = torch.full((M, width), float('nan'), device=dev)
+    W0c = W0[:, :compact].contiguous()                        # (any column subset: the product only sees a [width, compact] matrix)
+    dX0 = torch.full((M, compact), float('nan'), device=dev)
+    fo.rc_chain(True, M, dY, width, [dict(W=W1, mask_bits=m0, out=d0, n_store=width),
+                                     dict(W=W0c, out=dX0, n_store=compact, side=True)], form=2)
+    g0 = (dY.double() @ W1.double()) * (r0 > 0)
+    assert bool(torch.isfinite(d0).all()) and bool(torch.isfinite(dX0).all())
+    assert rel_l2(d0, g0) < 2e-6
+    assert rel_l2(dX0, g0 @ W0c.double()) < 2e-6
