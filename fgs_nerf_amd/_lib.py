@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -56,7 +56,8 @@ _SIGNATURES = {
     "fgs_adam_upd_dev": [P, P, P, P, P, I64, P, I32, F32, F32, F32, F32, I32, P, P],
     "fgs_adam_upd_multi_dev": [I32, P, P, P, P, P, P, P, P, P, F32, F32, F32, P, P],
     "fgs_mlp_rc_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P, P],
-    "fgs_mlp_rc2_chain": [I32, I64, I32, P, P, I64, I32, P, I64, P, P],
+    "fgs_mlp_rc2_chain": [I32, I64, I32, P, P, I64, I32, P, I64, I32, P, P],
+    "fgs_mlp_rc2_pack": [I32, I32, P, I32, P, I64, I32, I32, P, I32, P, I64, P],
     "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P, P],

@@ -110,7 +110,9 @@ class MaskedAdam(torch.optim.Optimizer):
             return self._dev['ss'][gi], self._dev['skip']
         return None, self._skip
 
-    def _flush_small(self, batch, b1, b2, eps, ss_ptr=None, skip=None):
+    def _flush_small(self, batch, b1, b2, eps, skip=None):
+        """One launch for every small tensor of the step that shares (betas, eps): rows (param, grad, exp_avg, exp_avg_sq, step,
+        lr, masked, step-size device pointer or None) -- the groups' learning rates / step sizes are per tensor."""
         n = len(batch)
         if n == 0:
             return
@@ -120,8 +122,10 @@ class MaskedAdam(torch.optim.Optimizer):
         masked = (ctypes.c_int * n)(*[int(bool(row[6])) for row in batch])
         steps = (ctypes.c_int * n)(*[row[4] for row in batch])
         lrs = (ctypes.c_float * n)(*[row[5] for row in batch])
-        if ss_ptr is not None or skip is not None:
-            ss = (P * n)(*[ss_ptr] * n) if ss_ptr is not None else None
+        if skip is not None or any(row[7] is not None for row in batch):
+            ss = (P * n)(*[row[7] for row in batch]) if all(row[7] is not None for row in batch) else None
+            if ss is None and any(row[7] is not None for row in batch):
+                raise RuntimeError("MaskedAdam: a device schedule must cover every parameter group")
             call("fgs_adam_upd_multi_dev", n, *tables, sizes, ss, steps, lrs, masked, float(b1), float(b2), float(eps), skip,
                  stream())
             return
@@ -272,11 +276,13 @@ class MaskedAdam(torch.optim.Optimizer):
         are read from device memory, nothing that changes from step to step is passed by value."""
         early, self._early = self._early, {}
         host = self._dev is None
+        from . import fused_ops as _fo
+        _fo.WEIGHTS_EPOCH[0] += 1           # (packed weight images of the MLP chains are stale from here on: fused_ops.rc2_pack)
+        small = {}        # (b1, b2, eps, skip) -> rows: the small tensors of ALL groups with the same hyper-parameters, ONE launch
         for group in self.param_groups:
             b1, b2 = group['betas']
             ss_ptr, skip = self._sched(group)
             masked = group['skip_zero_grad']
-            small = []
             for p in group['params']:
                 if p.grad is None or id(p) in early:    # already updated by early_update()
                     continue
@@ -291,10 +297,12 @@ class MaskedAdam(torch.optim.Optimizer):
                 per_lr = self.per_lr is not None and p.shape == self.per_lr.shape
                 if (not per_lr and p.is_cuda and p.numel() < _SMALL and p.is_contiguous() and g.is_contiguous()
                         and p.dtype == torch.float32):
-                    small.append((p, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], masked))
+                    small.setdefault((float(b1), float(b2), float(group['eps']), skip), []).append(
+                        (p, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], masked, ss_ptr))
                 else:
                     self._big(p, g, st, group, ss_ptr, skip)
-            self._flush_small(small, b1, b2, group['eps'], ss_ptr=ss_ptr, skip=skip)
+        for (b1, b2, eps, skip), rows in small.items():
+            self._flush_small(rows, b1, b2, eps, skip=skip)
         for done in early.values():                     # everything after step() sees the early updates
             if done is not None:
                 torch.cuda.current_stream().wait_event(done)

@@ -76,20 +76,22 @@ struct P2Layer {
   int64_t ldw;
   int n_out, n_in;      // W is [n_out][ldw] with n_in valid columns
   int n_ft, k8;         // image geometry
-  int64_t f4_begin;     // first float4 of this layer in the flat work range (= img / 4)
+  int transpose;
+  float *dst;           // the layer's fragments
+  int64_t f4_begin;     // first float4 of this layer in the flat work range of the launch
 };
-struct P2Args {
-  int n_layers, transpose;
-  float *img;
-  float *zeros;         // R2_ZERO_FLOATS floats, zero-filled by the first threads
+struct P2Args {           // up to two chains' images in one launch (fgs_mlp_rc2_pack: the forward and the backward chain of a step)
+  int n_layers;
+  float *zeros[2];      // R2_ZERO_FLOATS floats each, zero-filled by the first threads (second may be null)
   int64_t f4_total;
-  P2Layer L[R2_MAXL];
+  P2Layer L[2 * R2_MAXL];
 };
 
 // image element (row, k) = transpose ? W[k][row] : W[row][k]; zero outside.  One thread per float4 = one lane's operand.
 __global__ __launch_bounds__(FGS_BLOCK) void k_rc2_pack(P2Args a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64) reinterpret_cast<float4 *>(a.zeros)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < 64) reinterpret_cast<float4 *>(a.zeros[0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  else if (i < 128 && a.zeros[1]) reinterpret_cast<float4 *>(a.zeros[1])[i - 64] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i >= a.f4_total) return;
   int l = 0;
   while (l + 1 < a.n_layers && i >= a.L[l + 1].f4_begin) ++l;
@@ -98,16 +100,16 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_rc2_pack(P2Args a) {
   const int lane = (int)(q & 63);
   const int g = (int)((q >> 6) % L.k8), ft = (int)((q >> 6) / L.k8);
   const int row = 32 * ft + (lane & 31), k0 = 8 * g + 4 * (lane >> 5);
-  const int n_rows = a.transpose ? L.n_in : L.n_out, n_k = a.transpose ? L.n_out : L.n_in;
+  const int n_rows = L.transpose ? L.n_in : L.n_out, n_k = L.transpose ? L.n_out : L.n_in;
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = k0 + j;
     float x = 0.f;
-    if (row < n_rows && k < n_k) x = a.transpose ? L.W[(int64_t)k * L.ldw + row] : L.W[(int64_t)row * L.ldw + k];
+    if (row < n_rows && k < n_k) x = L.transpose ? L.W[(int64_t)k * L.ldw + row] : L.W[(int64_t)row * L.ldw + k];
     v[j] = x;
   }
-  *reinterpret_cast<float4 *>(a.img + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4 *>(L.dst + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ the chain
@@ -609,57 +611,54 @@ FGS_API int64_t fgs_mlp_rc2_image_floats(int backward, int n_layers, const fgs_r
   return total + R2_SINK_FLOATS + R2_ZERO_FLOATS;
 }
 
-FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_rc2_layer_t *layers, const float *in0,
-                              int64_t ld_in0, int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn,
-                              fgs_stream_t stream) {
-  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_layers >= 1 && n_layers <= R2_MAXL, FGS_E_RANGE,
-              "fgs_mlp_rc2_chain: M=%lld n_layers=%d (1..%d)", (long long)M, n_layers, R2_MAXL);
-  if (M == 0) return 0;
-  FGS_REQUIRE(layers && in0 && image_ws, FGS_E_INVALID, "fgs_mlp_rc2_chain: null pointer");
-  FGS_REQUIRE(in0_cols > 0 && in0_cols <= 256 && (in0_cols % 4) == 0 && (ld_in0 % 4) == 0 && ld_in0 >= in0_cols &&
-                  r2_aligned16(in0) && r2_aligned16(image_ws),
-              FGS_E_INVALID, "fgs_mlp_rc2_chain: first input: 4..256 columns, multiple of 4, 16-byte aligned rows");
+namespace {
+// validates a chain and fills the kernel arguments and the pack records of its layers (appended to p.L from p.n_layers on)
+int r2_build(const char *who, int backward, int64_t M, int n_layers, const fgs_rc2_layer_t *layers, const float *in0, int64_t ld_in0,
+             int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, R2Args &a, P2Args &p, int chain_slot,
+             int &main_rows_out) {
+  FGS_REQUIRE(n_layers >= 1 && n_layers <= R2_MAXL, FGS_E_RANGE, "%s: n_layers=%d (1..%d)", who, n_layers, R2_MAXL);
+  FGS_REQUIRE(layers && image_ws && (reinterpret_cast<uintptr_t>(image_ws) & 15) == 0, FGS_E_INVALID, "%s: null / unaligned pointer", who);
+  FGS_REQUIRE(in0_cols > 0 && in0_cols <= 256 && (in0_cols % 4) == 0 && (ld_in0 % 4) == 0 && ld_in0 >= in0_cols,
+              FGS_E_INVALID, "%s: first input: 4..256 columns, multiple of 4", who);
   const int64_t need = fgs_mlp_rc2_image_floats(backward, n_layers, layers);
-  FGS_REQUIRE(image_ws_floats >= need, FGS_E_INVALID, "fgs_mlp_rc2_chain: image workspace %lld floats, need %lld",
-              (long long)image_ws_floats, (long long)need);
-  R2Args a;
-  P2Args p;
+  FGS_REQUIRE(image_ws_floats >= need, FGS_E_INVALID, "%s: image workspace %lld floats, need %lld", who, (long long)image_ws_floats,
+              (long long)need);
   a.M = M; a.m_dev = fgs_dyn_rows(dyn); a.n_layers = n_layers; a.img = image_ws; a.stamps = fgs_dyn_stamps(dyn);
   a.sink = image_ws + (need - R2_SINK_FLOATS - R2_ZERO_FLOATS);
   a.zeros = image_ws + (need - R2_ZERO_FLOATS);
   a.in0 = in0; a.ld_in0 = ld_in0; a.in0_cols = in0_cols;
   a.ext = nullptr; a.ld_ext = 0; a.ext_cols = 0; a.ext_valid = 0;
-  p.n_layers = n_layers; p.transpose = backward ? 1 : 0; p.img = image_ws; p.zeros = const_cast<float *>(a.zeros);
+  p.zeros[chain_slot] = const_cast<float *>(a.zeros);
   int carried = in0_cols;            // columns of the carried input (what X holds)
   int main_rows = 0;                 // width of the chain's main layers
   int64_t base = 0;
   for (int l = 0; l < n_layers; ++l) {
     const fgs_rc2_layer_t &U = layers[l];
-    FGS_REQUIRE(U.W && U.n_out > 0 && U.n_in > 0 && U.ldw >= U.n_in, FGS_E_INVALID, "fgs_mlp_rc2_chain: layer %d: bad weight", l);
+    FGS_REQUIRE(U.W && U.n_out > 0 && U.n_in > 0 && U.ldw >= U.n_in, FGS_E_INVALID, "%s: layer %d: bad weight", who, l);
     const int rows = backward ? U.n_in : U.n_out, k = backward ? U.n_out : U.n_in;
     const int ext_cols = backward ? 0 : U.ext_cols;
     FGS_REQUIRE(k <= carried + ext_cols && carried + ext_cols < k + 4, FGS_E_INVALID,
-                "fgs_mlp_rc2_chain: layer %d reduces over %d columns but its input has %d (+%d appended)", l, k, carried, ext_cols);
+                "%s: layer %d reduces over %d columns but its input has %d (+%d appended)", who, l, k, carried, ext_cols);
     FGS_REQUIRE(ext_cols >= 0 && ext_cols <= R2_PE && (ext_cols % 4) == 0 &&
                     (ext_cols == 0 || (U.ext && !a.ext && carried == 256 && (U.ld_ext % 4) == 0 && r2_aligned16(U.ext) && !U.side)),
-                FGS_E_INVALID, "fgs_mlp_rc2_chain: layer %d: appended columns need a full 256-column carried input, <= %d of them, "
-                               "multiple of 4, aligned, at most one such layer", l, R2_PE);
+                FGS_E_INVALID, "%s: layer %d: appended columns need a full 256-column carried input, <= %d of them, "
+                               "multiple of 4, aligned, at most one such layer", who, l, R2_PE);
     if (U.side)
       FGS_REQUIRE(rows <= 64 && U.out && !U.bias && !U.relu && !U.mask_bits, FGS_E_INVALID,
-                  "fgs_mlp_rc2_chain: side layer %d: <= 64 output columns, an output, no bias / activation", l);
+                  "%s: side layer %d: <= 64 output columns, an output, no bias / activation", who, l);
     else
       FGS_REQUIRE((rows == 256 || rows == 192 || rows == 128) && (main_rows == 0 || rows == main_rows) && U.out &&
                       U.n_store == rows && (rows == 256 || ext_cols == 0), FGS_E_INVALID,
-                  "fgs_mlp_rc2_chain: layer %d produces %d columns (stores %d): the main layers of one chain are all 256, "
-                  "192 or 128 wide, their output is stored whole, appended columns need 256", l, rows, U.n_store);
+                  "%s: layer %d produces %d columns (stores %d): the main layers of one chain are all 256, "
+                  "192 or 128 wide, their output is stored whole, appended columns need 256", who, l, rows, U.n_store);
     if (!U.side) main_rows = rows;
     FGS_REQUIRE(!U.out || ((U.ldo % 4) == 0 && r2_aligned16(U.out) && (U.n_store % 4) == 0 && U.n_store <= (U.side ? 64 : 256) &&
-                           U.ldo >= U.n_store), FGS_E_INVALID, "fgs_mlp_rc2_chain: layer %d: bad output", l);
+                           U.ldo >= U.n_store), FGS_E_INVALID, "%s: layer %d: bad output", who, l);
     FGS_REQUIRE((!U.bias || r2_aligned16(U.bias)) && (!U.mask_bits || (reinterpret_cast<uintptr_t>(U.mask_bits) & 3) == 0),
-                FGS_E_INVALID, "fgs_mlp_rc2_chain: layer %d: bias must be 16-byte aligned", l);
+                FGS_E_INVALID, "%s: layer %d: bias must be 16-byte aligned", who, l);
     R2Layer &L = a.L[l];
     r2_geometry(backward, U, L.n_ft, L.k8x, L.k8e);
-    FGS_REQUIRE(L.n_ft >= 1 && L.k8x * 8 <= 256, FGS_E_RANGE, "fgs_mlp_rc2_chain: layer %d: reduction over %d columns", l, k);
+    FGS_REQUIRE(L.n_ft >= 1 && L.k8x * 8 <= 256, FGS_E_RANGE, "%s: layer %d: reduction over %d columns", who, l, k);
     L.img = base;
     L.side = U.side ? 1 : 0;
     L.relu = backward ? 0 : U.relu;
@@ -669,27 +668,88 @@ FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_r
     L.out = U.out; L.ldo = U.ldo; L.n_store = U.n_store;
     if (ext_cols) { a.ext = U.ext; a.ld_ext = U.ld_ext; a.ext_cols = ext_cols; a.ext_valid = k - carried; }
     if (l == 0) { a.in0_valid = ext_cols ? in0_cols : (k < in0_cols ? k : in0_cols); a.in0_zero_to = L.k8x * 8; }
-    P2Layer &P = p.L[l];
-    P.W = U.W; P.ldw = U.ldw; P.n_out = U.n_out; P.n_in = U.n_in; P.n_ft = L.n_ft; P.k8 = L.k8x + L.k8e; P.f4_begin = base / 4;
+    P2Layer &P = p.L[p.n_layers++];
+    P.W = U.W; P.ldw = U.ldw; P.n_out = U.n_out; P.n_in = U.n_in; P.n_ft = L.n_ft; P.k8 = L.k8x + L.k8e;
+    P.transpose = backward ? 1 : 0; P.dst = image_ws + base; P.f4_begin = p.f4_total;
+    p.f4_total += (int64_t)L.n_ft * (L.k8x + L.k8e) * 64;
     base += (int64_t)L.n_ft * (L.k8x + L.k8e) * 256;
     if (!U.side) carried = rows;
   }
   if (a.in0_zero_to < in0_cols) a.in0_zero_to = in0_cols;
-  p.f4_total = base / 4;
-  hipStream_t st = fgs_s(stream);
-  hipLaunchKernelGGL(k_rc2_pack, dim3(fgs_blocks(p.f4_total)), dim3(FGS_BLOCK), 0, st, p);
-  FGS_LAUNCH_OK("fgs_mlp_rc2_chain (pack)");
+  FGS_REQUIRE(main_rows > 0, FGS_E_INVALID, "%s: a chain needs a main layer", who);
+  main_rows_out = main_rows;
+  return 0;
+}
+
+int r2_launch(int backward, int64_t M, int main_rows, const R2Args &a, hipStream_t st) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       cus <= 0)
     cus = 256;
   const int64_t T = (M + 31) / 32;
   const unsigned grid = (unsigned)(T < cus ? T : cus);
-  FGS_REQUIRE(main_rows > 0, FGS_E_INVALID, "fgs_mlp_rc2_chain: a chain needs a main layer");
 #define R2_LAUNCH(B, N) hipLaunchKernelGGL((k_mlp_rc2<B, N>), dim3(grid), dim3(R2_THREADS), 0, st, a)
   if (backward) { if (main_rows == 256) R2_LAUNCH(true, 8); else if (main_rows == 192) R2_LAUNCH(true, 6); else R2_LAUNCH(true, 4); }
   else { if (main_rows == 256) R2_LAUNCH(false, 8); else if (main_rows == 192) R2_LAUNCH(false, 6); else R2_LAUNCH(false, 4); }
 #undef R2_LAUNCH
   FGS_LAUNCH_OK("fgs_mlp_rc2_chain");
+  return 0;
+}
+}  // namespace
+
+// prepacked != 0: image_ws already holds this chain's fragments (fgs_mlp_rc2_pack with the same layer list and unchanged weights):
+// no pack launch.
+FGS_API int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_rc2_layer_t *layers, const float *in0,
+                              int64_t ld_in0, int in0_cols, float *image_ws, int64_t image_ws_floats, int prepacked,
+                              const fgs_dyn_t *dyn, fgs_stream_t stream) {
+  FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_mlp_rc2_chain: M=%lld", (long long)M);
+  if (M == 0) return 0;
+  FGS_REQUIRE(in0 && r2_aligned16(in0), FGS_E_INVALID, "fgs_mlp_rc2_chain: first input null / unaligned");
+  R2Args a;
+  P2Args p;
+  p.n_layers = 0; p.f4_total = 0; p.zeros[0] = p.zeros[1] = nullptr;
+  int main_rows = 0;
+  if (int e = r2_build("fgs_mlp_rc2_chain", backward, M, n_layers, layers, in0, ld_in0, in0_cols, image_ws, image_ws_floats, dyn, a, p,
+                       0, main_rows))
+    return e;
+  hipStream_t st = fgs_s(stream);
+  if (!prepacked) {
+    hipLaunchKernelGGL(k_rc2_pack, dim3(fgs_blocks(p.f4_total < 128 ? 128 : p.f4_total)), dim3(FGS_BLOCK), 0, st, p);
+    FGS_LAUNCH_OK("fgs_mlp_rc2_chain (pack)");
+  }
+  return r2_launch(backward, M, main_rows, a, st);
+}
+
+// The weight images of TWO chains (a step's forward and backward chain; the second may be absent: n_layers_b = 0) in ONE launch,
+// for fgs_mlp_rc2_chain(..., prepacked = 1).  Only W / ldw / n_out / n_in / side / ext_cols of the layers are read.
+FGS_API int fgs_mlp_rc2_pack(int backward_a, int n_layers_a, const fgs_rc2_layer_t *layers_a, int in0_cols_a, float *image_ws_a,
+                             int64_t image_ws_floats_a, int backward_b, int n_layers_b, const fgs_rc2_layer_t *layers_b,
+                             int in0_cols_b, float *image_ws_b, int64_t image_ws_floats_b, fgs_stream_t stream) {
+  P2Args p;
+  p.n_layers = 0; p.f4_total = 0; p.zeros[0] = p.zeros[1] = nullptr;
+  const int bw[2] = {backward_a, backward_b}, nl[2] = {n_layers_a, n_layers_b}, ic[2] = {in0_cols_a, in0_cols_b};
+  const fgs_rc2_layer_t *ls[2] = {layers_a, layers_b};
+  float *ws[2] = {image_ws_a, image_ws_b};
+  const int64_t wf[2] = {image_ws_floats_a, image_ws_floats_b};
+  for (int c = 0; c < 2; ++c) {
+    if (nl[c] <= 0) continue;
+    FGS_REQUIRE(nl[c] <= R2_MAXL && ls[c], FGS_E_INVALID, "fgs_mlp_rc2_pack: chain %d: bad layer list", c);
+    // (the pack needs no outputs: validate on a copy whose outputs point at the image itself)
+    fgs_rc2_layer_t tmp[R2_MAXL];
+    for (int l = 0; l < nl[c]; ++l) {
+      tmp[l] = ls[c][l];
+      tmp[l].out = ws[c]; tmp[l].ldo = 256; tmp[l].n_store = tmp[l].side ? 4 : (bw[c] ? tmp[l].n_in : tmp[l].n_out);
+      tmp[l].bias = nullptr; tmp[l].mask_bits = nullptr; tmp[l].relu = 0;
+      if (tmp[l].ext_cols && !tmp[l].ext) tmp[l].ext = ws[c];
+      if (tmp[l].ext_cols && !tmp[l].ld_ext) tmp[l].ld_ext = 256;
+    }
+    R2Args a;
+    int main_rows = 0;
+    if (int e = r2_build("fgs_mlp_rc2_pack", bw[c], 1, nl[c], tmp, ws[c], ic[c], ic[c], ws[c], wf[c], nullptr, a, p, c, main_rows))
+      return e;
+  }
+  if (p.f4_total == 0) return 0;
+  hipLaunchKernelGGL(k_rc2_pack, dim3(fgs_blocks(p.f4_total < 128 ? 128 : p.f4_total)), dim3(FGS_BLOCK), 0, fgs_s(stream), p);
+  FGS_LAUNCH_OK("fgs_mlp_rc2_pack");
   return 0;
 }

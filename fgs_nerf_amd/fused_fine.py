@@ -108,6 +108,19 @@ def _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, a
     return dZ, dX0
 
 
+def _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c):
+    """The layer list of the form-2 backward chain as far as its WEIGHTS go (the order _backward_rc issues: refnet main layers,
+    the reflection-encoding side layer, refnet layer 0, rgbnet main layers, the compact dX0 side layer) -- what the combined pack
+    launch of the forward pass needs (fused_ops.rc2_pack)."""
+    L = [dict(W=ref_w[i].detach()) for i in range(n_ref - 2, 0, -1)]
+    L.append(dict(W=V0p[:, rw:], side=True))
+    L.append(dict(W=ref_w[0].detach()[:, :rw]))
+    L += [dict(W=rgb_w[i].detach()) for i in range(n_rgb - 1, 0, -1)]
+    if W0c is not None and W0c.shape[1] <= 64:
+        L.append(dict(W=W0c, side=True))
+    return L
+
+
 def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts_rgb, acts_ref,
                  gw_rgb, gb_rgb, gw_ref, gb_ref, cs, gV0p=None, rgb_b=None):
     """FGS_MLP=rc: every 256-wide data gradient of the two MLPs in ONE register-resident launch (fgs_mlp_rc_chain on the
@@ -164,7 +177,7 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
         layers.append(dict(W=W0c, out=dX0, n_store=W0c.shape[1], side=True))
         flop_side += 2.0 * M * rw * run.dx0_cols[2]
         run.dx0_compact = True
-        fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=2)
+        fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=2, prepacked=S.get('rc2_token'))
     else:
         fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=form)
         dX0 = None
@@ -339,7 +352,12 @@ class _FusedFine(torch.autograd.Function):
             if collapse:
                 flop_fwd -= 2.0 * M * rw * rgb_w[-1].shape[1]
             rc_form = 2 if (_rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and not collapse) else 1
-            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run), form=rc_form)
+            rc2_token = None
+            if rc_form == 2 and any(ctx.needs_input_grad):
+                # the weight images of BOTH chains of this step in one launch, here (the backward chain then starts without one)
+                bwd_w = _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c)
+                rc2_token = fo.rc2_pack(layers, False, ldx0, bwd_w, True, fw, device=dev)
+            fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run), form=rc_form, prepacked=rc2_token)
         elif one_launch:
             layers = []
             for i in range(n_rgb):       # the last rgbnet layer writes Z[:, :rw] (no ReLU); Z[:, rw:] holds the reflect PE
@@ -403,6 +421,7 @@ class _FusedFine(torch.autograd.Function):
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
                                    acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, WT=WT, relu_bits=relu_bits,
                                    Wc_full=(Wc_full if use_rc else None), rc_form=(rc_form if use_rc else None),
+                                   rc2_token=(rc2_token if use_rc else None),
                                    pre_rgb=pre_rgb, pre_sig=pre_sig,
                                    alphainv_last=alphainv_last, k0_strides=(ksC, ksX, ksY, ksZ)))
         run.extras = dict(step_id=step_id, rec_idx=rec_idx, normal_marched=normal_marched, depth=depth,

@@ -205,14 +205,12 @@ def rc_mask_bits(M: int, device) -> torch.Tensor:
     return torch.empty(((M + 31) // 32 + 4) * 64 * 4, dtype=torch.int32, device=device)
 
 
-def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None,
-             rows_dev=None, form: int = 1) -> None:
-    """One-launch MLP chain.  form 1: register-resident activations (include/fgs_hip.h fgs_mlp_rc_chain); form 2: the waves split
-    the features, the slab's activations in LDS (fgs_mlp_rc2_chain: width 256 only, no round quantisation, `side` layers).
-    `layers`: list of dicts with W (the nn.Linear weight [n_out, >= n_in], any leading dimension) and optional n_in (default
-    W.shape[1]), bias, relu, mask_bits (int32 buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext
-    ([M, >= ext_cols] view) / ext_cols, side (form 2)."""
-    import ctypes
+# Bumped by MaskedAdam whenever it updates parameters: a weight image packed under an older epoch is stale (rc2_pack / rc_chain
+# `prepacked`).  (Writes to the weights that bypass the optimizer between a forward pass and its backward pass are not seen.)
+WEIGHTS_EPOCH = [0]
+
+
+def _rc_layer_array(layers, form: int):
     from ._lib import Rc2Layer, RcLayer
     n = len(layers)
     arr = ((Rc2Layer if form == 2 else RcLayer) * n)()
@@ -230,20 +228,76 @@ def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, f
         arr[i].ext_cols = int(l.get('ext_cols', 0 if ext is None else ext.shape[1]))
         if form == 2:
             arr[i].side = int(bool(l.get('side', False)))
+    return arr
+
+
+def _rc_image_ws(arr, n, backward: bool, form: int, device):
+    import ctypes
     image_floats = lib().fgs_mlp_rc2_image_floats if form == 2 else lib().fgs_mlp_rc_image_floats
     need = int(image_floats(int(backward), n, ctypes.cast(arr, ctypes.c_void_p)))
     if need < 0:
         raise RuntimeError("rc_chain: bad layer list")
-    key = (in0.device.index, stream(), bool(backward), form)
+    key = (device.index, stream(), bool(backward), form)
     ws = _RC_IMAGES.get(key)
     if ws is None or ws.numel() < need:
-        ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=in0.device)
+        ws = _RC_IMAGES[key] = torch.empty(need, dtype=torch.float32, device=device)
+    return ws
+
+
+def _rc_weight_sig(layers):
+    """What a packed image depends on: the weight views (address, pitch, shape) and roles of the layers, in order."""
+    return tuple((l['W'].data_ptr(), l['W'].stride(0), tuple(l['W'].shape), int(l.get('n_in', l['W'].shape[1])),
+                  bool(l.get('side', False)), int(l.get('ext_cols', 0 if l.get('ext') is None else l['ext'].shape[1])))
+                 for l in layers)
+
+
+def rc2_pack(layers_a, backward_a: bool, in0_cols_a: int, layers_b=None, backward_b: bool = True, in0_cols_b: int = 256,
+             device=None):
+    """The weight images of one or two form-2 chains in ONE launch (fgs_mlp_rc2_pack); returns a token for rc_chain(prepacked=...):
+    the chains then skip their own pack launches while the token is current (same workspaces, same weight views, no optimizer
+    update since)."""
+    import ctypes
+    arr_a = _rc_layer_array(layers_a, 2)
+    ws_a = _rc_image_ws(arr_a, len(layers_a), backward_a, 2, device)
+    arr_b = ws_b = None
+    if layers_b:
+        arr_b = _rc_layer_array(layers_b, 2)
+        ws_b = _rc_image_ws(arr_b, len(layers_b), backward_b, 2, device)
+    call("fgs_mlp_rc2_pack", int(backward_a), len(layers_a), ctypes.cast(arr_a, ctypes.c_void_p), int(in0_cols_a), ptr(ws_a),
+         ws_a.numel(), int(backward_b), 0 if not layers_b else len(layers_b),
+         None if arr_b is None else ctypes.cast(arr_b, ctypes.c_void_p), int(in0_cols_b), ptr(ws_b),
+         0 if ws_b is None else ws_b.numel(), stream())
+    sig, ws = {bool(backward_a): _rc_weight_sig(layers_a)}, {bool(backward_a): ws_a}
+    if layers_b:
+        sig[bool(backward_b)] = _rc_weight_sig(layers_b)
+        ws[bool(backward_b)] = ws_b
+    return dict(epoch=WEIGHTS_EPOCH[0], ws=ws, sig=sig)
+
+
+def rc_chain(backward: bool, M: int, in0: torch.Tensor, in0_cols: int, layers, flop: float = 0.0, label: str = None,
+             rows_dev=None, form: int = 1, prepacked=None) -> None:
+    """One-launch MLP chain.  form 1: register-resident activations (include/fgs_hip.h fgs_mlp_rc_chain); form 2: the waves split
+    the features, the slab's activations in LDS (fgs_mlp_rc2_chain: widths 256 / 192 / 128, no round quantisation, `side` layers).
+    `layers`: list of dicts with W (the nn.Linear weight [n_out, >= n_in], any leading dimension) and optional n_in (default
+    W.shape[1]), bias, relu, mask_bits (int32 buffer from rc_mask_bits), out ([M, >= n_store] row-major) / n_store, ext
+    ([M, >= ext_cols] view) / ext_cols, side (form 2).  `prepacked`: rc2_pack's token."""
+    import ctypes
+    n = len(layers)
+    arr = _rc_layer_array(layers, form)
+    ws = _rc_image_ws(arr, n, backward, form, in0.device)
+    # valid while no optimizer update happened since, the workspace is the one the pack filled and the weight views are the same
+    pre = int(form == 2 and prepacked is not None and prepacked['epoch'] == WEIGHTS_EPOCH[0]
+              and prepacked['ws'].get(bool(backward)) is ws and prepacked['sig'].get(bool(backward)) == _rc_weight_sig(layers))
     kern, pack = ("k_mlp_rc2", "k_rc2_pack") if form == 2 else ("k_mlp_rc", "k_rc_pack")
     label = label or (f"{kern} backward chain (+ {pack})" if backward else f"{kern} forward chain (+ {pack})")
     d = dyn(row_count=rows_dev, stamps=_stamp_arg(label, flop, "rc"))
-    _timed(label, flop,
-           lambda: call("fgs_mlp_rc2_chain" if form == 2 else "fgs_mlp_rc_chain", int(backward), M, n,
-                        ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0), in0_cols, ptr(ws), ws.numel(), d, stream()))
+    if form == 2:
+        fn = lambda: call("fgs_mlp_rc2_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),      # noqa: E731
+                          in0_cols, ptr(ws), ws.numel(), pre, d, stream())
+    else:
+        fn = lambda: call("fgs_mlp_rc_chain", int(backward), M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(in0), in0.stride(0),       # noqa: E731
+                          in0_cols, ptr(ws), ws.numel(), d, stream())
+    _timed(label, flop, fn)
 
 
 def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:

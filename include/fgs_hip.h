@@ -36,8 +36,8 @@ typedef void *fgs_stream_t;
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
  * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
- * 9 = fgs_step_scalars_tick2. */
-#define FGS_ABI_VERSION 9
+ * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked). */
+#define FGS_ABI_VERSION 10
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -386,7 +386,14 @@ typedef struct fgs_rc2_layer {
 } fgs_rc2_layer_t;
 int64_t fgs_mlp_rc2_image_floats(int backward, int n_layers, const fgs_rc2_layer_t *layers);
 int fgs_mlp_rc2_chain(int backward, int64_t M, int n_layers, const fgs_rc2_layer_t *layers, const float *in0, int64_t ld_in0,
-                      int in0_cols, float *image_ws, int64_t image_ws_floats, const fgs_dyn_t *dyn, fgs_stream_t stream);
+                      int in0_cols, float *image_ws, int64_t image_ws_floats, int prepacked, const fgs_dyn_t *dyn,
+                      fgs_stream_t stream);
+/* The weight images of TWO chains -- a step's forward and backward chain; n_layers_b = 0: one -- in ONE launch, for
+ * fgs_mlp_rc2_chain(..., prepacked = 1, ...) calls with the same layer lists while the weights are unchanged.  Only W / ldw /
+ * n_out / n_in / side / ext_cols of the layers are read. */
+int fgs_mlp_rc2_pack(int backward_a, int n_layers_a, const fgs_rc2_layer_t *layers_a, int in0_cols_a, float *image_ws_a,
+                     int64_t image_ws_floats_a, int backward_b, int n_layers_b, const fgs_rc2_layer_t *layers_b, int in0_cols_b,
+                     float *image_ws_b, int64_t image_ws_floats_b, fgs_stream_t stream);
 /* Every weight and bias gradient of the MLPs in ONE launch (csrc/mlp_wgrad.hip): for each item
  *   dW[n_out, n_in] += dY[M, n_out]^T . X[M, n_in]      dbias[n_out] += column sums of dY   (dbias may be NULL)
  * with fp32 atomics (zero-initialise dW / dbias).  The samples are split over the chip, a workgroup holds a 256 x 256 block
