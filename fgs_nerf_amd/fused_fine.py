@@ -108,15 +108,17 @@ def _backward_chain(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, a
     return dZ, dX0
 
 
-def _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c):
+def _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c, W0c_views=None):
     """The layer list of the form-2 backward chain as far as its WEIGHTS go (the order _backward_rc issues: refnet main layers,
     the reflection-encoding side layer, refnet layer 0, rgbnet main layers, the compact dX0 side layer) -- what the combined pack
     launch of the forward pass needs (fused_ops.rc2_pack)."""
     L = [dict(W=ref_w[i].detach()) for i in range(n_ref - 2, 0, -1)]
-    L.append(dict(W=V0p[:, rw:], side=True))
+    L.append(dict(W=(V0p if V0p is not None else ref_w[0].detach())[:, rw:], side=True))
     L.append(dict(W=ref_w[0].detach()[:, :rw]))
     L += [dict(W=rgb_w[i].detach()) for i in range(n_rgb - 1, 0, -1)]
-    if W0c is not None and W0c.shape[1] <= 64:
+    if W0c_views is not None:
+        L += [dict(W=v, side=True) for v in W0c_views]
+    elif W0c is not None and W0c.shape[1] <= 64:
         L.append(dict(W=W0c, side=True))
     return L
 
@@ -150,7 +152,8 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     if form == 2:
         # side layer: the reflection-encoding columns of dZ = dY_ref[0] . V0[:, rw:], from the carried gradient BEFORE the next
         # main layer replaces it (the first form leaves this product and dX0 to k_gemm launches behind the chain)
-        layers.append(dict(W=S['V0p'][:, rw:], out=dZ[:, rw:], n_store=ldz - rw, side=True))
+        V0_enc = (S['V0p'] if S.get('V0p') is not None else ref_w[0].detach())[:, rw:]
+        layers.append(dict(W=V0_enc, out=dZ[:, rw:], n_store=ldz - rw, side=True))
         flop_side += 2.0 * M * fw * (z_cols - rw)
     dY_rgb = [None] * n_rgb                  # dY_rgb[i]: gradient w.r.t. the output of rgbnet layer i
     if collapse:
@@ -170,7 +173,17 @@ def _backward_rc(run, dY, M, rw, fw, ldz, ldx0, n_rgb, n_ref, rgb_w, ref_w, acts
     flop_chain = 2.0 * M * (fw * fw * (n_ref - 2) + fw * rw + rw * rw * (n_rgb - 1))
     if collapse:
         flop_chain -= 2.0 * M * rw * rw
-    if form == 2 and S.get('W0c') is not None and S['W0c'].shape[1] <= 64:
+    if form == 2 and S.get('W0c_views') is not None:
+        # ... and dX0 in compact form (fgs_dyn_t.dx0_compact) as the chain's last two side layers: the k0 columns and the columns
+        # behind the encodings of the fixed ray inputs, straight from the first rgbnet layer's weight
+        va, vb = S['W0c_views']
+        dX0 = torch.empty(M, (va.shape[1] + vb.shape[1] + 3) // 4 * 4, dtype=F32, device=dev)
+        layers.append(dict(W=va, out=dX0, n_store=va.shape[1], side=True))
+        layers.append(dict(W=vb, out=dX0[:, va.shape[1]:], n_store=vb.shape[1], side=True))
+        flop_side += 2.0 * M * rw * run.dx0_cols[2]
+        run.dx0_compact = True
+        fo.rc_chain(True, M, dY, fw, layers, flop=flop_chain + flop_side, rows_dev=_rows(run), form=2, prepacked=S.get('rc2_token'))
+    elif form == 2 and S.get('W0c') is not None and S['W0c'].shape[1] <= 64:
         # ... and dX0 in compact form (fgs_dyn_t.dx0_compact) as the chain's last (side) layer
         W0c = S['W0c']
         dX0 = torch.empty(M, W0c.shape[1], dtype=F32, device=dev)
@@ -270,7 +283,16 @@ class _FusedFine(torch.autograd.Function):
         token = None if sf else _count_begin(run, ws['surv_off'], N)
         # K-padded first-layer weights of both MLPs, one launch (F.pad: a fill + a copy launch per matrix)
         W0c = None
-        if _DX0_COMPACT and _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and any(ctx.needs_input_grad):
+        W0c_views = None
+        want_rc2 = _rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and not (_MLP_COLLAPSE and n_rgb >= 2 and n_ref >= 2)
+        if want_rc2 and _DX0_COMPACT and run.dx0_cols[0] % 4 == 0 and (run.dx0_cols[2] - run.dx0_cols[0]) % 4 == 0:
+            # the feature-split chains read the parameters themselves (their pack launch gathers element by element: no pitch or
+            # alignment to provide), the compact dX0 as two side layers over column ranges of the first rgbnet layer: no copies
+            k0d, gap, cw = run.dx0_cols
+            W0 = rgb_w[0].detach()
+            W0c_views = (W0[:, :k0d], W0[:, k0d + gap:])
+            W0p = V0p = None
+        elif _DX0_COMPACT and _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and any(ctx.needs_input_grad):
             # ... and, in the same launch, the first rgbnet layer's weights WITHOUT the columns of the xyz / view-direction
             # encodings: the backward pass needs d loss / d X0 only for the k0, sdf, tap and gradient columns (12 + 40 of 106)
             k0d, gap, cw = run.dx0_cols
@@ -316,6 +338,9 @@ class _FusedFine(torch.autograd.Function):
              ptr(X0), ptr(Z), ptr(normal), dyn(row_count=_rows(run)), st)
         # 4. MLPs
         use_rc = _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and M > 0
+        if V0p is None and not use_rc:       # (no survivors at all: the fallback products below take the padded copies)
+            W0p, V0p = fo.pad_cols_multi([rgb_w[0].detach(), ref_w[0].detach()], [ldx0, ldz])
+            W0c_views = None
         one_launch = (not use_rc and _MLP_FWD_ONE_LAUNCH and rw == 256 and fw == 256 and ldx0 <= 128 and 0 < ldz - rw <= 64 and
                       n_rgb + n_ref - 1 <= 8)
         grp = _gemm_group("forward chain (" + ("k_mlp_rc: register-resident, all layers in one launch" if use_rc else
@@ -355,7 +380,7 @@ class _FusedFine(torch.autograd.Function):
             rc2_token = None
             if rc_form == 2 and any(ctx.needs_input_grad):
                 # the weight images of BOTH chains of this step in one launch, here (the backward chain then starts without one)
-                bwd_w = _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c)
+                bwd_w = _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c, W0c_views)
                 rc2_token = fo.rc2_pack(layers, False, ldx0, bwd_w, True, fw, device=dev)
             fo.rc_chain(False, M, X0, ldx0, layers, flop=flop_fwd, rows_dev=_rows(run), form=rc_form, prepacked=rc2_token)
         elif one_launch:
@@ -419,7 +444,7 @@ class _FusedFine(torch.autograd.Function):
         # -> run -> output is a cycle through C++ that Python's collector cannot see (0.3 GB leaked per step).  Keep
         # detached aliases (same storage, no grad_fn) instead.
         run.saved = _detached(dict(ray_id=ray_id, pts=pts, sdf=sdf, gradient=gradient, weights=weights, rgb=rgb, X0=X0, Z=Z,
-                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, WT=WT, relu_bits=relu_bits,
+                                   acts_rgb=acts_rgb, acts_ref=acts_ref, W0p=W0p, V0p=V0p, W0c=W0c, W0c_views=W0c_views, WT=WT, relu_bits=relu_bits,
                                    Wc_full=(Wc_full if use_rc else None), rc_form=(rc_form if use_rc else None),
                                    rc2_token=(rc2_token if use_rc else None),
                                    pre_rgb=pre_rgb, pre_sig=pre_sig,

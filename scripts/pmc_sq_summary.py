@@ -13,7 +13,8 @@ busy / (4 SIMDs x CUs in use x kernel cycles).  Kernel cycles come from the UN-p
 import csv, glob, json, sys
 from collections import defaultdict
 
-KEYS = (("k_mlp_rc<false", "k_mlp_rc forward chain"), ("k_mlp_rc<true", "k_mlp_rc backward chain"), ("k_mlp_wgrad", "k_mlp_wgrad"))
+KEYS = (("k_mlp_rc2<false", "k_mlp_rc2 forward chain"), ("k_mlp_rc2<true", "k_mlp_rc2 backward chain"),
+        ("k_mlp_rc<false", "k_mlp_rc forward chain"), ("k_mlp_rc<true", "k_mlp_rc backward chain"), ("k_mlp_wgrad", "k_mlp_wgrad"))
 CLOCK_GHZ = 2.39
 
 
