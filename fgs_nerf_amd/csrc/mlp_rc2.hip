@@ -43,7 +43,7 @@ struct R2Layer {
   int64_t img;                 // float offset of the layer's fragment image
   int k8x, k8e;                // k-groups over X (the carried input) and over E (appended columns); both multiples of 4
   int n_ft;                    // output feature tiles: 8 (main) or 1..2 (side)
-  int side;
+  int side;                    // 0: main, 1: side (plain), 2: side + bias + sigmoid, the first n_store <= 4 columns stored one by one
   int relu;
   const float *bias;           // forward main layers (may be null)
   unsigned *mask_w;            // forward + relu: sign bits of the output, [tile][wave][lane] words
@@ -524,6 +524,24 @@ __device__ __forceinline__ void r2_slab(const R2Args &a, float *X, float *E, R2W
       r2_prefetch<NFT>(a, l + 1, w, pre);
       __builtin_amdgcn_sched_barrier(0);
       const int n_store = __builtin_amdgcn_readfirstlane(L.n_store);
+      if (__builtin_amdgcn_readfirstlane(L.side) == 2) {
+        // the 256 -> 3 output head (model/nerf.py:884): rgb = sigmoid(h . V^T + c).  Features 0 .. 3 of the tile are registers
+        // 0 .. 3 of the lanes with h = 0: a lane stores its sample's n_store values, 12 contiguous bytes per lane
+        const float4 bq = L.bias ? *reinterpret_cast<const float4 *>(L.bias) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          if (n < ns) {
+            const int64_t gr = row0 + (n0 + n) * 32 + w.j;
+            if (gr < w.M && w.h == 0) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (c < n_store) L.out[gr * L.ldo + c] = 1.f / (1.f + expf(-(acc[0][n][c] + bv[c])));
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         if (n < ns) {
@@ -643,7 +661,11 @@ int r2_build(const char *who, int backward, int64_t M, int n_layers, const fgs_r
                     (ext_cols == 0 || (U.ext && !a.ext && carried == 256 && (U.ld_ext % 4) == 0 && r2_aligned16(U.ext) && !U.side)),
                 FGS_E_INVALID, "%s: layer %d: appended columns need a full 256-column carried input, <= %d of them, "
                                "multiple of 4, aligned, at most one such layer", who, l, R2_PE);
-    if (U.side)
+    if (U.side == 2)
+      FGS_REQUIRE(!backward && rows <= 4 && U.out && U.n_store >= 1 && U.n_store <= rows && U.ldo >= U.n_store && !U.relu &&
+                      !U.mask_bits && (!U.bias || r2_aligned16(U.bias)), FGS_E_INVALID,
+                  "%s: head layer %d: forward, <= 4 output columns, an output, 16-byte aligned bias", who, l);
+    else if (U.side)
       FGS_REQUIRE(rows <= 64 && U.out && !U.bias && !U.relu && !U.mask_bits, FGS_E_INVALID,
                   "%s: side layer %d: <= 64 output columns, an output, no bias / activation", who, l);
     else
@@ -652,17 +674,18 @@ int r2_build(const char *who, int backward, int64_t M, int n_layers, const fgs_r
                   "%s: layer %d produces %d columns (stores %d): the main layers of one chain are all 256, "
                   "192 or 128 wide, their output is stored whole, appended columns need 256", who, l, rows, U.n_store);
     if (!U.side) main_rows = rows;
-    FGS_REQUIRE(!U.out || ((U.ldo % 4) == 0 && r2_aligned16(U.out) && (U.n_store % 4) == 0 && U.n_store <= (U.side ? 64 : 256) &&
-                           U.ldo >= U.n_store), FGS_E_INVALID, "%s: layer %d: bad output", who, l);
+    FGS_REQUIRE(!U.out || U.side == 2 || ((U.ldo % 4) == 0 && r2_aligned16(U.out) && (U.n_store % 4) == 0 &&
+                                           U.n_store <= (U.side ? 64 : 256) && U.ldo >= U.n_store),
+                FGS_E_INVALID, "%s: layer %d: bad output", who, l);
     FGS_REQUIRE((!U.bias || r2_aligned16(U.bias)) && (!U.mask_bits || (reinterpret_cast<uintptr_t>(U.mask_bits) & 3) == 0),
                 FGS_E_INVALID, "%s: layer %d: bias must be 16-byte aligned", who, l);
     R2Layer &L = a.L[l];
     r2_geometry(backward, U, L.n_ft, L.k8x, L.k8e);
     FGS_REQUIRE(L.n_ft >= 1 && L.k8x * 8 <= 256, FGS_E_RANGE, "%s: layer %d: reduction over %d columns", who, l, k);
     L.img = base;
-    L.side = U.side ? 1 : 0;
+    L.side = U.side == 2 ? 2 : (U.side ? 1 : 0);
     L.relu = backward ? 0 : U.relu;
-    L.bias = backward ? nullptr : U.bias;
+    L.bias = backward ? nullptr : U.bias;      // (main layers and the head)
     L.mask_w = (!backward && U.relu) ? reinterpret_cast<unsigned *>(U.mask_bits) : nullptr;
     L.mask_r = backward ? reinterpret_cast<const unsigned *>(U.mask_bits) : nullptr;
     L.out = U.out; L.ldo = U.ldo; L.n_store = U.n_store;
@@ -738,7 +761,7 @@ FGS_API int fgs_mlp_rc2_pack(int backward_a, int n_layers_a, const fgs_rc2_layer
     fgs_rc2_layer_t tmp[R2_MAXL];
     for (int l = 0; l < nl[c]; ++l) {
       tmp[l] = ls[c][l];
-      tmp[l].out = ws[c]; tmp[l].ldo = 256; tmp[l].n_store = tmp[l].side ? 4 : (bw[c] ? tmp[l].n_in : tmp[l].n_out);
+      tmp[l].out = ws[c]; tmp[l].ldo = 256; tmp[l].n_store = tmp[l].side == 2 ? 1 : tmp[l].side ? 4 : (bw[c] ? tmp[l].n_in : tmp[l].n_out);
       tmp[l].bias = nullptr; tmp[l].mask_bits = nullptr; tmp[l].relu = 0;
       if (tmp[l].ext_cols && !tmp[l].ext) tmp[l].ext = ws[c];
       if (tmp[l].ext_cols && !tmp[l].ld_ext) tmp[l].ld_ext = 256;

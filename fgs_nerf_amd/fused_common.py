@@ -233,6 +233,12 @@ def _linear_bwd(dY, W, X, dX, dW, M, n_out, k_in, mask=None, colsum=None, logica
 _MLP_FORM = int(os.environ.get("FGS_MLP_FORM", "2"))
 
 
+# FGS_RC2_HEAD=1: the 256 -> 3 output head rides in the form-2 forward chain as its last side layer (`side` = 2: bias, sigmoid)
+# instead of the k_head_fwd launch.  Measured, round 4: the chain grows by 11 us (one feature tile still walks all 32 k-groups of
+# both slabs), k_head_fwd and its launch were 17: 1.6566 against 1.6569 ms per step -- nothing; default off.
+_RC2_HEAD = os.environ.get("FGS_RC2_HEAD", "0") == "1"
+
+
 def _rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) -> bool:
     """Shapes the feature-split chains cover: 256-wide trunks, <= 52 appended columns, <= 10 layers incl. the side layers."""
     return (_MLP_FORM == 2 and _rc_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and rw == 256 and fw == 256 and ldz - rw <= 52

@@ -349,6 +349,7 @@ class _FusedFine(torch.autograd.Function):
         acts_rgb = [X0] + [torch.empty(M, rw, dtype=F32, device=dev) for _ in range(n_rgb - 1)]   # input of each rgbnet layer
         acts_ref = [Z] + [torch.empty(M, fw, dtype=F32, device=dev) for _ in range(n_ref - 1)]    # input of each refnet layer
         relu_bits = None
+        rgb = None
         if use_rc:
             # ReLU sign bits of every hidden layer, 16 bytes per lane of each 32-sample group, one buffer for all layers
             per = fo.rc_mask_bits(M, dev).numel()
@@ -378,6 +379,12 @@ class _FusedFine(torch.autograd.Function):
                 flop_fwd -= 2.0 * M * rw * rgb_w[-1].shape[1]
             rc_form = 2 if (_rc2_eligible(rw, fw, ldx0, ldz, n_rgb, n_ref) and not collapse) else 1
             rc2_token = None
+            if rc_form == 2 and _RC2_HEAD and ref_w[-1].shape[0] <= 4:
+                # the 256 -> 3 output head + sigmoid as the chain's last (side) layer: no k_head_fwd launch, no re-read of the
+                # last hidden activation
+                rgb = torch.empty(M, ref_w[-1].shape[0], dtype=F32, device=dev)
+                layers.append(dict(W=ref_w[-1].detach(), bias=ref_b[-1].detach(), out=rgb, n_store=ref_w[-1].shape[0], side=2))
+                flop_fwd += 2.0 * M * fw * ref_w[-1].shape[0]
             if rc_form == 2 and any(ctx.needs_input_grad):
                 # the weight images of BOTH chains of this step in one launch, here (the backward chain then starts without one)
                 bwd_w = _rc2_bwd_weights(n_rgb, n_ref, rgb_w, ref_w, rw, V0p, W0c, W0c_views)
@@ -413,9 +420,10 @@ class _FusedFine(torch.autograd.Function):
                 a = out
         a = acts_ref[n_ref - 1]
         grp.__exit__()
-        rgb = torch.empty(M, 3, dtype=F32, device=dev)
-        call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb),
-             dyn(row_count=_rows(run)), st)
+        if rgb is None:
+            rgb = torch.empty(M, 3, dtype=F32, device=dev)
+            call("fgs_head_fwd", ptr(a), a.stride(0), fw, M, ptr(ref_w[-1].detach()), ptr(ref_b[-1].detach()), ptr(rgb),
+                 dyn(row_count=_rows(run)), st)
         # 5. compositing
         rgb_marched = torch.empty(N, 3, dtype=F32, device=dev)
         sigmoid_rgb = torch.empty(N, 3, dtype=F32, device=dev)

@@ -227,7 +227,7 @@ def _rc_layer_array(layers, form: int):
         arr[i].ext, arr[i].ld_ext = ptr(ext), (0 if ext is None else ext.stride(0))
         arr[i].ext_cols = int(l.get('ext_cols', 0 if ext is None else ext.shape[1]))
         if form == 2:
-            arr[i].side = int(bool(l.get('side', False)))
+            arr[i].side = int(l.get('side', 0))            # (True / 1: side layer; 2: the output head)
     return arr
 
 
@@ -247,7 +247,7 @@ def _rc_image_ws(arr, n, backward: bool, form: int, device):
 def _rc_weight_sig(layers):
     """What a packed image depends on: the weight views (address, pitch, shape) and roles of the layers, in order."""
     return tuple((l['W'].data_ptr(), l['W'].stride(0), tuple(l['W'].shape), int(l.get('n_in', l['W'].shape[1])),
-                  bool(l.get('side', False)), int(l.get('ext_cols', 0 if l.get('ext') is None else l['ext'].shape[1])))
+                  int(l.get('side', 0)), int(l.get('ext_cols', 0 if l.get('ext') is None else l['ext'].shape[1])))
                  for l in layers)
 
 

@@ -372,7 +372,8 @@ int fgs_mlp_rc_chain(int backward, int64_t M, int n_layers, const fgs_rc_layer_t
  * bench's 57 K survivors).  Weights go from L2 straight into matrix-core operand registers in fragment order (no LDS ring).
  * Arguments as fgs_mlp_rc_chain, plus SIDE layers: `side` != 0 marks a narrow product (<= 64 output columns, no bias / activation)
  * of the CURRENT carried input that is written to `out` only and leaves the carried input alone -- the backward chain's
- * reflection-encoding columns of dZ and the compact dX0, which the first form left to fgs_gemm_f32.  Main layers store all 256
+ * reflection-encoding columns of dZ and the compact dX0, which the first form left to fgs_gemm_f32.  `side` == 2 (forward): the
+ * 256 -> 3 output head -- bias, sigmoid, the first n_store <= 4 columns stored one by one (any ldo).  Main layers store all 256
  * output columns (n_store = 256) or none.  mask_bits: one 32-bit word per (32-sample tile, wave, lane), [ceil(M / 32)][4][64] --
  * the same size as the first form's buffer, another layout (private to the two chains of one step).  Deterministic; not
  * bit-identical to the first form (another k order). */
