@@ -79,9 +79,12 @@ def train_step(model, opt, averager, batch, n_rays_global):
     from fgs_nerf_amd import synth
     from fgs_nerf_amd.losses import fused_render_losses
     ro, rd, vd, target = batch
+    loss_cfg = synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS
+    from fgs_nerf_amd.fused import set_loss_spec
+    set_loss_spec(model, target, loss_cfg)        # (fine stage: compositing + losses + their gradients become one launch)
     res = model(ro, rd, vd, global_step=GLOBAL_STEP, **synth.RENDER_KWARGS)
-    # nerf_training.py:308-327; two HIP launches each way on the fused path, plain torch on the composed path
-    loss = fused_render_losses(res, target, synth.FINE_LOSS if model.stage == 'fine' else synth.COARSE_LOSS, model)
+    # nerf_training.py:308-327
+    loss = fused_render_losses(res, target, loss_cfg, model)
     pts = res.get('survivor_pts') if hasattr(res, 'get') else None
     if pts is not None:   # every k0 gradient of this step comes from trilinear lookups at the survivors
         # (sync-free: `pts` has CAPACITY rows, the rows that count are behind a device-side counter)
@@ -89,7 +92,8 @@ def train_step(model, opt, averager, batch, n_rays_global):
     opt.zero_grad(set_to_none=True)
     seed = STEP_STATS.get("seed")
     if seed is None or seed.device != loss.device:
-        seed = STEP_STATS["seed"] = torch.ones((), dtype=torch.float32, device=loss.device)
+        from fgs_nerf_amd.losses import register_unit_seed
+        seed = STEP_STATS["seed"] = register_unit_seed(torch.ones((), dtype=torch.float32, device=loss.device))
     loss.backward(seed)             # (the gradient seed given: one fill launch less than autograd's implicit ones_like)
     averager.average()
     # fine stage: CUDA-side TV on the sdf grid only (weight_tv_k0 = 0), dense (nerf_training.py:353-371)

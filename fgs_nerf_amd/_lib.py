@@ -19,7 +19,7 @@ P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -88,6 +88,7 @@ _SIGNATURES = {
     "fgs_adam_upd_multi": [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P],
     "fgs_fine_loss_fwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, P],
     "fgs_fine_loss_bwd": [I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "fgs_fine_render_loss": [I64, I64, P, P, P, P, P, F32, F32, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, P, P, P],
     "fgs_feat_fine_fwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P],
     "fgs_feat_fine_bwd": [I64, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64,
                           P, P, P, P],

@@ -101,13 +101,14 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_fwd(LossArgs L, float *loss,
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) s += part[w];
+    // (agent-scope store, waited for, then the arrival: see k_render_loss for why there is no agent-scope fence)
     __hip_atomic_store(partials + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    is_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
   float v = 0.f;
   for (unsigned b = threadIdx.x; b < gridDim.x; b += FGS_BLOCK)
     v += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -179,6 +180,166 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_bwd(LossArgs L, const float 
   if (g_normal) loss_surv_bwd(L, i, go, g_normal, g_raw_rgb);
 }
 
+// ------------------------------------------------------------------------------------------------ fused compositing + losses
+// One launch for what a training step runs between its two MLP chains besides the 256 -> 3 head: per-ray compositing
+// (model/nerf.py:888-920; k_composite_fwd), the loss terms above (k_loss_fwd), their gradients (k_loss_bwd) and the compositing
+// backward (k_composite_bwd) -- five launches of a captured step, each of which costs ~5 us whatever it does.  One wave per ray,
+// two passes over the ray's survivors: (1) the weighted sums, from which the ray's pixel, its loss terms and d loss / d pixel
+// follow; (2) per survivor d loss / d (pre-sigmoid head output), d loss / d weight, the orientation term and its gradient w.r.t.
+// the normal.  The loss gradients assume d total / d loss = *seed (NULL: 1); the loss scalar is summed per wave, per block and
+// by the last block to arrive in a fixed order (as k_loss_fwd does): bit-reproducible, another order than the separate kernels'.
+struct RenderLossArgs {
+  int64_t N, M;
+  const int64_t *m_dev;
+  const int64_t *surv_off;                      // [N + 1]
+  const float *weights, *rgb, *normal;          // per survivor; rgb = sigmoid(head output)
+  const int64_t *step_id;                       // per survivor (depth) or null
+  const float *viewdirs, *target, *alphainv_last;      // per ray
+  const float *seed;
+  float bg, dist;
+  float w_main, w_rgbper, w_ent, w_ori, w_sig;
+  float *rgb_marched, *sigmoid_rgb, *pre_rgb, *pre_sig, *normal_marched, *depth;      // per ray
+  float *d_out, *d_w, *g_normal;                // per survivor
+  float *g_last, *g_rm;                         // per ray
+};
+
+__device__ __forceinline__ float rl_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(FGS_BLOCK) void k_render_loss(RenderLossArgs A, float *loss, float *partials, unsigned *counter) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + wv;
+  float ray_loss = 0.f;
+  if (ray < A.N) {
+    const int64_t s0 = fgs_uniform(A.surv_off[ray]), s1 = fgs_uniform(A.surv_off[ray + 1]);
+    // ---- pass 1: compositing sums (k_composite_fwd)
+    float acc[3] = {0.f, 0.f, 0.f}, sig[3] = {0.f, 0.f, 0.f}, nrm[3] = {0.f, 0.f, 0.f}, wsum = 0.f, dep = 0.f;
+    for (int64_t i = s0 + lane; i < s1; i += FGS_WAVE) {
+      const float w = A.weights[i];
+      wsum += w;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = A.rgb[3 * i + c];
+        acc[c] += w * v;
+        sig[c] += w * (1.f / (1.f + expf(-v)));
+        if (A.normal_marched) nrm[c] += w * A.normal[3 * i + c];
+      }
+      if (A.depth) dep += (w * (float)A.step_id[i]) * A.dist;
+    }
+    wsum = rl_wave_sum(wsum);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      acc[c] = rl_wave_sum(acc[c]);
+      sig[c] = rl_wave_sum(sig[c]);
+      if (A.normal_marched) nrm[c] = rl_wave_sum(nrm[c]);
+    }
+    if (A.depth) dep = rl_wave_sum(dep);
+    // ---- the ray: pixel, loss terms, d loss / d pixel (k_loss_fwd / k_loss_bwd, ray part)
+    const float go = A.seed ? *A.seed : 1.f;
+    const float bgterm = (1.f - wsum) * A.bg;
+    const float inv = 1.f / (float)(A.N * 3), inv2 = 2.f / (float)(A.N * 3);
+    float g1[3], g2[3], tg[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = acc[c] + bgterm, b = sig[c] + bgterm;
+      const float rm = fminf(fmaxf(a, 0.f), 1.f), sr = fminf(fmaxf(b, 0.f), 1.f);
+      tg[c] = A.target[3 * ray + c];
+      const float da = rm - tg[c], db = sr - tg[c];
+      ray_loss += A.w_main * (da * da) * inv + A.w_sig * (db * db) * inv;
+      const float grm = go * A.w_main * inv2 * da, gsr = go * A.w_sig * inv2 * db;
+      g1[c] = (a >= 0.f && a <= 1.f) ? grm : 0.f;        // clamp(0, 1) passes the gradient on the closed interval
+      g2[c] = (b >= 0.f && b <= 1.f) ? gsr : 0.f;
+      if (lane == 0) {
+        A.pre_rgb[3 * ray + c] = a; A.pre_sig[3 * ray + c] = b;
+        A.rgb_marched[3 * ray + c] = rm; A.sigmoid_rgb[3 * ray + c] = sr;
+        if (A.normal_marched) A.normal_marched[3 * ray + c] = nrm[c];
+        A.g_rm[3 * ray + c] = grm;
+      }
+    }
+    if (lane == 0) {
+      if (A.depth) A.depth[ray] = dep;
+      float gl = 0.f;
+      if (ray == A.N - 1 && A.w_ent > 0.f) {           // `alphainv_cum[..., -1]` on a 1-D tensor: ONE ray (nerf_training.py:316-319)
+        const float raw = A.alphainv_last[ray];
+        const float p = fminf(fmaxf(raw, 1e-6f), 1.f - 1e-6f);
+        ray_loss += A.w_ent * (-(p * logf(p) + (1.f - p) * logf(1.f - p)));
+        if (raw >= 1e-6f && raw <= 1.f - 1e-6f) gl = go * A.w_ent * (logf(1.f - raw) - logf(raw));
+      }
+      A.g_last[ray] = gl;
+    } else {
+      ray_loss = 0.f;                                    // (the ray's terms are counted once, by lane 0)
+    }
+    // ---- pass 2: per survivor (k_loss_fwd / k_loss_bwd survivor part, k_composite_bwd)
+    const float vd[3] = {A.viewdirs[3 * ray], A.viewdirs[3 * ray + 1], A.viewdirs[3 * ray + 2]};
+    for (int64_t i = s0 + lane; i < s1; i += FGS_WAVE) {
+      const float w = A.weights[i];
+      float gn[3] = {0.f, 0.f, 0.f};
+      if (A.w_ori > 0.f) {
+        const float d = -((A.normal[3 * i] * vd[0] + A.normal[3 * i + 1] * vd[1]) + A.normal[3 * i + 2] * vd[2]);
+        const float q = fminf(0.f, d);
+        ray_loss += A.w_ori * w * q * q;
+        if (d < 0.f) {
+          const float k = go * A.w_ori * w * 2.f * d;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gn[c] = k * (-vd[c]);
+        }
+      }
+      float dw = 0.f, se = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        A.g_normal[3 * i + c] = gn[c];
+        const float v = A.rgb[3 * i + c];
+        const float sg = 1.f / (1.f + expf(-v));
+        dw += v * g1[c] + sg * g2[c] - A.bg * (g1[c] + g2[c]);
+        float d_rgb = w * g1[c] + (w * g2[c]) * (sg * (1.f - sg));
+        if (A.w_rgbper > 0.f) {
+          const float e = v - tg[c];
+          se += e * e;
+          d_rgb += go * A.w_rgbper * w * 2.f * e / (float)A.N;
+        }
+        A.d_out[3 * i + c] = d_rgb * (v * (1.f - v));     // rgb = sigmoid(out)
+      }
+      if (A.w_rgbper > 0.f) ray_loss += A.w_rgbper * se * w / (float)A.N;
+      A.d_w[i] = dw;
+    }
+    ray_loss = rl_wave_sum(ray_loss);
+  }
+  // ---- the scalar: wave -> block -> the last block to arrive sums the blocks in a fixed order
+  __shared__ float part[FGS_BLOCK / FGS_WAVE];
+  __shared__ int is_last;
+  if (lane == 0) part[wv] = ray_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) s += part[w];
+    // The partial leaves as an agent-scope store (written through this XCD's L2) and is waited for before the arrival is
+    // counted: no agent-scope release fence here -- that one writes back EVERY dirty line of the L2 (the activations the
+    // kernels around this one leave there), once per workgroup: 1024 of them made this a 42 us launch.
+    __hip_atomic_store(partials + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float v = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += FGS_BLOCK)
+    v += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: not from this XCD's L2)
+  v = rl_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) part[wv] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) s += part[w];
+    loss[0] = s;
+    *counter = 0u;
+  }
+}
+
 int fill(LossArgs *L, int64_t N, int64_t M, const float *rgb_marched, const float *sigmoid_rgb, const float *target,
          const float *alphainv_cum, const float *weights, const float *normal, const float *raw_rgb,
          const int64_t *ray_id, const float *viewdirs, const float *w5, const fgs_dyn_t *dyn) {
@@ -240,5 +401,39 @@ FGS_API int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, co
   hipLaunchKernelGGL(k_loss_bwd, dim3(fgs_blocks(n_thr)), dim3(FGS_BLOCK), 0, st, L, grad_out, g_rgb_marched, g_sigmoid_rgb,
                      g_last, M > 0 ? g_normal : (float *)nullptr, g_raw_rgb);
   FGS_LAUNCH_OK("fgs_fine_loss_bwd");
+  return 0;
+}
+
+// The fused form of fgs_composite_fwd + fgs_fine_loss_fwd + fgs_fine_loss_bwd + fgs_composite_bwd (one launch; see k_render_loss).
+// rgb [M,3] = sigmoid(head output); surv_off [N + 1] the per-ray survivor offsets; seed_dev: device float d total / d loss (NULL: 1).
+// Outputs: the per-ray render (rgb_marched, sigmoid_rgb, pre_rgb, pre_sig; normal_marched / depth optional), loss_out, and the
+// gradients the backward pass starts from: d_out [M,3] (w.r.t. the head's pre-sigmoid output), d_w [M], g_normal [M,3],
+// g_last [N], g_rgb_marched [N,3] (d loss / d rgb_marched before the clamp gate: what fgs_fine_loss_bwd returns).
+// scratch: >= 1 + ceil(N / 4) floats whose first word is zero when first handed in (left zero).
+FGS_API int fgs_fine_render_loss(int64_t N, int64_t M, const int64_t *surv_off, const float *weights, const float *rgb,
+                                 const float *normal, const int64_t *step_id, float bg, float dist, const float *viewdirs,
+                                 const float *target, const float *alphainv_last, const float *weights5_host, const float *seed_dev,
+                                 float *rgb_marched, float *sigmoid_rgb, float *pre_rgb, float *pre_sig, float *normal_marched,
+                                 float *depth, float *loss_out, float *scratch, int64_t scratch_floats, float *d_out, float *d_w,
+                                 float *g_normal, float *g_last, float *g_rgb_marched, const fgs_dyn_t *dyn, fgs_stream_t stream) {
+  FGS_REQUIRE(N > 0 && N < ((int64_t)1 << 31) && M >= 0 && M < ((int64_t)1 << 31), FGS_E_RANGE, "fgs_fine_render_loss: N=%lld M=%lld",
+              (long long)N, (long long)M);
+  FGS_REQUIRE(surv_off && viewdirs && target && alphainv_last && weights5_host && rgb_marched && sigmoid_rgb && pre_rgb && pre_sig &&
+                  loss_out && scratch && g_last && g_rgb_marched && (M == 0 || (weights && rgb && normal && d_out && d_w && g_normal)) &&
+                  (!depth || step_id), FGS_E_INVALID, "fgs_fine_render_loss: null pointer");
+  const unsigned blocks = fgs_blocks(N * FGS_WAVE);
+  FGS_REQUIRE(scratch_floats >= (int64_t)blocks + 1, FGS_E_INVALID, "fgs_fine_render_loss: scratch %lld floats, need %u",
+              (long long)scratch_floats, blocks + 1);
+  RenderLossArgs A;
+  A.N = N; A.M = M; A.m_dev = fgs_dyn_rows(dyn); A.surv_off = surv_off; A.weights = weights; A.rgb = rgb; A.normal = normal;
+  A.step_id = step_id; A.viewdirs = viewdirs; A.target = target; A.alphainv_last = alphainv_last; A.seed = seed_dev; A.bg = bg;
+  A.dist = dist;
+  A.w_main = weights5_host[0]; A.w_rgbper = weights5_host[1]; A.w_ent = weights5_host[2]; A.w_ori = weights5_host[3];
+  A.w_sig = weights5_host[4];
+  A.rgb_marched = rgb_marched; A.sigmoid_rgb = sigmoid_rgb; A.pre_rgb = pre_rgb; A.pre_sig = pre_sig; A.normal_marched = normal_marched;
+  A.depth = depth; A.d_out = d_out; A.d_w = d_w; A.g_normal = g_normal; A.g_last = g_last; A.g_rm = g_rgb_marched;
+  hipLaunchKernelGGL(k_render_loss, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), A, loss_out, scratch + 1,
+                     reinterpret_cast<unsigned *>(scratch));
+  FGS_LAUNCH_OK("fgs_fine_render_loss");
   return 0;
 }

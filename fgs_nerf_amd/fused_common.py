@@ -557,6 +557,26 @@ def enable_early_update(model, optimizer, averager=None, inline: bool = False) -
         cache['opt_hook'] = optimizer.early_update
 
 
+# FGS_FUSED_LOSS=1 (default): a training step that announces its loss (set_loss_spec) gets compositing, the loss terms, their
+# gradients and the compositing backward in ONE launch (fgs_fine_render_loss) instead of five; 0: the separate launches
+_FUSED_LOSS = os.environ.get("FGS_FUSED_LOSS", "1") == "1"
+
+
+def set_loss_spec(model, target, loss_cfg, seed=None) -> None:
+    """Announce the loss the NEXT fused fine-stage forward passes of `model` will be differentiated through: `target` [N,3] and
+    the loss weights (the keys losses.fused_render_losses reads).  The forward pass then runs compositing + losses + their
+    gradients + the compositing backward as one launch and hands the result to losses.fused_render_losses(res, target, cfg),
+    which must be called with the same target tensor and weights (anything else: the ordinary path, nothing lost but the launch).
+    `seed`: the device scalar the caller will pass to loss.backward(seed) (read by the kernel; None: 1).  None as target: off."""
+    cache = model.__dict__.setdefault('_fused_cache', {})
+    if target is None or not _FUSED_LOSS:
+        cache.pop('loss_spec', None)
+        return
+    from .losses import _w5
+    w5 = _w5(loss_cfg)
+    cache['loss_spec'] = dict(target=target, w5=w5, w5_key=tuple(float(v) for v in w5), seed=seed)
+
+
 def disable_early_update(model, averager=None) -> None:
     model.__dict__.setdefault('_fused_cache', {}).pop('opt_hook', None)
     if averager is not None:

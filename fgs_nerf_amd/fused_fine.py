@@ -431,8 +431,28 @@ class _FusedFine(torch.autograd.Function):
         pre_sig = torch.empty(N, 3, dtype=F32, device=dev)
         normal_marched = torch.empty(N, 3, dtype=F32, device=dev) if run.render_grad else None
         depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
-        call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
-             ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+        spec = run.cache.get('loss_spec')
+        fused_loss = None
+        if (spec is not None and any(ctx.needs_input_grad) and M > 0 and spec['target'].shape == (N, 3) and spec['target'].is_cuda
+                and spec['target'].is_contiguous() and spec['target'].dtype == F32):
+            # compositing + the announced loss + its gradients + the compositing backward: one launch (fused_common.set_loss_spec)
+            from .losses import _loss_scratch
+            fl = dict(loss=torch.empty((), dtype=F32, device=dev), d_out=torch.empty(M, 3, dtype=F32, device=dev),
+                      d_w=torch.empty(M, dtype=F32, device=dev), g_normal=torch.empty(M, 3, dtype=F32, device=dev),
+                      g_last=torch.empty(N, dtype=F32, device=dev), g_rm=torch.empty(N, 3, dtype=F32, device=dev),
+                      target_ptr=spec['target'].data_ptr(), w5_key=spec['w5_key'], used=False,
+                      seed_ptr=None if spec['seed'] is None else spec['seed'].data_ptr())
+            scratch = _loss_scratch(dev, (N + 3) // 4 + 1)
+            call("fgs_fine_render_loss", N, M, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg,
+                 run.dist, ptr(run.viewdirs), ptr(spec['target']), ptr(alphainv_last), spec['w5'], ptr(spec['seed']),
+                 ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), ptr(fl['loss']),
+                 ptr(scratch), scratch.numel(), ptr(fl['d_out']), ptr(fl['d_w']), ptr(fl['g_normal']), ptr(fl['g_last']),
+                 ptr(fl['g_rm']), dyn(row_count=_rows(run)), st)
+            fused_loss = fl
+        else:
+            call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
+                 ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+        run.fused_loss = fused_loss
         # The big zero fills of the backward pass are issued HERE: when loss.backward() starts, the autograd engine needs
         # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
         run.pre = None
@@ -530,14 +550,20 @@ class _FusedFine(torch.autograd.Function):
 
         if M == 0:
             return _FusedFine._backward_empty(run, sdf_grid, k0_grid, mlp, rgb_w, ref_w, rw, fw, ldx0, ldz)
-        _seam(run, 'inputs', g_rgb_marched=g_rgb_marched, g_sigmoid_rgb=g_sigmoid_rgb, g_last=g_last, g_weights=g_weights,
-              g_raw_rgb=g_raw_rgb, g_normal=g_normal)
-        # 1. compositing
-        d_out = torch.empty(M, 3, dtype=F32, device=dev)
-        d_w = torch.empty(M, dtype=F32, device=dev)
-        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
-             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
-             dyn(row_count=_rows(run)), st)
+        fl = getattr(run, 'fused_loss', None)
+        if fl is not None and fl['used']:
+            # the forward pass already ran the loss and the compositing backward (fgs_fine_render_loss): the gradients that arrive
+            # here are the loss node's placeholders; the real ones are in the stash
+            d_out, d_w, g_normal, g_last = fl['d_out'], fl['d_w'], fl['g_normal'], fl['g_last']
+        else:
+            _seam(run, 'inputs', g_rgb_marched=g_rgb_marched, g_sigmoid_rgb=g_sigmoid_rgb, g_last=g_last, g_weights=g_weights,
+                  g_raw_rgb=g_raw_rgb, g_normal=g_normal)
+            # 1. compositing
+            d_out = torch.empty(M, 3, dtype=F32, device=dev)
+            d_w = torch.empty(M, dtype=F32, device=dev)
+            call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
+                 ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
+                 dyn(row_count=_rows(run)), st)
         _seam(run, 'composite', d_out=d_out, d_w=d_w)
 
         # gradient buffers of the MLP parameters (weights via split-K atomics -> zero-initialised): one zero fill for all of
@@ -778,6 +804,7 @@ def forward_fine(model, rays_o, rays_d, viewdirs, global_step=20000, **render_kw
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
+             '_fused_loss': getattr(run, 'fused_loss', None),
              'survivor_pts': run.saved['pts'],
              # sync-free mode: the per-survivor entries above have CAPACITY rows; the rows that count are the first
              # *survivor_count_ptr (a device int64), which consumers pass on as fgs_dyn_t.row_count

@@ -28,7 +28,8 @@ import torch
 from . import fused
 from . import fused_ops as fo
 from ._lib import call, lib, ptr, stream
-from .losses import fused_render_losses
+from .fused_common import set_loss_spec
+from .losses import fused_render_losses, register_unit_seed
 
 
 def variant_allows_defer(var) -> bool:
@@ -112,7 +113,7 @@ class CapturedFineStep:
         # ---- static inputs: one buffer, so that a batch that arrives packed as [4, n_rays, 3] is ONE copy
         self.inputs = torch.zeros(4, n_rays, 3, device=dev)
         self.rays_o, self.rays_d, self.viewdirs, self.target = self.inputs.unbind(0)
-        self._seed = torch.ones((), dtype=torch.float32, device=dev)
+        self._seed = register_unit_seed(torch.ones((), dtype=torch.float32, device=dev))
         self.graphs = [None] * len(self.variants)
         self.losses = [None] * len(self.variants)
         self._updated = [[] for _ in self.variants]
@@ -246,6 +247,7 @@ class CapturedFineStep:
             X, Y, Z = (int(v) for v in im.mask.shape)
             call("fgs_box_mask_fill", ptr(im.mask), X, Y, Z, ptr(self.scalars[self.inc_col:self.inc_col + 6]), stream())
         # (global_step only selects the training branch here: 1/s comes from the device scalars)
+        set_loss_spec(self.model, self.target, self.loss_cfg)
         res = self.model(self.rays_o, self.rays_d, self.viewdirs, global_step=1, **self.kw)
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
         var = self.variants[variant]

@@ -93,10 +93,48 @@ class _FineLoss(torch.autograd.Function):
         return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None, None
 
 
+UNIT_SEEDS = set()       # data_ptr()s of device scalars known to hold 1.0 (bench.py / CapturedFineStep pass them to loss.backward)
+
+
+def register_unit_seed(t: torch.Tensor) -> torch.Tensor:
+    UNIT_SEEDS.add(t.data_ptr())
+    return t
+
+
+class _FusedLossNode(torch.autograd.Function):
+    """The loss a fused forward pass already computed (fgs_fine_render_loss, fused_common.set_loss_spec): forward hands out the
+    scalar; backward marks the stash as the gradient source of the forward node and passes d loss / d rgb_marched on as a
+    placeholder (the forward node's backward reads the stash, not its incoming gradients).  A seed other than the one the kernel
+    assumed scales the stash (small torch launches: not a path of the captured step)."""
+
+    @staticmethod
+    def forward(ctx, rgb_marched, stash):
+        ctx.stash = stash
+        stash['used'] = True
+        return stash['loss'].detach()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        st = ctx.stash
+        assumed = st['seed_ptr']
+        if assumed is not None:
+            if grad_out.data_ptr() != assumed:
+                raise RuntimeError("fused loss: loss.backward() was given another seed than set_loss_spec announced")
+        elif grad_out.data_ptr() not in UNIT_SEEDS:
+            # the kernel assumed d total / d loss = 1 and this scalar is not known to be 1: scale what it left
+            for k in ('d_out', 'd_w', 'g_normal', 'g_last', 'g_rm'):
+                st[k].mul_(grad_out)
+        return st['g_rm'], None
+
+
 def fused_render_losses(res, target, cfg, model=None):
     """Same scalar and gradients as ``render_losses`` for a fused-path result dict (``res['ray_viewdirs']`` [N,3])."""
     rv = res.get('ray_viewdirs') if hasattr(res, 'get') else None
     if rv is None or not res['rgb_marched'].is_cuda:
         return render_losses(res, target, cfg, model)
+    fl = res.get('_fused_loss')
+    if fl is not None and not fl['used'] and fl['target_ptr'] == target.data_ptr() and fl['w5_key'] == tuple(float(v) for v in _w5(cfg)):
+        return _FusedLossNode.apply(res['rgb_marched'], fl)
     return _FineLoss.apply(res['rgb_marched'], res['sigmoid_rgb'], res['alphainv_cum'], res['normal'], res['raw_rgb'],
                            res['weights'], res['ray_id'], rv, target, _w5(cfg), res.get('survivor_count_ptr'))

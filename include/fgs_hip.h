@@ -36,8 +36,9 @@ typedef void *fgs_stream_t;
  * library (the Python binding: fgs_nerf_amd/_lib.py ABI_VERSION -> FgsError) instead of calling it with another argument
  * list.  1 = rounds 1-2 (never bumped, although the table changed); 3 = round 3; 4 = explicit fgs_dyn_t instead of the
  * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
- * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked). */
-#define FGS_ABI_VERSION 10
+ * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked);
+ * 11 = fgs_fine_render_loss. */
+#define FGS_ABI_VERSION 11
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -263,6 +264,19 @@ int fgs_fine_loss_bwd(int64_t N, int64_t M, const float *rgb_marched, const floa
                       const int64_t *ray_id, const float *viewdirs, const float *weights5_host, const float *grad_out,
                       float *g_rgb_marched, float *g_sigmoid_rgb, float *g_last, float *g_normal, float *g_raw_rgb,
                       const fgs_dyn_t *dyn, fgs_stream_t stream);
+/* fgs_composite_fwd + fgs_fine_loss_fwd + fgs_fine_loss_bwd + fgs_composite_bwd as ONE launch (csrc/losses.hip k_render_loss: one wave
+ * per ray, two passes over its survivors) -- what a training step runs between its two MLP chains besides the 256 -> 3 head
+ * (model/nerf.py:888-920, model/nerf_training.py:308-327).  rgb [M,3] = sigmoid(head output); surv_off [N + 1]; seed_dev: device
+ * float d total / d loss (NULL: 1).  Outputs: the per-ray render, loss_out, and the gradients the backward pass starts from:
+ * d_out [M,3] (w.r.t. the head's pre-sigmoid output), d_w [M], g_normal [M,3], g_last [N], g_rgb_marched [N,3].
+ * scratch: >= 1 + ceil(N / 4) floats, first word zero when first handed in (left zero).  The scalar is summed in a fixed order
+ * (bit-reproducible; another order than the separate launches'). */
+int fgs_fine_render_loss(int64_t N, int64_t M, const int64_t *surv_off, const float *weights, const float *rgb, const float *normal,
+                         const int64_t *step_id, float bg, float dist, const float *viewdirs, const float *target,
+                         const float *alphainv_last, const float *weights5_host, const float *seed_dev, float *rgb_marched,
+                         float *sigmoid_rgb, float *pre_rgb, float *pre_sig, float *normal_marched, float *depth, float *loss_out,
+                         float *scratch, int64_t scratch_floats, float *d_out, float *d_w, float *g_normal, float *g_last,
+                         float *g_rgb_marched, const fgs_dyn_t *dyn, fgs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Trilinear grid lookup -- replaces F.grid_sample(grid[1,C,X,Y,Z], ind_norm, 'bilinear',
