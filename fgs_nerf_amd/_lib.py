@@ -8,18 +8,18 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfgs_hip.so")
 
-P, F32, I64, I32 = c_void_p, c_float, c_int64, c_int
+P, F32, I64, I32, F64 = c_void_p, c_float, c_int64, c_int, c_double
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -80,8 +80,8 @@ _SIGNATURES = {
     "fgs_brick_gather_dev": [P, I32, I32, I32, I32, P, P, I64, P, P],
     "fgs_brick_scatter_dev": [P, I32, I32, I32, I32, P, P, I64, P, F32, P],
     "fgs_brick_count_guard": [P, I64, P, P, P, P],
-    "fgs_tv_loss_value": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P],
-    "fgs_tv_loss_grad": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, I32, P],
+    "fgs_tv_loss_value": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, I32, F64, P, P, I64, P, P, P, P],
+    "fgs_tv_loss_grad": [P, P, I64, I64, I64, I64, I64, I64, I64, I64, P, P, P, I32, P],
     "fgs_brick_masks_pts": [P, I64, P, P, I32, I32, I32, P, P, P],
     "fgs_adam_upd_voxels": [P, P, P, P, I32, I32, I32, I32, P, I32, F32, F32, F32, F32, P, P, P],
     "fgs_adam_upd_bricks": [P, P, P, P, I32, I32, I32, I32, P, P, I64, P, I32, F32, F32, F32, F32, P, P, P],
@@ -98,7 +98,7 @@ _SIGNATURES = {
     "fgs_composite_bwd": [I64, P, P, P, P, P, P, P, P, P, F32, P, P, P, P],
     "fgs_smooth3d_fwd": [P, I32, I32, I32, I32, P, P, P],
     "fgs_smooth3d_bwd": [P, I64, I32, I32, I32, I32, P, P, P, P],
-    "fgs_smooth_tv_loss": [P, I32, I32, I32, P, P, P, F32, P, P, P],
+    "fgs_smooth_tv_loss": [P, I32, I32, I32, P, P, P, F32, P, P, I64, P, P, P],
     "fgs_sdf_gradvol_fwd": [P, I32, I32, I32, F32, I32, P, P, P, P],
     "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, I32, P, I32, P],
     "fgs_march_coarse_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, P, P, P, F32, F32, F32,
@@ -167,7 +167,8 @@ def exported_symbols():
     """Every symbol include/fgs_hip.h declares (used by the CPU-side ABI test)."""
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
                                           "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats",
-                                          "fgs_mlp_rc2_image_floats", "fgs_adam_step_size"])
+                                          "fgs_mlp_rc2_image_floats", "fgs_adam_step_size", "fgs_smooth_tv_scratch_floats",
+                                          "fgs_tv_loss_scratch_doubles"])
 
 
 def lib() -> ctypes.CDLL:
@@ -200,6 +201,10 @@ def lib() -> ctypes.CDLL:
         handle.fgs_mlp_rc_image_floats.argtypes = [c_int, c_int, c_void_p]
         handle.fgs_mlp_rc2_image_floats.restype = c_int64
         handle.fgs_mlp_rc2_image_floats.argtypes = [c_int, c_int, c_void_p]
+        handle.fgs_smooth_tv_scratch_floats.restype = c_int64
+        handle.fgs_smooth_tv_scratch_floats.argtypes = [c_int, c_int, c_int]
+        handle.fgs_tv_loss_scratch_doubles.restype = c_int64
+        handle.fgs_tv_loss_scratch_doubles.argtypes = []
         handle.fgs_mc_num_blocks.restype = c_int64
         handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

@@ -35,7 +35,10 @@ struct TvEpi {
   const uint8_t *mask;      // [X,Y,Z] nonempty mask or null
   const float *inv_count;   // device scalar 1 / (number of elements in the mean)
   float weight;
-  float *loss;              // device scalar, accumulated atomically
+  float *loss;              // device scalar: weight * mean (+ *add_in), written by the workgroup that arrives last
+  const float *add_in;      // device scalar or null
+  float *partials;          // one float per workgroup
+  unsigned *counter;        // arrival counter (zero when handed in, left zero)
 };
 
 template <int K, bool REPL, int EPI = 0>
@@ -113,10 +116,37 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restr
         part = fmaf(m * e, e, part);
       }
   }
-  // block reduction of the loss contribution: wave shuffle, then one atomic per wave
+  // the loss: one partial per workgroup, summed in a fixed order by the workgroup that arrives last (until round 4: one float
+  // atomic per wave on ONE address -- 10 K of them were 125 of this launch's 142 us at 114^3, and the sum depended on their order)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-  if ((threadIdx.x & 63) == 0 && part != 0.f) atomicAdd(tv.loss, part * tv.weight * *tv.inv_count);
+  __shared__ float wpart[FGS_BLOCK / FGS_WAVE];
+  __shared__ int is_last;
+  if ((threadIdx.x & 63) == 0) wpart[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) t += wpart[w];
+    __hip_atomic_store(tv.partials + wg, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = fgs_arrive_is_last(tv.counter, n_wg) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double t = 0.0;
+  for (unsigned b = threadIdx.x; b < n_wg; b += FGS_BLOCK)
+    t += (double)__hip_atomic_load(tv.partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+  __shared__ double fpart[FGS_BLOCK / FGS_WAVE];
+  if ((threadIdx.x & 63) == 0) fpart[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) sum += fpart[w];
+    *tv.loss = (float)(sum * (double)tv.weight * (double)*tv.inv_count) + (tv.add_in ? *tv.add_in : 0.f);
+    *tv.counter = 0u;
+  }
 }
 
 // Fold the adjoint computed on the padded domain [(n + 2r)^3, index p = q + r] back onto the grid:
@@ -291,14 +321,22 @@ FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64
 //   loss_accum += weight * mean_masked((conv3(g).detach() - g)^2),   d_g3 = d loss / d g3   (fully written)
 // taps_host: the 27 taps of tv_smooth_conv (replicate padding); mask [X,Y,Z] uint8 or NULL; inv_count_dev = 1 / (number
 // of elements the mean runs over: 3 * mask.sum(), or 3 X Y Z), a DEVICE scalar so that no host read is needed.
+FGS_API int64_t fgs_smooth_tv_scratch_floats(int X, int Y, int Z) {
+  if (X <= 0 || Y <= 0 || Z <= 0) return 0;
+  return 1 + 3 * (int64_t)((X + CT_X - 1) / CT_X) * ((Y + CT_Y - 1) / CT_Y) * ((Z + CT_Z - 1) / CT_Z);
+}
+
 FGS_API int fgs_smooth_tv_loss(const float *g3, int X, int Y, int Z, const float *taps_host, const uint8_t *mask,
-                               const float *inv_count_dev, float weight, float *loss_accum, float *d_g3,
-                               fgs_stream_t stream) {
+                               const float *inv_count_dev, float weight, const float *add_in_dev, float *scratch,
+                               int64_t scratch_floats, float *loss_out, float *d_g3, fgs_stream_t stream) {
   Conv3 c;
   if (int e = make_conv("fgs_smooth_tv_loss", X, Y, Z, 3, taps_host, &c)) return e;
-  FGS_REQUIRE(g3 && inv_count_dev && loss_accum && d_g3 && g3 != d_g3, FGS_E_INVALID, "fgs_smooth_tv_loss: null or aliased pointers");
+  FGS_REQUIRE(g3 && inv_count_dev && loss_out && scratch && d_g3 && g3 != d_g3, FGS_E_INVALID,
+              "fgs_smooth_tv_loss: null or aliased pointers");
   const int64_t tiles = (int64_t)((X + CT_X - 1) / CT_X) * ((Y + CT_Y - 1) / CT_Y) * ((Z + CT_Z - 1) / CT_Z);
-  TvEpi tv{mask, inv_count_dev, weight, loss_accum};
+  FGS_REQUIRE(scratch_floats >= 1 + 3 * tiles, FGS_E_INVALID, "fgs_smooth_tv_loss: scratch %lld floats, need %lld",
+              (long long)scratch_floats, (long long)(1 + 3 * tiles));
+  TvEpi tv{mask, inv_count_dev, weight, loss_out, add_in_dev, scratch + 1, reinterpret_cast<unsigned *>(scratch)};
   hipLaunchKernelGGL((k_conv3d_tiled<3, true, 1>), dim3((unsigned)tiles, 3), dim3(FGS_BLOCK), 0, fgs_s(stream), g3, X, Y, Z, c,
                      1, (int64_t)1, d_g3, tv);
   FGS_LAUNCH_OK("fgs_smooth_tv_loss");

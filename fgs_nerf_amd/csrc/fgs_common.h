@@ -81,6 +81,17 @@ static inline int fgs_env_int(const char *name, int dflt) {
 
 // ------------------------------------------------------------------------------------ device
 
+// "The last workgroup sums the partials": called by ONE thread of a workgroup after it has written the workgroup's partial
+// result(s) with agent-scope atomic stores (written through the XCD's L2); returns true in the workgroup that arrives last,
+// which then reads all partials with agent-scope atomic loads.  There is deliberately no agent-scope release fence: on this
+// part it writes back EVERY dirty line of the L2 (whatever the neighbouring kernels left there), once per workgroup -- a
+// 1024-workgroup loss kernel spent 20 of its 42 us in them.  The stores are waited for (vmcnt) before the arrival is counted.
+__device__ __forceinline__ bool fgs_arrive_is_last(unsigned *counter, unsigned n_workgroups) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_workgroups - 1;
+}
+
 // s_setprio with a run-time (wave-uniform) level: the instruction takes an immediate.
 __device__ __forceinline__ void fgs_setprio(int p) {
   if (p == 1) __builtin_amdgcn_s_setprio(1);

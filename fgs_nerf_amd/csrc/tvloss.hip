@@ -43,9 +43,24 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// sums[0..2] += sum over valid pairs along x / y / z of |v[i+1] - v[i]|;  sums[3] += sum v;  sums[4..6] += valid pairs per axis
+// What the last workgroup makes of the seven sums (the scalar algebra of total_variation and of its backward, in double):
+struct TvFin {
+  const int64_t *count;   // device: mask.sum() of the caller's mask tensor (the denominator with a mask), or null: v.sum()
+  int per_axis_mean;      // model/dvgo.py:420-428: (mean_x + mean_y + mean_z) / 3 over the valid pairs
+  double scale;           // factor on the term (sdf_tv / 2 / voxel_size * weight_tv_density ...)
+  const float *add_in;    // device scalar added to the scaled term, or null
+  float *loss_out;        // scale * tv (+ *add_in)
+  float *w_out;           // 4 floats for k_tv_loss_grad: scale * d tv / d S_axis, and scale * d tv / d sum(v)
+  double *sums_out;       // optional: the seven sums {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z}
+};
+
+// One partial of seven doubles per workgroup, summed in a fixed order by the workgroup that arrives last: S_axis = sum over the
+// valid pairs along the axis of |v[i+1] - v[i]|, sum(v), pairs per axis.  (Until round 4 every workgroup added into seven
+// doubles with atomics -- 28 K atomics on seven addresses were 50 of the pass's 56 us at 114^3 -- and ~30 small torch launches
+// turned the sums into the loss and the backward factors.)
 template <bool CH_LAST>
-__global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__restrict__ v, TvGrid g, double *__restrict__ sums) {
+__global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__restrict__ v, TvGrid g, double *partials, unsigned *counter,
+                                                             TvFin fin) {
   float s[3] = {0.f, 0.f, 0.f}, tot = 0.f;
   unsigned cnt[3] = {0u, 0u, 0u};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -62,6 +77,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__rest
     if (z + 1 < g.d.Z && (!g.mask || g.mask[mo + 1])) { s[2] += fabsf(v[o + g.d.sZ] - a); ++cnt[2]; }
   }
   __shared__ double part[FGS_BLOCK / FGS_WAVE][7];
+  __shared__ int is_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double r[7] = {(double)s[0], (double)s[1], (double)s[2], (double)tot, (double)cnt[0], (double)cnt[1], (double)cnt[2]};
 #pragma unroll
@@ -74,17 +90,61 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__rest
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < FGS_BLOCK / FGS_WAVE; ++w) t += part[w][threadIdx.x];
-    atomicAdd(sums + threadIdx.x, t);
+    __hip_atomic_store(partials + 7 * (int64_t)blockIdx.x + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = fgs_arrive_is_last(counter, gridDim.x) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  // 7 x 32 threads: thread (k, j) sums partials b = j, j + 32, ... of sum k; then the 32 in order
+  __shared__ double fin_part[7][32];
+  if (threadIdx.x < 7 * 32) {
+    const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
+    double t = 0.0;
+    for (unsigned b = j; b < gridDim.x; b += 32)
+      t += __hip_atomic_load(partials + 7 * (int64_t)b + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fin_part[k][j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double S[7];
+  for (int k = 0; k < 7; ++k) {
+    double t = 0.0;
+    for (int j = 0; j < 32; ++j) t += fin_part[k][j];
+    S[k] = t;
+    if (fin.sums_out) fin.sums_out[k] = t;
+  }
+  double loss, w[4];
+  if (fin.per_axis_mean) {
+    loss = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      w[k] = 1.0 / (3.0 * S[4 + k]);
+      loss += S[k] * w[k];
+    }
+    w[3] = 0.0;
+  } else {
+    const double den = fin.count ? (double)*fin.count : S[3];
+    const double Ssum = (S[0] + S[1]) + S[2];
+    loss = Ssum / (3.0 * den);
+    w[0] = w[1] = w[2] = 1.0 / (3.0 * den);
+    w[3] = fin.count ? 0.0 : -Ssum / (3.0 * den * den);     // without a mask the denominator is v.sum(): it has a derivative too
+  }
+  if (fin.loss_out) *fin.loss_out = (float)(fin.scale * loss) + (fin.add_in ? *fin.add_in : 0.f);
+  if (fin.w_out)
+    for (int k = 0; k < 4; ++k) fin.w_out[k] = (float)(fin.scale * w[k]);
+  *counter = 0u;
 }
 
 // grad[j] (+)= sum over axes of w[axis] * (sign(v[j] - v[j-1]) [pair below valid] - sign(v[j+1] - v[j]) [pair above valid]) + w[3]
 template <bool CH_LAST, bool ACCUMULATE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_grad(const float *__restrict__ v, TvGrid g, const float *__restrict__ w,
-                                                            float *__restrict__ grad) {
+                                                            const float *__restrict__ upstream, float *__restrict__ grad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.n) return;
-  const float wx = w[0], wy = w[1], wz = w[2], w0 = w[3];
+  const float up = upstream ? *upstream : 1.f;
+  const float wx = w[0] * up, wy = w[1] * up, wz = w[2] * up, w0 = w[3] * up;
   int64_t c, x, y, z;
   tv_decode<CH_LAST>(g, i, c, x, y, z);
   const int64_t o = c * g.d.sC + x * g.d.sX + y * g.d.sY + z * g.d.sZ;
@@ -122,27 +182,39 @@ int tv_grid(const char *who, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t
 
 }  // namespace
 
-// Value pass.  v: [1,C,X,Y,Z] with element strides (channel-first or channel-last dense); mask: [X][Y][Z] bytes (non-zero =
-// inside; shared by all channels) or NULL; sums: 7 device doubles the pass ADDS into (the caller zeroes them):
-// {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z}.
+// Value pass (see include/fgs_hip.h).  scratch: 8-byte aligned, >= 1 + 7 * FGS_TV_VALUE_WGS doubles, first word zero when first
+// handed in (left zero).
+constexpr unsigned FGS_TV_VALUE_WGS = 1024;
+FGS_API int64_t fgs_tv_loss_scratch_doubles(void) { return 1 + 7 * (int64_t)FGS_TV_VALUE_WGS; }
+
 FGS_API int fgs_tv_loss_value(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
-                              int64_t sX, int64_t sY, int64_t sZ, double *sums, fgs_stream_t stream) {
+                              int64_t sX, int64_t sY, int64_t sZ, const int64_t *count_dev, int per_axis_mean, double scale,
+                              const float *add_in_dev, double *scratch, int64_t scratch_doubles, float *loss_out, float *w_out,
+                              double *sums_out, fgs_stream_t stream) {
   TvGrid g;
   bool ch_last;
   if (int e = tv_grid("fgs_tv_loss_value", C, X, Y, Z, sC, sX, sY, sZ, mask, &g, &ch_last)) return e;
-  FGS_REQUIRE(v && sums, FGS_E_INVALID, "fgs_tv_loss_value: null pointer");
-  const unsigned blocks = (unsigned)((g.n + FGS_BLOCK - 1) / FGS_BLOCK < 4096 ? (g.n + FGS_BLOCK - 1) / FGS_BLOCK : 4096);
-  if (ch_last) hipLaunchKernelGGL(k_tv_loss_value<true>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, sums);
-  else hipLaunchKernelGGL(k_tv_loss_value<false>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, sums);
+  FGS_REQUIRE(v && scratch && (loss_out || w_out || sums_out), FGS_E_INVALID, "fgs_tv_loss_value: null pointer");
+  FGS_REQUIRE(per_axis_mean || (count_dev != nullptr) == (mask != nullptr), FGS_E_INVALID,
+              "fgs_tv_loss_value: the denominator of the masked form is count_dev, of the unmasked form sum(v)");
+  const int64_t want = (g.n + FGS_BLOCK - 1) / FGS_BLOCK;
+  const unsigned blocks = (unsigned)(want < FGS_TV_VALUE_WGS ? want : FGS_TV_VALUE_WGS);
+  FGS_REQUIRE(scratch_doubles >= 1 + 7 * (int64_t)blocks, FGS_E_INVALID, "fgs_tv_loss_value: scratch %lld doubles, need %lld",
+              (long long)scratch_doubles, (long long)(1 + 7 * (int64_t)blocks));
+  const TvFin fin{count_dev, per_axis_mean, scale, add_in_dev, loss_out, w_out, sums_out};
+  unsigned *counter = reinterpret_cast<unsigned *>(scratch);
+  if (ch_last) hipLaunchKernelGGL(k_tv_loss_value<true>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, scratch + 1, counter, fin);
+  else hipLaunchKernelGGL(k_tv_loss_value<false>, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), v, g, scratch + 1, counter, fin);
   FGS_LAUNCH_OK("fgs_tv_loss_value");
   return 0;
 }
 
-// Gradient pass.  w: 4 device floats {w_x, w_y, w_z, w_0}: grad[j] = (accumulate ? grad[j] : 0) + sum_axis w_axis * (signed
+// Gradient pass.  w: 4 device floats {w_x, w_y, w_z, w_0} (what the value pass left in w_out), upstream_dev: device scalar that
+// multiplies them (d total / d term) or NULL: grad[j] = (accumulate ? grad[j] : 0) + sum_axis w_axis * (signed
 // pair terms of element j) + w_0   (w_0: the derivative through a v.sum() denominator; 0 otherwise).  grad has v's strides.
 FGS_API int fgs_tv_loss_grad(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
-                             int64_t sX, int64_t sY, int64_t sZ, const float *w, float *grad, int accumulate,
-                             fgs_stream_t stream) {
+                             int64_t sX, int64_t sY, int64_t sZ, const float *w, const float *upstream_dev, float *grad,
+                             int accumulate, fgs_stream_t stream) {
   TvGrid g;
   bool ch_last;
   if (int e = tv_grid("fgs_tv_loss_grad", C, X, Y, Z, sC, sX, sY, sZ, mask, &g, &ch_last)) return e;
@@ -150,11 +222,11 @@ FGS_API int fgs_tv_loss_grad(const float *v, const unsigned char *mask, int64_t 
   const dim3 grid(fgs_blocks(g.n)), blk(FGS_BLOCK);
   hipStream_t st = fgs_s(stream);
   if (ch_last) {
-    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<true, true>), grid, blk, 0, st, v, g, w, grad);
-    else hipLaunchKernelGGL((k_tv_loss_grad<true, false>), grid, blk, 0, st, v, g, w, grad);
+    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<true, true>), grid, blk, 0, st, v, g, w, upstream_dev, grad);
+    else hipLaunchKernelGGL((k_tv_loss_grad<true, false>), grid, blk, 0, st, v, g, w, upstream_dev, grad);
   } else {
-    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<false, true>), grid, blk, 0, st, v, g, w, grad);
-    else hipLaunchKernelGGL((k_tv_loss_grad<false, false>), grid, blk, 0, st, v, g, w, grad);
+    if (accumulate) hipLaunchKernelGGL((k_tv_loss_grad<false, true>), grid, blk, 0, st, v, g, w, upstream_dev, grad);
+    else hipLaunchKernelGGL((k_tv_loss_grad<false, false>), grid, blk, 0, st, v, g, w, upstream_dev, grad);
   }
   FGS_LAUNCH_OK("fgs_tv_loss_grad");
   return 0;

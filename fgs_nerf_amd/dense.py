@@ -13,7 +13,7 @@ import ctypes
 
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, lib, ptr, stream
 
 
 def _taps_c(taps: torch.Tensor):
@@ -117,83 +117,109 @@ def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, ho
     return _GradVol.apply(grid, float(voxel_size), pack, GRAD_MODES[mode])
 
 
+_TV_SCRATCH = {}          # (device index, kind) -> scratch of a TV value launch (first word: its arrival counter, left zero)
+
+
+def _tv_scratch(dev, kind: str, n: int, dtype) -> torch.Tensor:
+    key = (dev.index, kind)
+    t = _TV_SCRATCH.get(key)
+    if t is None or t.numel() < n:
+        t = _TV_SCRATCH[key] = torch.zeros(n, dtype=dtype, device=dev)     # (a replaced one stays referenced by its launches' stream order)
+    return t
+
+
+def _is_unit_seed(g_loss: torch.Tensor) -> bool:
+    from .losses import UNIT_SEEDS
+    return g_loss.data_ptr() in UNIT_SEEDS
+
+
 class _SmoothTV(torch.autograd.Function):
-    """weight * mean_masked((tv_smooth_conv(g).detach() - g)^2) over a [1,3,X,Y,Z] gradient volume: value and d/dg in one
-    HIP pass per channel (include/fgs_hip.h fgs_smooth_tv_loss)."""
+    """weight * mean_masked((tv_smooth_conv(g).detach() - g)^2) (+ add_in) over a [1,3,X,Y,Z] gradient volume: value and d/dg in
+    one HIP pass per channel (include/fgs_hip.h fgs_smooth_tv_loss); `add_in`: the loss so far (saves an addition launch)."""
 
     @staticmethod
-    def forward(ctx, grad3, taps_c, mask_u8, inv_count, weight):
+    def forward(ctx, grad3, taps_c, mask_u8, inv_count, weight, add_in):
         if not (grad3.is_cuda and grad3.dtype == torch.float32 and grad3.dim() == 5 and grad3.shape[:2] == (1, 3)):
             raise RuntimeError("expected a float32 CUDA gradient volume of shape [1,3,X,Y,Z]")
         g = grad3.contiguous()
         X, Y, Z = (int(v) for v in g.shape[2:])
-        loss = torch.zeros((), dtype=torch.float32, device=g.device)
+        loss = torch.empty((), dtype=torch.float32, device=g.device)
         d_g = torch.empty_like(g)
-        call("fgs_smooth_tv_loss", ptr(g), X, Y, Z, taps_c, ptr(mask_u8), ptr(inv_count), float(weight), ptr(loss), ptr(d_g),
-             stream())
+        need = int(lib().fgs_smooth_tv_scratch_floats(X, Y, Z))
+        scratch = _tv_scratch(g.device, 'smooth', need, torch.float32)
+        call("fgs_smooth_tv_loss", ptr(g), X, Y, Z, taps_c, ptr(mask_u8), ptr(inv_count), float(weight), ptr(add_in), ptr(scratch),
+             scratch.numel(), ptr(loss), ptr(d_g), stream())
         ctx.save_for_backward(d_g)
+        ctx.has_add = add_in is not None
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loss):
         (d_g,) = ctx.saved_tensors
-        return d_g * g_loss, None, None, None, None
+        # (a captured step passes a registered unit seed through the additions in front of this node: no grid-sized multiply)
+        g = d_g if _is_unit_seed(g_loss) else d_g * g_loss
+        return g, None, None, None, None, (g_loss if ctx.has_add else None)
 
 
-def smooth_tv_loss(grad3: torch.Tensor, taps_c, mask_u8, inv_count: torch.Tensor, weight: float) -> torch.Tensor:
-    return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight))
+def smooth_tv_loss(grad3: torch.Tensor, taps_c, mask_u8, inv_count: torch.Tensor, weight: float, add_in=None) -> torch.Tensor:
+    return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight), add_in)
 
 
 class _GridTV(torch.autograd.Function):
-    """`total_variation(v, mask)` of the reference (model/nerf.py:1212-1221; `per_axis_mean=True`: model/dvgo.py:420-428) as
-    one HIP value pass and one HIP gradient pass (csrc/tvloss.hip) instead of ~20 dense torch kernels that each save a
-    grid-sized tensor.  Denominators and the backward scale factors are device scalars: nothing is read by the host."""
+    """scale * `total_variation(v, mask)` (+ add_in) of the reference (model/nerf.py:1212-1221; `per_axis_mean=True`:
+    model/dvgo.py:420-428) as one HIP value pass and one HIP gradient pass (csrc/tvloss.hip) instead of ~20 dense torch kernels that
+    each save a grid-sized tensor.  The scalar algebra between the seven sums, the loss and the backward factors runs in the value
+    launch's last workgroup (double), the upstream gradient is read by the gradient launch: two launches in all."""
 
     @staticmethod
-    def forward(ctx, v, mask_u8, masked_count, per_axis_mean):
+    def forward(ctx, v, mask_u8, masked_count, per_axis_mean, scale, add_in):
         if not (v.is_cuda and v.dtype == torch.float32 and v.dim() == 5 and v.shape[0] == 1):
             raise RuntimeError("expected a float32 CUDA grid of shape [1,C,X,Y,Z]")
         from .ops import grid_strides
         dims = grid_strides(v)                                   # C, X, Y, Z, sC, sX, sY, sZ
-        sums = torch.zeros(7, dtype=torch.float64, device=v.device)
-        call("fgs_tv_loss_value", ptr(v), ptr(mask_u8), *dims, ptr(sums), stream())
-        S, V, n_pairs = sums[0:3], sums[3], sums[4:7]
-        if per_axis_mean:                                        # (mean_x + mean_y + mean_z) / 3 over the valid pairs
-            axis_w = 1.0 / (3.0 * n_pairs)
-            loss = (S * axis_w).sum()
-            w0 = torch.zeros((), dtype=torch.float64, device=v.device)
-        else:                                                    # (S_x + S_y + S_z) / 3 / (mask.sum() or v.sum())
-            den = masked_count.to(torch.float64) if mask_u8 is not None else V
-            axis_w = (1.0 / (3.0 * den)).expand(3)
-            loss = S.sum() / (3.0 * den)
-            # without a mask the denominator is v.sum(): d/dv also carries -S / (3 V^2)
-            w0 = torch.zeros((), dtype=torch.float64, device=v.device) if mask_u8 is not None else -S.sum() / (3.0 * den * den)
-        ctx.save_for_backward(v, torch.cat([axis_w.reshape(3), w0.reshape(1)]))
-        ctx.mask_u8, ctx.dims = mask_u8, dims
-        return loss.to(torch.float32)
+        loss = torch.empty((), dtype=torch.float32, device=v.device)
+        w = torch.empty(4, dtype=torch.float32, device=v.device)
+        scratch = _tv_scratch(v.device, 'grid', int(lib().fgs_tv_loss_scratch_doubles()), torch.float64)
+        count = masked_count if (mask_u8 is not None and not per_axis_mean) else None
+        call("fgs_tv_loss_value", ptr(v), ptr(mask_u8), *dims, ptr(count), int(bool(per_axis_mean)), float(scale), ptr(add_in),
+             ptr(scratch), scratch.numel(), ptr(loss), ptr(w), None, stream())
+        ctx.save_for_backward(v, w)
+        ctx.mask_u8, ctx.dims, ctx.has_add = mask_u8, dims, add_in is not None
+        return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loss):
         v, w = ctx.saved_tensors
-        w = (w * g_loss.to(torch.float64)).to(torch.float32).contiguous()
+        up = None if _is_unit_seed(g_loss) else g_loss.to(torch.float32).contiguous()
         grad = torch.empty_strided(v.shape, v.stride(), dtype=torch.float32, device=v.device)
-        call("fgs_tv_loss_grad", ptr(v), ptr(ctx.mask_u8), *ctx.dims, ptr(w), ptr(grad), 0, stream())
-        return grad, None, None, None
+        call("fgs_tv_loss_grad", ptr(v), ptr(ctx.mask_u8), *ctx.dims, ptr(w), ptr(up), ptr(grad), 0, stream())
+        return grad, None, None, None, None, (g_loss if ctx.has_add else None)
 
 
-def grid_tv_loss(v: torch.Tensor, mask=None, per_axis_mean: bool = False) -> torch.Tensor:
-    """The reference's `total_variation(v, mask)` on a CUDA grid.  `mask`: bool [1,1,X,Y,Z] or [1,C,X,Y,Z] with identical
-    channels (the reference builds the latter with `.repeat(1, C, 1, 1, 1)`: model/nerf.py:454) or None."""
+_MASK_COUNTS = []         # [(mask tensor, its _version, mask_u8 view, mask.sum() as a device int64)]: the count is two launches
+
+
+def _mask_count(mask: torch.Tensor):
+    for m, ver, u8, cnt in _MASK_COUNTS:
+        if m is mask and ver == mask._version:
+            return u8, cnt
+    m0 = mask[0, 0].contiguous()
+    u8 = m0.view(torch.uint8) if m0.dtype == torch.bool else (m0 != 0).view(torch.uint8)
+    cnt = (m0.sum() * mask.shape[1]).to(torch.int64).reshape(1)          # mask.sum() of the tensor the caller passed (device scalar)
+    _MASK_COUNTS.append((mask, mask._version, u8, cnt))
+    del _MASK_COUNTS[:-4]
+    return u8, cnt
+
+
+def grid_tv_loss(v: torch.Tensor, mask=None, per_axis_mean: bool = False, scale: float = 1.0, add_in=None) -> torch.Tensor:
+    """scale * the reference's `total_variation(v, mask)` (+ add_in) on a CUDA grid.  `mask`: bool [1,1,X,Y,Z] or [1,C,X,Y,Z] with
+    identical channels (the reference builds the latter with `.repeat(1, C, 1, 1, 1)`: model/nerf.py:454) or None."""
     mask_u8 = count = None
     if mask is not None:
-        m = mask
-        if m.dim() != 5 or tuple(m.shape[2:]) != tuple(v.shape[2:]) or m.shape[1] not in (1, v.shape[1]):
+        if mask.dim() != 5 or tuple(mask.shape[2:]) != tuple(v.shape[2:]) or mask.shape[1] not in (1, v.shape[1]):
             raise RuntimeError(f"mask shape {tuple(mask.shape)} does not fit grid {tuple(v.shape)}")
-        reps = m.shape[1]
-        m0 = m[0, 0].contiguous()
-        mask_u8 = m0.view(torch.uint8) if m0.dtype == torch.bool else (m0 != 0).view(torch.uint8)
-        count = m0.sum() * reps                                  # mask.sum() of the tensor the caller passed (device scalar)
-    return _GridTV.apply(v, mask_u8, count, bool(per_axis_mean))
+        mask_u8, count = _mask_count(mask)
+    return _GridTV.apply(v, mask_u8, count, bool(per_axis_mean), float(scale), add_in)
 

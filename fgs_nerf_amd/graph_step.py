@@ -60,7 +60,7 @@ class CapturedFineStep:
     inc_bounds_of    : None, or iteration index -> the six index bounds of that iteration's voxel-increment mask
                        (`model.inc_index_bounds(lower, upper)`; model/nerf_training.py:286-291): the mask of `model.inc_mask` (set
                        before capture, never replaced afterwards) is rewritten in place by every replay
-    variants         : None, or a list of dicts {'tv': ..., 'extra_loss': callable(model) -> scalar tensor or None}: one graph
+    variants         : None, or a list of dicts {'tv': ..., 'extra_loss': callable(model, loss) -> loss + extra terms, or None}: one graph
                        per entry over the SAME static inputs, schedule table and counters, chosen per iteration by
                        `replay(batch, variant=k)` -- iterations of different SHAPE inside one window (the shipped fine config
                        runs the TV add-grad and the autograd smooth-gradient TV term every third iteration,
@@ -252,7 +252,7 @@ class CapturedFineStep:
         loss = fused_render_losses(res, self.target, self.loss_cfg, self.model)
         var = self.variants[variant]
         if var.get('extra_loss') is not None:
-            loss = loss + var['extra_loss'](self.model)
+            loss = var['extra_loss'](self.model, loss)
         av = self.averager
         if av is not None:
             # the bricks this step's k0 gradient can touch, their union over ranks and the union's brick list -- all on a side

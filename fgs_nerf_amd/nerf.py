@@ -361,8 +361,59 @@ class nerf(torch.nn.Module):
         return g
 
     # ------------------------------------------------------------------ regularisers
-    def density_total_variation(self, sdf_tv=0, smooth_grad_tv=0, sdf_thrd=0.999):
-        """model/nerf.py:430-447."""
+    def density_total_variation(self, sdf_tv=0, smooth_grad_tv=0, sdf_thrd=0.999, weight=1.0, add_to=None):
+        """model/nerf.py:430-447.  `weight`, `add_to` (not in the reference): returns weight * tv (+ add_to) -- on CUDA grids the
+        HIP launches apply the factor and add the loss so far themselves, and a training step's loss then takes two launches per
+        term instead of two plus the scalar arithmetic around them (nerf_training passes weight_tv_density and the loss)."""
+        fused = self.sdf.grid.is_cuda and not (weight == 1.0 and add_to is None)
+        if fused:
+            return self._density_tv_fused(sdf_tv, smooth_grad_tv, float(weight), add_to)
+        tv = self._density_tv(sdf_tv, smooth_grad_tv)
+        if weight != 1.0:
+            tv = weight * tv
+        return tv if add_to is None else add_to + tv
+
+    def _smooth_tv_operands(self, grad):
+        """Host copy of tv_smooth_conv's frozen taps and the (masked) mean's element count as a cached DEVICE scalar."""
+        from . import dense
+        w = self.tv_smooth_conv.weight
+        taps = self.__dict__.get('_tv_taps_c')
+        if taps is None or taps[0] is not w:                 # host copy of the frozen taps, made once
+            taps = (w, dense._taps_c(w))
+            self.__dict__['_tv_taps_c'] = taps
+        m = self.nonempty_mask
+        cnt = self.__dict__.get('_nonempty_count')
+        if cnt is None or cnt[0] is not m or cnt[2] != tuple(grad.shape):
+            n = (3.0 * m.sum().to(torch.float32)) if m is not None else torch.tensor(float(grad.numel()), device=grad.device)
+            mask_u8 = None if m is None else m.reshape(m.shape[-3:]).contiguous().view(torch.uint8)
+            cnt = (m, (1.0 / n).reshape(1).contiguous(), tuple(grad.shape), mask_u8)
+            self.__dict__['_nonempty_count'] = cnt
+        return taps[1], cnt[3], cnt[1]
+
+    def _voxel_size_host(self) -> float:
+        """float(self.voxel_size) read once per voxel_size tensor (a device scalar: reading it inside a stream capture is illegal;
+        the warm-up pass in front of every capture fills the cache)."""
+        vs = self.voxel_size
+        c = self.__dict__.get('_voxel_size_f')
+        if c is None or c[0] is not vs:
+            c = (vs, float(vs))
+            self.__dict__['_voxel_size_f'] = c
+        return c[1]
+
+    def _density_tv_fused(self, sdf_tv, smooth_grad_tv, weight, acc):
+        from . import dense
+        if sdf_tv > 0:
+            acc = dense.grid_tv_loss(self.sdf.grid, self.nonempty_mask, per_axis_mean=False,
+                                     scale=weight * sdf_tv / 2.0 / self._voxel_size_host(), add_in=acc)
+        if smooth_grad_tv > 0:
+            grad = self.gradient                                     # [1,3,X,Y,Z]
+            if not grad.is_contiguous():
+                grad = grad.contiguous()
+            taps_c, mask_u8, inv_count = self._smooth_tv_operands(grad)
+            acc = dense.smooth_tv_loss(grad, taps_c, mask_u8, inv_count, weight * smooth_grad_tv, add_in=acc)
+        return acc if acc is not None else 0
+
+    def _density_tv(self, sdf_tv, smooth_grad_tv):
         tv = 0
         if sdf_tv > 0:
             tv += total_variation(self.sdf.grid, self.nonempty_mask) / 2 / self.voxel_size * sdf_tv
@@ -372,19 +423,8 @@ class nerf(torch.nn.Module):
                 # value and gradient of the term in one LDS-tiled HIP pass per component (csrc/dense.hip); the element
                 # count of the (masked) mean is a cached DEVICE scalar, so nothing here reads back to the host
                 from . import dense
-                w = self.tv_smooth_conv.weight
-                taps = self.__dict__.get('_tv_taps_c')
-                if taps is None or taps[0] is not w:                 # host copy of the frozen taps, made once
-                    taps = (w, dense._taps_c(w))
-                    self.__dict__['_tv_taps_c'] = taps
-                m = self.nonempty_mask
-                cnt = self.__dict__.get('_nonempty_count')
-                if cnt is None or cnt[0] is not m or cnt[2] != tuple(grad.shape):
-                    n = (3.0 * m.sum().to(torch.float32)) if m is not None else torch.tensor(float(grad.numel()), device=grad.device)
-                    mask_u8 = None if m is None else m.reshape(m.shape[-3:]).contiguous().view(torch.uint8)
-                    cnt = (m, (1.0 / n).reshape(1).contiguous(), tuple(grad.shape), mask_u8)
-                    self.__dict__['_nonempty_count'] = cnt
-                tv += dense.smooth_tv_loss(grad, taps[1], cnt[3], cnt[1], smooth_grad_tv)
+                taps_c, mask_u8, inv_count = self._smooth_tv_operands(grad)
+                tv += dense.smooth_tv_loss(grad, taps_c, mask_u8, inv_count, smooth_grad_tv)
             else:
                 g = grad.permute(1, 0, 2, 3, 4)
                 err = self.tv_smooth_conv(g).detach() - g

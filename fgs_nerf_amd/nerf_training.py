@@ -250,9 +250,9 @@ class TrainStepper:
         if tv_now and ct.get('weight_tv_density', 0) > 0:    # autograd TV terms (:330-345)
             sdf_tv, smooth_grad_tv = tv_terms.get('sdf_tv', 0), tv_terms.get('smooth_grad_tv', 0)
             if smooth_grad_tv > 0:
-                loss = loss + ct.weight_tv_density * model.density_total_variation(sdf_tv=0, smooth_grad_tv=smooth_grad_tv)
+                loss = model.density_total_variation(sdf_tv=0, smooth_grad_tv=smooth_grad_tv, weight=ct.weight_tv_density, add_to=loss)
             if ori_tv:
-                loss = loss + ct.weight_tv_density * model.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0)
+                loss = model.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0, weight=ct.weight_tv_density, add_to=loss)
                 if ct.get('weight_tv_k0', 0) > 0:
                     loss = loss + ct.weight_tv_k0 * model.k0_total_variation(**ct.get('k0_tv_terms', {}))
                     hinted = False            # k0 receives a dense gradient: the survivor-point occupancy does not cover it
@@ -373,11 +373,14 @@ class TrainStepper:
                 tv = (w_tv * sdf_tv / ct.N_rand, dense.pop())
             pieces = []
             if s_tv > 0:
-                pieces.append(lambda m: m.density_total_variation(sdf_tv=0, smooth_grad_tv=s_tv))
+                pieces.append(lambda m, acc: m.density_total_variation(sdf_tv=0, smooth_grad_tv=s_tv, weight=w_tv, add_to=acc))
             if ori_tv and sdf_tv > 0:
-                pieces.append(lambda m: m.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0))
+                pieces.append(lambda m, acc: m.density_total_variation(sdf_tv=sdf_tv, smooth_grad_tv=0, weight=w_tv, add_to=acc))
             if pieces:
-                extra = lambda m: w_tv * sum(f(m) for f in pieces)   # noqa: E731
+                def extra(m, loss, _pieces=tuple(pieces)):      # (the terms add themselves to the loss: no addition launches)
+                    for f in _pieces:
+                        loss = f(m, loss)
+                    return loss
         variants = [dict(tv=None, extra_loss=None)]
         tv_variant = 0
         if tv is not None or extra is not None:

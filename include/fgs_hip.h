@@ -38,7 +38,7 @@ typedef void *fgs_stream_t;
  * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
  * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked);
  * 11 = fgs_fine_render_loss. */
-#define FGS_ABI_VERSION 11
+#define FGS_ABI_VERSION 12
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -596,12 +596,18 @@ int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel
                         float voxel_size, int mode, float *d_sdf, int accumulate, fgs_stream_t stream);
 
 /* Smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446; the shipped fine config adds it every
- * third iteration) over the gradient volume g3 [3,X,Y,Z], value and gradient in one LDS-tiled pass per channel:
- *   *loss_accum += weight * mean_masked((tv_smooth_conv(g3).detach() - g3)^2),    d_g3 = d(that term) / d g3.
+ * third iteration, the coarse configs every iteration) over the gradient volume g3 [3,X,Y,Z], value and gradient in one
+ * LDS-tiled pass per channel:
+ *   *loss_out = weight * mean_masked((tv_smooth_conv(g3).detach() - g3)^2) (+ *add_in_dev),    d_g3 = d(weight * mean) / d g3.
  * taps_host: the 27 taps of tv_smooth_conv (HOST, replicate padding); mask [X,Y,Z] uint8 (nonempty_mask) or NULL;
- * inv_count_dev: DEVICE scalar 1 / (elements in the mean) -- 3 * mask.sum() or 3 X Y Z -- so no host read is needed. */
+ * inv_count_dev: DEVICE scalar 1 / (elements in the mean) -- 3 * mask.sum() or 3 X Y Z -- so no host read is needed;
+ * add_in_dev: device scalar added to the term (the loss so far: saves the caller an addition launch) or NULL.
+ * The scalar is a fixed-order sum (one partial per workgroup, summed by the one that arrives last): bit-reproducible.
+ * scratch: fgs_smooth_tv_scratch_floats(X, Y, Z) floats whose first word is zero when first handed in (left zero). */
+int64_t fgs_smooth_tv_scratch_floats(int X, int Y, int Z);
 int fgs_smooth_tv_loss(const float *g3, int X, int Y, int Z, const float *taps_host, const uint8_t *mask,
-                       const float *inv_count_dev, float weight, float *loss_accum, float *d_g3, fgs_stream_t stream);
+                       const float *inv_count_dev, float weight, const float *add_in_dev, float *scratch, int64_t scratch_floats,
+                       float *loss_out, float *d_g3, fgs_stream_t stream);
 
 /* Fused front half of forward_coarse (model/nerf.py:946-990), one wavefront per ray: sample_pts_on_rays, optional mask
  * cache (stage 'coarse' only, :952-959) and voxel-increment MaskGrid (:962-967; inc_world uint8 [iX,iY,iZ] with the
@@ -670,14 +676,25 @@ int fgs_mc_emit(const float *field, int X, int Y, int Z, float iso, const int8_t
  * model/dvgo.py:420-428 as a value pass and a gradient pass (what the reference differentiates through diff -> abs ->
  * boolean index -> sum).  v: [1,C,X,Y,Z] float32 with element strides (channel-first or channel-last dense); mask:
  * [X][Y][Z] bytes, non-zero = inside, shared by all channels, or NULL.
- * value: ADDS into 7 device doubles {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z}: S_a = sum over the pairs along axis a
- * whose two voxels are inside the mask of |v[i+1] - v[i]|, pairs_a = their number.
- * grad: grad[j] = (accumulate ? grad[j] : 0) + sum_a w[a] * (sign(v[j] - v[j-1_a]) [valid] - sign(v[j+1_a] - v[j]) [valid]) +
- * w[3], sign(0) = 0; w: 4 DEVICE floats (the caller folds 1/3, the denominator and the upstream gradient into them). */
+ * value: the seven sums {S_x, S_y, S_z, sum(v), pairs_x, pairs_y, pairs_z} (S_a = sum over the pairs along axis a whose two
+ * voxels are inside the mask of |v[i+1] - v[i]|, pairs_a = their number; fixed-order double sums: bit-reproducible) and, from
+ * them on the device, in double:
+ *     tv = (S_x + S_y + S_z) / 3 / den,  den = *count_dev with a mask (the mask.sum() of the tensor the caller holds), sum(v)
+ *          without one (sic: model/nerf.py:1221)                                   [per_axis_mean = 0]
+ *     tv = (S_x / pairs_x + S_y / pairs_y + S_z / pairs_z) / 3                     [per_axis_mean = 1: model/dvgo.py:420-428]
+ *   *loss_out = (float)(scale * tv) (+ *add_in_dev),   w_out[0..2] = scale * d tv / d S_a,  w_out[3] = scale * d tv / d sum(v)
+ *   (0 with a mask), sums_out[0..6] = the sums.  Any of loss_out / w_out / sums_out may be NULL.
+ *   scratch: fgs_tv_loss_scratch_doubles() doubles whose first word is zero when first handed in (left zero).
+ * grad: grad[j] = (accumulate ? grad[j] : 0) + u * (sum_a w[a] * (sign(v[j] - v[j-1_a]) [valid] - sign(v[j+1_a] - v[j])
+ * [valid]) + w[3]), sign(0) = 0; w: 4 DEVICE floats (the value pass's w_out), u = *upstream_dev (d total / d term) or 1. */
+int64_t fgs_tv_loss_scratch_doubles(void);
 int fgs_tv_loss_value(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
-                      int64_t sX, int64_t sY, int64_t sZ, double *sums, fgs_stream_t stream);
+                      int64_t sX, int64_t sY, int64_t sZ, const int64_t *count_dev, int per_axis_mean, double scale,
+                      const float *add_in_dev, double *scratch, int64_t scratch_doubles, float *loss_out, float *w_out,
+                      double *sums_out, fgs_stream_t stream);
 int fgs_tv_loss_grad(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
-                     int64_t sX, int64_t sY, int64_t sZ, const float *w, float *grad, int accumulate, fgs_stream_t stream);
+                     int64_t sX, int64_t sY, int64_t sZ, const float *w, const float *upstream_dev, float *grad, int accumulate,
+                     fgs_stream_t stream);
 
 /* masked_adam_upd (adam_upd_kernel.cu:25-40) over a SET of 4x4x4-voxel bricks of a channel-last [X][Y][Z][C] grid (C a
  * multiple of 4; sides need not be multiples of 4), and self-cleaning: only the selected bricks are visited, elements with

@@ -83,3 +83,51 @@ def test_grid_tv_loss_full_size_feature_grid(dev):
     tv.backward()
     assert torch.isfinite(tv) and float(tv) > 0
     assert not bool((v.grad != 0)[~mask.expand_as(v.grad)].any())
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_weighted_terms_added_to_a_loss_in_the_launches(dev, oracle, masked):
+    """density_total_variation(..., weight=, add_to=) -- the form nerf_training uses: the launches scale the terms and add the loss
+    so far themselves -- against weight * (reference expression) + loss in float64, values and gradients, with a registered unit
+    seed (no grid-sized multiply in the backward pass) and with an arbitrary one; the scalars are fixed-order sums: two runs agree
+    bit for bit."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.losses import register_unit_seed
+    model = synth.build_model(48, synth.COARSE_MODEL, device=dev)
+    with torch.no_grad():
+        model.sdf.grid.add_(torch.randn_like(model.sdf.grid) * 0.01)
+    model.nonempty_mask = (torch.rand(model.sdf.grid.shape, generator=torch.Generator().manual_seed(2)) > 0.4).to(dev) if masked else None
+    base_p = torch.tensor(0.37, device=dev, requires_grad=True)
+    w = 0.01
+
+    def run(seed):
+        model.sdf.grid.grad = None
+        base_p.grad = None
+        loss = base_p * 1.0
+        model.gradient = model.neus_sdf_gradient(sdf=model.sdf.grid)       # (the forward pass leaves it: an autograd node over sdf.grid)
+        loss = model.density_total_variation(sdf_tv=0, smooth_grad_tv=0.05, weight=w, add_to=loss)
+        loss = model.density_total_variation(sdf_tv=0.1, smooth_grad_tv=0, weight=w, add_to=loss)
+        loss.backward(seed)
+        return loss.detach().clone(), model.sdf.grid.grad.detach().clone(), base_p.grad.detach().clone()
+
+    unit = register_unit_seed(torch.ones((), device=dev))
+    la, ga, ba = run(unit)
+    lb, gb, bb = run(unit)
+    assert torch.equal(la, lb) and torch.equal(ga, gb)
+    lc, gc, bc = run(torch.full((), 0.25, device=dev))
+    assert float(ba) == 1.0 and float(bc) == 0.25
+    assert float((gc * 4.0 - ga).abs().max()) <= 1e-6 * float(ga.abs().max())
+    # the reference expressions (model/nerf.py:430-447), unfused, through the same model: torch ops around the two launches
+    model.sdf.grid.grad = None
+    model.gradient = model.neus_sdf_gradient(sdf=model.sdf.grid)
+    ref = 0.37 + w * model.density_total_variation(sdf_tv=0, smooth_grad_tv=0.05) + w * model.density_total_variation(sdf_tv=0.1, smooth_grad_tv=0)
+    ref.backward()
+    gr = model.sdf.grid.grad
+    assert abs(float(la) - float(ref)) <= 2e-6 * abs(float(ref)), (float(la), float(ref))
+    assert float((ga - gr).abs().max()) <= 3e-6 * float(gr.abs().max())
+    # ... and the sdf TV part against the oracle's float64 statement
+    sdf64 = model.sdf.grid.detach().double().cpu().contiguous()
+    m64 = None if not masked else model.nonempty_mask.cpu()
+    tv64 = float(oracle.total_variation(sdf64, m64)) / 2 / float(model.voxel_size) * 0.1
+    only = model.density_total_variation(sdf_tv=0.1, smooth_grad_tv=0, weight=w, add_to=None)
+    assert abs(float(only) - w * tv64) <= 2e-6 * abs(w * tv64)
