@@ -329,6 +329,35 @@ FGS_API int fgs_maskcache_lookup(const uint8_t *world, const float *xyz, const f
 
 // Exclusive prefix sum of int64 counts: out[0..n] (out[n] = total).  Used between the fused march kernel and the
 // survivor kernels (per-ray survivor counts -> segment offsets), the same scan sample_count uses.
+namespace {
+// out[a][i][0..2] = src_a[sel[i]][0..2]: the four row gathers of a training batch (model/nerf_training.py:256-261: target,
+// rays_o, rays_d, viewdirs by one index vector) in one launch, written where the captured step reads its inputs
+struct BatchSrc { const float *p[4]; };
+__global__ __launch_bounds__(FGS_BLOCK) void k_gather_batch(const int64_t *__restrict__ sel, int64_t n, int64_t n_src, BatchSrc src,
+                                                            float *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * n) return;
+  const int64_t a = t / n, i = t - a * n;
+  int64_t r = sel[i];
+  r = r < 0 ? 0 : (r >= n_src ? n_src - 1 : r);        // (an index out of range must not become a fault)
+  const float *s = src.p[a] + 3 * r;
+  float *o = out + 3 * t;
+  o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+}
+}  // namespace
+
+FGS_API int fgs_gather_batch(const int64_t *sel, int64_t n, int64_t n_src, const float *src0, const float *src1, const float *src2,
+                             const float *src3, float *out, fgs_stream_t stream) {
+  FGS_REQUIRE(n >= 0 && n_src > 0 && n < FGS_MAX_ELEMS / 16, FGS_E_RANGE, "fgs_gather_batch: n=%lld of %lld", (long long)n,
+              (long long)n_src);
+  if (n == 0) return 0;
+  FGS_REQUIRE(sel && src0 && src1 && src2 && src3 && out, FGS_E_INVALID, "fgs_gather_batch: null pointer");
+  const BatchSrc src{{src0, src1, src2, src3}};
+  hipLaunchKernelGGL(k_gather_batch, dim3(fgs_blocks(4 * n)), dim3(FGS_BLOCK), 0, fgs_s(stream), sel, n, n_src, src, out);
+  FGS_LAUNCH_OK("fgs_gather_batch");
+  return 0;
+}
+
 FGS_API int fgs_exclusive_scan_i64(const int64_t *in, int64_t n, int64_t *out, fgs_stream_t stream) {
   FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_exclusive_scan_i64: n=%lld", (long long)n);
   FGS_REQUIRE(out && (n == 0 || in), FGS_E_INVALID, "fgs_exclusive_scan_i64: null pointer");

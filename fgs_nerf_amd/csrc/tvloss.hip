@@ -26,6 +26,20 @@ struct TvGrid {
 // element index i -> (c, x, y, z) in the order that makes consecutive threads touch consecutive memory
 template <bool CH_LAST>
 __device__ __forceinline__ void tv_decode(const TvGrid &g, int64_t i, int64_t &c, int64_t &x, int64_t &y, int64_t &z) {
+  if (g.n < ((int64_t)1 << 31)) {      // (uniform) 32-bit divisions: the 64-bit ones were most of the value pass's instructions
+    unsigned j = (unsigned)i;
+    const unsigned C = (unsigned)g.d.C, X = (unsigned)g.d.X, Y = (unsigned)g.d.Y, Z = (unsigned)g.d.Z;
+    if (CH_LAST) {
+      c = j % C; j /= C;
+      z = j % Z; j /= Z;
+      y = j % Y; x = j / Y;
+    } else {
+      z = j % Z; j /= Z;
+      y = j % Y; j /= Y;
+      x = j % X; c = j / X;
+    }
+    return;
+  }
   if (CH_LAST) {
     c = i % g.d.C; i /= g.d.C;
     z = i % g.d.Z; i /= g.d.Z;

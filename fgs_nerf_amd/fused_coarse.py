@@ -148,8 +148,8 @@ class _FusedCoarse(torch.autograd.Function):
         pre_sig = torch.empty(N, 3, dtype=F32, device=dev)
         normal_marched = torch.empty(N, 3, dtype=F32, device=dev) if run.render_grad else None
         depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
-        call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
-             ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+        run.fused_loss = _composite(run, any(ctx.needs_input_grad), N, M, ws['surv_off'], weights, rgb, normal, step_id, alphainv_last,
+                                    rgb_marched, sigmoid_rgb, pre_rgb, pre_sig, normal_marched, depth)
         run.pre = None                                 # backward's big zero fills, issued here (see _FusedFine.forward)
         if any(ctx.needs_input_grad) and M > 0:
             run.pre = (torch.zeros(g.X, g.Y, g.Z, 4, dtype=F32, device=dev), pre_k0)
@@ -213,11 +213,16 @@ class _FusedCoarse(torch.autograd.Function):
             if run.s_param is not None:
                 grads.append(torch.zeros_like(run.s_param))
             return tuple(grads)
-        d_out = torch.empty(M, 3, dtype=F32, device=dev)
-        d_w = torch.empty(M, dtype=F32, device=dev)
-        call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
-             ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
-             dyn(row_count=_rows(run)), st)
+        fl = getattr(run, 'fused_loss', None)
+        if fl is not None and fl['used']:
+            # (the forward pass ran the loss and the compositing backward already: fused_common._composite)
+            d_out, d_w, g_normal, g_last = fl['d_out'], fl['d_w'], fl['g_normal'], fl['g_last']
+        else:
+            d_out = torch.empty(M, 3, dtype=F32, device=dev)
+            d_w = torch.empty(M, dtype=F32, device=dev)
+            call("fgs_composite_bwd", M, ptr(S['ray_id']), ptr(S['weights']), ptr(S['rgb']), ptr(S['pre_rgb']), ptr(S['pre_sig']),
+                 ptr(g_rgb_marched), ptr(g_sigmoid_rgb), ptr(g_raw_rgb), ptr(g_weights), run.bg, ptr(d_out), ptr(d_w),
+                 dyn(row_count=_rows(run)), st)
         acts = S['acts']
         a_last = acts[n_ref - 1]
         dY = torch.empty(M, fw, dtype=F32, device=dev)
@@ -407,6 +412,7 @@ def forward_coarse(model, rays_o, rays_d, viewdirs, global_step=20000, **render_
              'normal': normal, 'raw_alpha': alpha, 'raw_rgb': rgb, 'depth': depth,
              'disp': None if depth is None else 1 / depth, 'gradient': gradient, 's_val': s_val,
              'step_id': ex['step_id'], 'n_inbbox_visited': ex['n_inbbox'], 'ray_viewdirs': run.viewdirs,
+             '_fused_loss': getattr(run, 'fused_loss', None),
              'survivor_pts': run.saved['pts'],
              'survivor_count_ptr': run.count_ptr}       # sync-free mode: see forward_fine
     return LazyResult(eager, {'mask': lazy_mask, 'mask_outbbox': lazy_outbbox,

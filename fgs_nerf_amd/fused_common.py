@@ -577,6 +577,33 @@ def set_loss_spec(model, target, loss_cfg, seed=None) -> None:
     cache['loss_spec'] = dict(target=target, w5=w5, w5_key=tuple(float(v) for v in w5), seed=seed)
 
 
+def _composite(run, needs_grad, N, M, surv_off, weights, rgb, normal, step_id, alphainv_last, rgb_marched, sigmoid_rgb, pre_rgb,
+               pre_sig, normal_marched, depth):
+    """Compositing of a fused forward pass (both stages).  With an announced loss (set_loss_spec) whose target fits the batch: ONE
+    launch for compositing + the loss terms + their gradients + the compositing backward (fgs_fine_render_loss), and the stash the
+    loss node and the backward pass pick up; otherwise fgs_composite_fwd (returns None)."""
+    dev, st = weights.device, stream()
+    spec = run.cache.get('loss_spec')
+    if (spec is not None and needs_grad and M > 0 and spec['target'].shape == (N, 3) and spec['target'].is_cuda
+            and spec['target'].is_contiguous() and spec['target'].dtype == F32):
+        from .losses import _loss_scratch
+        fl = dict(loss=torch.empty((), dtype=F32, device=dev), d_out=torch.empty(M, 3, dtype=F32, device=dev),
+                  d_w=torch.empty(M, dtype=F32, device=dev), g_normal=torch.empty(M, 3, dtype=F32, device=dev),
+                  g_last=torch.empty(N, dtype=F32, device=dev), g_rm=torch.empty(N, 3, dtype=F32, device=dev),
+                  target_ptr=spec['target'].data_ptr(), w5_key=spec['w5_key'], used=False,
+                  seed_ptr=None if spec['seed'] is None else spec['seed'].data_ptr())
+        scratch = _loss_scratch(dev, (N + 3) // 4 + 1)
+        call("fgs_fine_render_loss", N, M, ptr(surv_off), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg,
+             run.dist, ptr(run.viewdirs), ptr(spec['target']), ptr(alphainv_last), spec['w5'], ptr(spec['seed']),
+             ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), ptr(fl['loss']),
+             ptr(scratch), scratch.numel(), ptr(fl['d_out']), ptr(fl['d_w']), ptr(fl['g_normal']), ptr(fl['g_last']),
+             ptr(fl['g_rm']), dyn(row_count=_rows(run)), st)
+        return fl
+    call("fgs_composite_fwd", N, ptr(surv_off), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
+         ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
+    return None
+
+
 def disable_early_update(model, averager=None) -> None:
     model.__dict__.setdefault('_fused_cache', {}).pop('opt_hook', None)
     if averager is not None:

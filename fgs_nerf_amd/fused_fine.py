@@ -431,28 +431,8 @@ class _FusedFine(torch.autograd.Function):
         pre_sig = torch.empty(N, 3, dtype=F32, device=dev)
         normal_marched = torch.empty(N, 3, dtype=F32, device=dev) if run.render_grad else None
         depth = torch.empty(N, dtype=F32, device=dev) if run.render_depth else None
-        spec = run.cache.get('loss_spec')
-        fused_loss = None
-        if (spec is not None and any(ctx.needs_input_grad) and M > 0 and spec['target'].shape == (N, 3) and spec['target'].is_cuda
-                and spec['target'].is_contiguous() and spec['target'].dtype == F32):
-            # compositing + the announced loss + its gradients + the compositing backward: one launch (fused_common.set_loss_spec)
-            from .losses import _loss_scratch
-            fl = dict(loss=torch.empty((), dtype=F32, device=dev), d_out=torch.empty(M, 3, dtype=F32, device=dev),
-                      d_w=torch.empty(M, dtype=F32, device=dev), g_normal=torch.empty(M, 3, dtype=F32, device=dev),
-                      g_last=torch.empty(N, dtype=F32, device=dev), g_rm=torch.empty(N, 3, dtype=F32, device=dev),
-                      target_ptr=spec['target'].data_ptr(), w5_key=spec['w5_key'], used=False,
-                      seed_ptr=None if spec['seed'] is None else spec['seed'].data_ptr())
-            scratch = _loss_scratch(dev, (N + 3) // 4 + 1)
-            call("fgs_fine_render_loss", N, M, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg,
-                 run.dist, ptr(run.viewdirs), ptr(spec['target']), ptr(alphainv_last), spec['w5'], ptr(spec['seed']),
-                 ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), ptr(fl['loss']),
-                 ptr(scratch), scratch.numel(), ptr(fl['d_out']), ptr(fl['d_w']), ptr(fl['g_normal']), ptr(fl['g_last']),
-                 ptr(fl['g_rm']), dyn(row_count=_rows(run)), st)
-            fused_loss = fl
-        else:
-            call("fgs_composite_fwd", N, ptr(ws['surv_off']), ptr(weights), ptr(rgb), ptr(normal), ptr(step_id), run.bg, run.dist,
-                 ptr(rgb_marched), ptr(sigmoid_rgb), ptr(pre_rgb), ptr(pre_sig), ptr(normal_marched), ptr(depth), st)
-        run.fused_loss = fused_loss
+        run.fused_loss = _composite(run, any(ctx.needs_input_grad), N, M, ws['surv_off'], weights, rgb, normal, step_id, alphainv_last,
+                                    rgb_marched, sigmoid_rgb, pre_rgb, pre_sig, normal_marched, depth)
         # The big zero fills of the backward pass are issued HERE: when loss.backward() starts, the autograd engine needs
         # ~90 us of host time before its first launch and the GPU would sit idle; now it spends that gap on the fills.
         run.pre = None

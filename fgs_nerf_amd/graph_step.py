@@ -370,6 +370,17 @@ class CapturedFineStep:
         self.viewdirs.copy_(vd, non_blocking=True)
         self.target.copy_(target, non_blocking=True)
 
+    def load_selected(self, sel: torch.Tensor, rays_o_src, rays_d_src, viewdirs_src, target_src) -> None:
+        """The batch `src[sel]` of four flat [R,3] float32 device tensors straight into the static inputs: one launch instead of
+        four gathers and four copies (model/nerf_training.py:256-261)."""
+        srcs = (rays_o_src, rays_d_src, viewdirs_src, target_src)
+        R = int(rays_o_src.shape[0])
+        if not (sel.is_cuda and sel.dtype == torch.int64 and sel.is_contiguous() and sel.numel() == self.inputs.shape[1]
+                and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (R, 3) for t in srcs)):
+            self.load(tuple(t[sel] for t in srcs))
+            return
+        call("fgs_gather_batch", ptr(sel), int(sel.numel()), R, *(ptr(t) for t in srcs), ptr(self.inputs), stream())
+
     def replay(self, batch: Optional[Sequence[torch.Tensor]] = None, variant: int = 0) -> torch.Tensor:
         """One training iteration: (optionally) copy the batch into the static inputs, launch the graph (of `variant`).
         Returns the device scalar holding this iteration's loss (overwritten by the next replay of the same variant)."""

@@ -93,11 +93,12 @@ class _FineLoss(torch.autograd.Function):
         return g_rm, g_sr, g_last, g_normal, g_raw, None, None, None, None, None, None
 
 
-UNIT_SEEDS = set()       # data_ptr()s of device scalars known to hold 1.0 (bench.py / CapturedFineStep pass them to loss.backward)
+UNIT_SEEDS = {}          # data_ptr() -> device scalar known to hold 1.0 (bench.py / CapturedFineStep pass them to loss.backward).
+                         # The tensors are KEPT: a freed seed's address would be handed to some other gradient scalar.
 
 
 def register_unit_seed(t: torch.Tensor) -> torch.Tensor:
-    UNIT_SEEDS.add(t.data_ptr())
+    UNIT_SEEDS[t.data_ptr()] = t
     return t
 
 

@@ -147,12 +147,14 @@ class TrainStepper:
         ct = self.cfg_train
         return ct.tv_from < global_step < ct.tv_end and global_step % ct.tv_every == 0
 
-    def _select_rays(self):
+    def _select_indices(self) -> torch.Tensor:
         ct = self.cfg_train
         if ct.get('ray_sampler', 'flatten') == 'random':   # flat equivalent of the reference's [B,H,W] triple randint
-            sel = torch.randint(len(self.rgb_tr), [ct.N_rand], generator=self._rand, device=self.rgb_tr.device)
-        else:
-            sel = self.sampler()
+            return torch.randint(len(self.rgb_tr), [ct.N_rand], generator=self._rand, device=self.rgb_tr.device)
+        return self.sampler()
+
+    def _select_rays(self):
+        sel = self._select_indices()
         return self.rgb_tr[sel], self.rays_o_tr[sel], self.rays_d_tr[sel], self.viewdirs_tr[sel]
 
     # ------------------------------------------------------------------------------------------------ one iteration
@@ -413,10 +415,9 @@ class TrainStepper:
         cap.capture(batch)               # AccumulateGrad nodes, bound to the default stream -- alive across the capture)
         losses = torch.empty(n_steps, dtype=torch.float32, device=self.rgb_tr.device)
         for i in range(n_steps):
-            if i:
-                t, ro, rd, vd = self._select_rays()
-                batch = (ro, rd, vd, t)
-            losses[i:i + 1].copy_(cap.replay(batch, variant=which[i]).detach().reshape(1))
+            if i:          # (iteration 0's batch was loaded by capture())
+                cap.load_selected(self._select_indices(), self.rays_o_tr, self.rays_d_tr, self.viewdirs_tr, self.rgb_tr)
+            losses[i:i + 1].copy_(cap.replay(None if i else batch, variant=which[i]).detach().reshape(1))
         for g in opt.param_groups:                                  # the host's copy of the schedule catches up
             g['lr'] = base_lr[id(g)] * factors[-1]
         overflow, _ = cap.check()

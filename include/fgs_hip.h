@@ -150,6 +150,12 @@ int fgs_sample_emit(const float *rays_o, const float *rays_d, const float *xyz_m
                     int64_t capacity, float *rays_pts, uint8_t *mask_outbbox, int64_t *ray_id, int64_t *step_id,
                     fgs_stream_t stream);
 
+/* The batch selection of a training iteration (model/nerf_training.py:256-261: rgb_tr[sel], rays_o_tr[sel], rays_d_tr[sel],
+ * viewdirs_tr[sel] -- four advanced-indexing gathers) in one launch: out[a][i][:] = src_a[sel[i]][:], out [4][n][3], src_a
+ * [n_src][3], sel device int64 (clamped into range). */
+int fgs_gather_batch(const int64_t *sel, int64_t n, int64_t n_src, const float *src0, const float *src1, const float *src2,
+                     const float *src3, float *out, fgs_stream_t stream);
+
 /* sample_ndc_pts_on_rays -- render_utils_kernel.cu:244-293 */
 int fgs_sample_ndc_pts(const float *rays_o, const float *rays_d, const float *xyz_min, const float *xyz_max,
                        int64_t n_samples, int64_t n_rays, float *rays_pts, uint8_t *mask_outbbox, fgs_stream_t stream);

@@ -186,3 +186,19 @@ def test_maskcache_ray_prefilter_on_the_device_matches_reference_fixture(dev, go
     assert ro.is_cuda and rgb_tr.is_cuda
     for got, key in ((rgb_tr, "rgb_tr"), (ro, "rays_o_tr"), (rd, "rays_d_tr"), (vd, "viewdirs_tr")):
         assert np.array_equal(got.cpu().numpy(), g[key]), key
+
+
+def test_batch_gather_in_one_launch(dev):
+    """fgs_gather_batch == the four advanced-indexing gathers of model/nerf_training.py:256-261 (bit-exact: copies), through
+    CapturedFineStep.load_selected's argument order (rays_o, rays_d, viewdirs, target -> inputs[0..3])."""
+    import torch
+    from fgs_nerf_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(4)
+    R, n = 50000, 8192
+    srcs = [torch.randn(R, 3, generator=g).to(dev) for _ in range(4)]
+    sel = torch.randperm(R, generator=g)[:n].to(dev)
+    out = torch.full((4, n, 3), float('nan'), device=dev)
+    call("fgs_gather_batch", ptr(sel), n, R, *(ptr(t) for t in srcs), ptr(out), stream())
+    torch.cuda.synchronize()
+    for a in range(4):
+        assert torch.equal(out[a], srcs[a][sel])

@@ -124,3 +124,41 @@ def test_training_step_with_announced_loss_matches_the_separate_launches(dev):
     assert abs(ld - le) <= 1e-6 * abs(le)
     for d, e in zip(gd, ge):
         assert rel_l2(d, e) < 2e-6
+
+
+def test_coarse_step_with_announced_loss_matches_the_separate_launches(dev):
+    """The same hand-over in the coarse stage's fused forward / backward pass (fused_coarse.py through fused_common._composite)."""
+    from conftest import rel_l2
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.fused import set_loss_spec
+    from fgs_nerf_amd.losses import fused_render_losses, register_unit_seed
+    n_rays = 1024
+    model = synth.build_model(96, synth.COARSE_MODEL, device=dev)
+    ro, rd, vd = (t[:n_rays].contiguous().to(dev) for t in synth.random_rays(4096, seed=synth.SEED))
+    target = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(12)).to(dev)
+    lossw = dict(synth.COARSE_LOSS, weight_rgbper=0.2, weight_orientation=1e-4)
+    params = [p for p in model.parameters() if p.requires_grad]
+    seed = register_unit_seed(torch.ones((), device=dev))
+
+    def step(announce):
+        for p in params:
+            p.grad = None
+        set_loss_spec(model, target if announce else None, lossw)
+        res = model(ro, rd, vd, global_step=700, **synth.RENDER_KWARGS)
+        loss = fused_render_losses(res, target, lossw, model)
+        taken = res.get('_fused_loss') is not None and res.get('_fused_loss')['used']
+        loss.backward(seed)
+        set_loss_spec(model, None, lossw)
+        return float(loss.detach()), [None if p.grad is None else p.grad.detach().clone() for p in params], taken
+
+    la, ga, taken_a = step(False)
+    lb, gb, taken_b = step(True)
+    assert taken_b and not taken_a
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    n_cmp = 0
+    for a, b, p in zip(ga, gb, params):
+        assert (a is None) == (b is None)
+        if a is not None and float(a.norm()) > 0:
+            assert rel_l2(b, a) < 2e-6, (tuple(p.shape), rel_l2(b, a))
+            n_cmp += 1
+    assert n_cmp >= 4
