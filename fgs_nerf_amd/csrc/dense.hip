@@ -133,9 +133,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restr
   }
   __syncthreads();
   if (!is_last) return;
-  double t = 0.0;
-  for (unsigned b = threadIdx.x; b < n_wg; b += FGS_BLOCK)
-    t += (double)__hip_atomic_load(tv.partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double t = fgs_partials_sum<float, double>(tv.partials, threadIdx.x, n_wg, FGS_BLOCK);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
   __shared__ double fpart[FGS_BLOCK / FGS_WAVE];

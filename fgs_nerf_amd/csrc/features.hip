@@ -149,10 +149,12 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
                                                              const float *__restrict__ tot_grad,
                                                              float *__restrict__ sdf_grad_grid, int prio) {
   fgs_setprio(prio);      // (FGS_PRIO_TAPS_BWD: the kernel runs beside k_mlp_wgrad, see fused.py _wgrad)
-  S.M = fgs_rows(S.M, S.m_dev);
+  // (S is only read: a kernel-argument struct that is written to AND indexed with a run-time index -- disp[j % K] -- is copied
+  // to scratch memory, 232 bytes per lane, and every later field access becomes a scratch load)
+  const int64_t M_rows = fgs_rows(S.M, S.m_dev);
   // (launched for a CAPACITY of rows under a device-side count: workgroups wholly beyond the count leave before they clear,
   // walk and flush their bricks -- 14 us of a 110 us launch at capacity = 1.5 x count)
-  if ((int64_t)blockIdx.x * (FGS_BLOCK / 32) * TAPS_GROUP >= S.M) return;
+  if ((int64_t)blockIdx.x * (FGS_BLOCK / 32) * TAPS_GROUP >= M_rows) return;
   __shared__ float brick_all[FGS_BLOCK / 32][BRICK * BRICK * BRICK];
   const int64_t m_first = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5) * TAPS_GROUP;
   const int j = threadIdx.x & 31;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
   const GridDesc gd = fgs_sdf_desc(S.geom);
   float *brick = brick_all[threadIdx.x >> 5];
   int bx0 = 0, by0 = 0, bz0 = 0;
-  if (m_first < S.M) {
+  if (m_first < M_rows) {
     const PointIdx p0 = fgs_point_to_index(S.pts[3 * m_first], S.pts[3 * m_first + 1], S.pts[3 * m_first + 2], S.geom.lo,
                                            S.geom.hi, gd);
     bx0 = (int)fgs_safe_floor(p0.fx) - BRICK_LO;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
   __syncthreads();
   for (int gi = 0; gi < TAPS_GROUP; ++gi) {
     const int64_t m = m_first + gi;
-    const bool row_ok = m < S.M;
+    const bool row_ok = m < M_rows;
     const bool tap_lane = row_ok && j < 6 * K;
     float f = 0.f, cl = 0.f, d_f = 0.f;
     TapPoint tp = {0.f, 0.f, 0.f, 0.f};
@@ -263,14 +265,15 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_taps_bwd(SurvArgs S, const f
         if (dgax != 0.f) {
           const TapPoint tm = fgs_tap_point(pc, gd, 2 * ax, 1.0f), tq = fgs_tap_point(pc, gd, 2 * ax + 1, 1.0f);
           const float cf = (dgax / S.geom.voxel_size) / (tq.clamped - tm.clamped);
-          const TapPoint &tt = (pr & 1) ? tq : tm;
-          brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd, fgs_tri_setup(tt.fx, tt.fy, tt.fz), (pr & 1) ? cf : -cf);
+          const bool hi = pr & 1;
+          brick_scatter(brick, bx0, by0, bz0, sdf_grad_grid, gd,
+                        fgs_tri_setup(hi ? tq.fx : tm.fx, hi ? tq.fy : tm.fy, hi ? tq.fz : tm.fz), hi ? cf : -cf);
         }
       }
     }
   }
   __syncthreads();
-  if (m_first < S.M) {
+  if (m_first < M_rows) {
     for (int e = j; e < BRICK * BRICK * BRICK; e += 32) {  // consecutive lanes = consecutive z of one (x,y) row
       const float v = brick[e];
       if (v == 0.f) continue;
@@ -296,61 +299,80 @@ __device__ __forceinline__ Normal3 normal_of(float gx, float gy, float gz) {
   return o;
 }
 
-// 32 lanes per survivor.  The 3 (F_pos + F_view + F_ref) sin/cos pairs of a row are dealt round-robin to the lanes (two
-// sincosf per lane for the fine layout instead of a chain of eight), consecutive lanes write consecutive columns; the raw
-// components, the normal and the scalar columns are written by the first lanes / the last lane.
+// 64 survivors per workgroup, two phases.  Phase 1, one lane per survivor (the first wavefront): the normal, the scaled
+// position and the reflection direction -- two square roots and nine correctly rounded divisions -- once per survivor, into LDS;
+// normal_out is written from here.  Phase 2, all four wavefronts over the flat list of (survivor, item) pairs, consecutive
+// lanes = consecutive items of one survivor = consecutive columns: an item is one (sin, cos) pair of the 3 (F_pos + F_view +
+// F_ref) the row holds, or one of the raw / scalar / padding columns.  (Until round 4: 32 lanes per survivor, every lane
+// repeating phase 1 -- ~200 of the ~400 vector instructions a wavefront issued for TWO survivors; a wave64 instruction
+// occupies its SIMD for four cycles, and the kernel was bound by exactly that: 32 us per 57 K survivors, 154 us per 354 K.)
+constexpr int ENC_SV = 64;        // survivors per workgroup
+constexpr int ENC_LD = 17;        // floats per survivor in LDS: u[3] v[3] refl[3] col_grad[3] sdf, pad (odd pitch)
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_fwd(SurvArgs S, float *X0, float *Z /* == X0 in coarse mode */,
                                                             float *__restrict__ normal_out) {
-  S.M = fgs_rows(S.M, S.m_dev);
-  const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  const int j = threadIdx.x & 31;
-  if (m >= S.M) return;
+  const int64_t M = fgs_rows(S.M, S.m_dev);
+  const int64_t m0 = (int64_t)blockIdx.x * ENC_SV;
+  if (m0 >= M) return;
   const FeatLayout &L = S.L;
-  float *x0 = X0 + m * L.ldx0;
-  float *zr = Z + m * L.ldz;
-  const int64_t r = S.ray_id[m];
-  const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
-  const float g[3] = {S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]};
-  const Normal3 nn = normal_of(g[0], g[1], g[2]);
-  const float dot = (v[0] * nn.n[0] + v[1] * nn.n[1]) + v[2] * nn.n[2];
-  float u[3], refl[3];
+  __shared__ float sv[ENC_SV * ENC_LD];
+  const int n_here = (int)((M - m0 < ENC_SV) ? (M - m0) : ENC_SV);
+  if (threadIdx.x < n_here) {
+    const int64_t m = m0 + threadIdx.x;
+    const int64_t r = S.ray_id[m];
+    const float v[3] = {S.viewdirs[3 * r], S.viewdirs[3 * r + 1], S.viewdirs[3 * r + 2]};
+    const float g[3] = {S.gradient[3 * m], S.gradient[3 * m + 1], S.gradient[3 * m + 2]};
+    const Normal3 nn = normal_of(g[0], g[1], g[2]);
+    const float dot = (v[0] * nn.n[0] + v[1] * nn.n[1]) + v[2] * nn.n[2];
+    float *o = sv + threadIdx.x * ENC_LD;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    u[c] = (S.pts[3 * m + c] - S.geom.lo[c]) / (S.geom.hi[c] - S.geom.lo[c]);   // rays_xyz, model/nerf.py:837
-    refl[c] = v[c] - (2.f * dot) * nn.n[c];                                     // model/nerf.py:879
+    for (int c = 0; c < 3; ++c) {
+      o[c] = (S.pts[3 * m + c] - S.geom.lo[c]) / (S.geom.hi[c] - S.geom.lo[c]);   // rays_xyz, model/nerf.py:837
+      o[3 + c] = v[c];
+      o[6 + c] = v[c] - (2.f * dot) * nn.n[c];                                    // model/nerf.py:879
+      o[9 + c] = L.coarse ? nn.n[c] : g[c];
+      normal_out[3 * m + c] = nn.n[c];
+    }
+    o[12] = L.center_sdf ? S.sdf[m] : 0.f;
   }
+  __syncthreads();
   const int Fp = L.n_posfreq, Fv = L.use_viewdir ? L.n_viewfreq : 0, Fr = L.n_reffreq;
   const int n_pairs = 3 * (Fp + Fv + Fr);
-  for (int p = j; p < n_pairs; p += 32) {
-    int q = p, F = Fp;
-    float *row = x0 + L.off_xyz;
-    const float *src = u;
-    if (q >= 3 * Fp) {
-      q -= 3 * Fp; F = Fv; row = x0 + L.off_view; src = v;
-      if (q >= 3 * Fv) { q -= 3 * Fv; F = Fr; row = zr + L.off_ref; src = refl; }
+  // raw items behind the pairs: u[3], v[3] (when used), refl[3], the gradient / normal columns [3], sdf (when used), the padding
+  // columns of X0 and (fine layout) of Z
+  const int pad_x = L.ldx0 - L.x0_cols, pad_z = L.coarse ? 0 : L.ldz - L.z_cols;
+  const int n_items = n_pairs + 13 + pad_x + pad_z;
+  const float inv_items = 1.f / (float)n_items;
+  const int total = n_here * n_items;
+  for (int i = threadIdx.x; i < total; i += FGS_BLOCK) {
+    int ml = (int)(((float)i + 0.5f) * inv_items);           // i / n_items (i < 2^16: the estimate is off by at most one)
+    int p = i - ml * n_items;
+    if (p < 0) { --ml; p += n_items; }
+    if (p >= n_items) { ++ml; p -= n_items; }
+    const float *o = sv + ml * ENC_LD;
+    float *x0 = X0 + (m0 + ml) * L.ldx0;
+    float *zr = Z + (m0 + ml) * L.ldz;
+    if (p < n_pairs) {
+      int q = p, F = Fp, set = 0;
+      float *row = x0 + L.off_xyz;
+      if (q >= 3 * Fp) {
+        q -= 3 * Fp; F = Fv; row = x0 + L.off_view; set = 3;
+        if (q >= 3 * Fv) { q -= 3 * Fv; F = Fr; row = zr + L.off_ref; set = 6; }
+      }
+      const int c = q / F, f = q - c * F;
+      float sn, cs;
+      sincosf(o[set + c] * (float)(1 << f), &sn, &cs);     // freq = 2^f exactly, as the repeated doubling gives
+      row[3 + c * F + f] = sn;
+      row[3 + 3 * F + c * F + f] = cs;
+      continue;
     }
-    const int c = q / F, f = q - c * F;
-    const float x = (c == 0) ? src[0] : (c == 1 ? src[1] : src[2]);
-    float sn, cs;
-    sincosf(x * (float)(1 << f), &sn, &cs);     // freq = 2^f exactly, as the repeated doubling gives
-    row[3 + c * F + f] = sn;
-    row[3 + 3 * F + c * F + f] = cs;
-  }
-  if (j < 3) {
-    x0[L.off_xyz + j] = (j == 0) ? u[0] : (j == 1 ? u[1] : u[2]);
-    normal_out[3 * m + j] = (j == 0) ? nn.n[0] : (j == 1 ? nn.n[1] : nn.n[2]);
-  } else if (j < 6) {
-    if (L.use_viewdir) x0[L.off_view + (j - 3)] = (j == 3) ? v[0] : (j == 4 ? v[1] : v[2]);
-  } else if (j < 9) {
-    zr[L.off_ref + (j - 6)] = (j == 6) ? refl[0] : (j == 7 ? refl[1] : refl[2]);
-  } else if (j == 31) {  // scalar features and zero padding
-    if (L.center_sdf) x0[L.off_sdf] = S.sdf[m];
-    x0[L.off_grad + 0] = L.coarse ? nn.n[0] : g[0];
-    x0[L.off_grad + 1] = L.coarse ? nn.n[1] : g[1];
-    x0[L.off_grad + 2] = L.coarse ? nn.n[2] : g[2];
-    for (int c = L.x0_cols; c < L.ldx0; ++c) x0[c] = 0.f;
-    if (!L.coarse)
-      for (int c = L.z_cols; c < L.ldz; ++c) zr[c] = 0.f;
+    const int e = p - n_pairs;
+    if (e < 3) x0[L.off_xyz + e] = o[e];
+    else if (e < 6) { if (L.use_viewdir) x0[L.off_view + (e - 3)] = o[e]; }
+    else if (e < 9) zr[L.off_ref + (e - 6)] = o[e];
+    else if (e < 12) x0[L.off_grad + (e - 9)] = o[e];
+    else if (e == 12) { if (L.center_sdf) x0[L.off_sdf] = o[12]; }
+    else if (e < 13 + pad_x) x0[L.x0_cols + (e - 13)] = 0.f;
+    else zr[L.z_cols + (e - 13 - pad_x)] = 0.f;
   }
 }
 
@@ -432,37 +454,64 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_enc_bwd(SurvArgs S, const fl
 }
 
 // ------------------------------------------------------------------------- 3-wide output head (refnet last Linear)
-// out = R3 . V4^T + c4 ; rgb = sigmoid(out).  One wavefront per row, lane l owns columns 4l..4l+3 (W <= 256).
+// out = R3 . V4^T + c4 ; rgb = sigmoid(out).  16 lanes per row, four rows per wavefront and pass, two passes in flight: lane l
+// of a row's group owns columns 4l + 64j (j < 4, W <= 256), the three dot products are summed over the 16 lanes of a DPP row
+// with quad_perm / row_half_mirror / row_mirror adds -- no LDS traffic.  (Until round 4 one wavefront per row: one 16-byte load
+// per lane and 18 ds_bpermute per row, a chain of dependent latencies: 91 us for 354 K rows of 192, 3 TB/s.)
+__device__ __forceinline__ float head_row16_sum(float v) {
+  // lanes of a DPP row (16): quad sums, then the other quad of the half (i <-> 7 - i), then the other half (i <-> 15 - i)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 __global__ __launch_bounds__(FGS_BLOCK) void k_head_fwd(const float *__restrict__ R, int64_t ldr, int W, int64_t M,
                                                         const float *__restrict__ V, const float *__restrict__ bias,
                                                         float *__restrict__ rgb, const int64_t *__restrict__ m_dev) {
   M = fgs_rows(M, m_dev);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, l = lane & 15, g = lane >> 4;
   const int64_t wave = (int64_t)blockIdx.x * (FGS_BLOCK / FGS_WAVE) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (FGS_BLOCK / FGS_WAVE);
-  const bool col_ok = 4 * lane < W;
-  float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0;
-  if (col_ok) {
-    w0 = *reinterpret_cast<const float4 *>(V + 0 * W + 4 * lane);
-    w1 = *reinterpret_cast<const float4 *>(V + 1 * W + 4 * lane);
-    w2 = *reinterpret_cast<const float4 *>(V + 2 * W + 4 * lane);
-  }
-  for (int64_t m = wave; m < M; m += n_waves) {
-    float4 x = make_float4(0, 0, 0, 0);
-    if (col_ok) x = *reinterpret_cast<const float4 *>(R + m * ldr + 4 * lane);
-    float a0 = ((x.x * w0.x + x.y * w0.y) + x.z * w0.z) + x.w * w0.w;
-    float a1 = ((x.x * w1.x + x.y * w1.y) + x.z * w1.z) + x.w * w1.w;
-    float a2 = ((x.x * w2.x + x.y * w2.y) + x.z * w2.z) + x.w * w2.w;
+  float4 w[3][4];
+  bool ok[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a0 += __shfl_xor(a0, off, 64);
-      a1 += __shfl_xor(a1, off, 64);
-      a2 += __shfl_xor(a2, off, 64);
+  for (int j = 0; j < 4; ++j) {
+    ok[j] = 4 * l + 64 * j < W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      w[c][j] = ok[j] ? *reinterpret_cast<const float4 *>(V + c * W + 4 * l + 64 * j) : make_float4(0, 0, 0, 0);
+  }
+  const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+  constexpr int PASSES = 2;
+  for (int64_t mb = wave * 4; mb < M; mb += n_waves * 4 * PASSES) {
+    float4 x[PASSES][4];
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int64_t m = mb + u * n_waves * 4 + g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        x[u][j] = (m < M && ok[j]) ? *reinterpret_cast<const float4 *>(R + m * ldr + 4 * l + 64 * j) : make_float4(0, 0, 0, 0);
     }
-    if (lane == 0) {
-      rgb[3 * m + 0] = 1.f / (1.f + expf(-(a0 + bias[0])));
-      rgb[3 * m + 1] = 1.f / (1.f + expf(-(a1 + bias[1])));
-      rgb[3 * m + 2] = 1.f / (1.f + expf(-(a2 + bias[2])));
+#pragma unroll
+    for (int u = 0; u < PASSES; ++u) {
+      const int64_t m = mb + u * n_waves * 4 + g;
+      float a[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // (the order of the old kernel inside a lane's four columns; across lanes the sum order differs: float rounding only)
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          t += ((x[u][j].x * w[c][j].x + x[u][j].y * w[c][j].y) + x[u][j].z * w[c][j].z) + x[u][j].w * w[c][j].w;
+        a[c] = head_row16_sum(t);
+      }
+      if (l == 0 && m < M) {
+        rgb[3 * m + 0] = 1.f / (1.f + expf(-(a[0] + b0)));
+        rgb[3 * m + 1] = 1.f / (1.f + expf(-(a[1] + b1)));
+        rgb[3 * m + 2] = 1.f / (1.f + expf(-(a[2] + b2)));
+      }
     }
   }
 }
@@ -769,7 +818,7 @@ FGS_API int fgs_feat_coarse_fwd(int64_t M, const int64_t *ray_id, const float *p
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   hipLaunchKernelGGL(k_feat_k0_fwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grid, kd, X0);
   FGS_LAUNCH_OK("fgs_feat_coarse_fwd/k0");
-  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, X0, normal_out);
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M, ENC_SV)), dim3(FGS_BLOCK), 0, st, S, X0, X0, normal_out);
   FGS_LAUNCH_OK("fgs_feat_coarse_fwd/enc");
   return 0;
 }
@@ -825,7 +874,7 @@ FGS_API int fgs_feat_fine_fwd(int64_t M, const int64_t *ray_id, const float *pts
     hipLaunchKernelGGL(k_feat_taps_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, sdf_grid, X0);
     FGS_LAUNCH_OK("fgs_feat_fine_fwd/taps");
   }
-  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M * 32)), dim3(FGS_BLOCK), 0, st, S, X0, Zbuf, normal_out);
+  hipLaunchKernelGGL(k_feat_enc_fwd, dim3(fgs_blocks(M, ENC_SV)), dim3(FGS_BLOCK), 0, st, S, X0, Zbuf, normal_out);
   FGS_LAUNCH_OK("fgs_feat_fine_fwd/enc");
   return 0;
 }
@@ -892,8 +941,8 @@ FGS_API int fgs_head_fwd(const float *R, int64_t ldr, int W, int64_t M, const fl
               "fgs_head_fwd: M=%lld W=%d ldr=%lld (W <= 256, multiples of 4)", (long long)M, W, (long long)ldr);
   if (M == 0) return 0;
   FGS_REQUIRE(R && V && bias && rgb, FGS_E_INVALID, "fgs_head_fwd: null pointer");
-  const int64_t want = (M + 3) / 4;
-  const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  const int64_t want = (M + 31) / 32;            // a workgroup takes 4 waves x 4 rows x 2 passes per trip
+  const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
   hipLaunchKernelGGL(k_head_fwd, dim3(blocks), dim3(FGS_BLOCK), 0, fgs_s(stream), R, ldr, W, M, V, bias, rgb, fgs_dyn_rows(dyn));
   FGS_LAUNCH_OK("fgs_head_fwd");
   return 0;

@@ -92,6 +92,24 @@ __device__ __forceinline__ bool fgs_arrive_is_last(unsigned *counter, unsigned n
   return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_workgroups - 1;
 }
 
+// ... and the reading side: sum of p[first], p[first + stride], ... (index < n) in index order, the agent-scope loads issued eight at
+// a time before the first addition (one at a time, each a ~1 us round trip to memory, they were 30 of a 37 us launch).
+template <typename T, typename ACC = T>
+__device__ __forceinline__ ACC fgs_partials_sum(const T *p, unsigned first, unsigned n, unsigned stride) {
+  ACC acc = (ACC)0;
+  for (unsigned b = first; b < n; b += 8 * stride) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned i = b + u * stride;
+      v[u] = i < n ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (ACC)v[u];
+  }
+  return acc;
+}
+
 // s_setprio with a run-time (wave-uniform) level: the instruction takes an immediate.
 __device__ __forceinline__ void fgs_setprio(int p) {
   if (p == 1) __builtin_amdgcn_s_setprio(1);

@@ -109,9 +109,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_loss_fwd(LossArgs L, float *loss,
   }
   __syncthreads();
   if (!is_last) return;
-  float v = 0.f;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += FGS_BLOCK)
-    v += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float v = fgs_partials_sum<float>(partials, threadIdx.x, gridDim.x, FGS_BLOCK);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   __syncthreads();
@@ -325,9 +323,7 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_render_loss(RenderLossArgs A, flo
   }
   __syncthreads();
   if (!is_last) return;
-  float v = 0.f;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += FGS_BLOCK)
-    v += __hip_atomic_load(partials + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (agent scope: not from this XCD's L2)
+  float v = fgs_partials_sum<float>(partials, threadIdx.x, gridDim.x, FGS_BLOCK);      // (agent scope: not from this XCD's L2)
   v = rl_wave_sum(v);
   __syncthreads();
   if (lane == 0) part[wv] = v;

@@ -112,21 +112,18 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__rest
   if (threadIdx.x == 0) is_last = fgs_arrive_is_last(counter, gridDim.x) ? 1 : 0;
   __syncthreads();
   if (!is_last) return;
-  // 7 x 32 threads: thread (k, j) sums partials b = j, j + 32, ... of sum k; then the 32 in order
-  __shared__ double fin_part[7][32];
-  if (threadIdx.x < 7 * 32) {
-    const int k = threadIdx.x >> 5, j = threadIdx.x & 31;
-    double t = 0.0;
-    for (unsigned b = j; b < gridDim.x; b += 32)
-      t += __hip_atomic_load(partials + 7 * (int64_t)b + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fin_part[k][j] = t;
+  // 7 x 36 threads: thread (k, j) sums partials b = j, j + 36, ... of sum k; then the 36 in order
+  __shared__ double fin_part[7][36];
+  if (threadIdx.x < 7 * 36) {
+    const unsigned k = threadIdx.x % 7u, j = threadIdx.x / 7u;
+    fin_part[k][j] = fgs_partials_sum<double>(partials + k, 7u * j, 7u * gridDim.x, 7u * 36u);
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
   double S[7];
   for (int k = 0; k < 7; ++k) {
     double t = 0.0;
-    for (int j = 0; j < 32; ++j) t += fin_part[k][j];
+    for (int j = 0; j < 36; ++j) t += fin_part[k][j];
     S[k] = t;
     if (fin.sums_out) fin.sums_out[k] = t;
   }
@@ -198,7 +195,7 @@ int tv_grid(const char *who, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t
 
 // Value pass (see include/fgs_hip.h).  scratch: 8-byte aligned, >= 1 + 7 * FGS_TV_VALUE_WGS doubles, first word zero when first
 // handed in (left zero).
-constexpr unsigned FGS_TV_VALUE_WGS = 1024;
+constexpr unsigned FGS_TV_VALUE_WGS = 1024;     // (4 per CU: the pass is a chain of dependent cache hits per element -- latency, not bytes)
 FGS_API int64_t fgs_tv_loss_scratch_doubles(void) { return 1 + 7 * (int64_t)FGS_TV_VALUE_WGS; }
 
 FGS_API int fgs_tv_loss_value(const float *v, const unsigned char *mask, int64_t C, int64_t X, int64_t Y, int64_t Z, int64_t sC,
