@@ -56,18 +56,35 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const flo
   X0[m * S.L.ldx0 + S.L.off_k0 + c] = fgs_tri_sample(k0, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz));
 }
 
+// One thread per (survivor, z corner, channel), four atomics each -- the (x, y) corners.  Float atomics execute at the memory
+// side and are priced per 64-byte request (MI355X_MICROARCH.md, global float atomics: ~20 G requests/s chip-wide): with the two z
+// corners of an (x, y) pair in ONE wave-instruction their 2 x C contiguous floats (96 bytes at C = 12, channel-last grid) leave as
+// 2.25 requests on average instead of 2 x 1.5 -- the kernel runs at that request rate, nothing else (12 requests per survivor
+// before: 57 K survivors 45 us, 354 K 277 us).
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__restrict__ k0_grad, GridDesc kd,
                                                            const float *__restrict__ dX0) {
   __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
                                      // the vector pipe: this memory-bound kernel's few vector instructions go first
-  S.M = fgs_rows(S.M, S.m_dev);
+  const int64_t M = fgs_rows(S.M, S.m_dev);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= S.M * kd.C) return;
-  const int64_t m = surv_of(tid, S.M, kd.C), c = tid - m * kd.C;
+  const int64_t C2 = 2 * kd.C;
+  if (tid >= M * C2) return;
+  const int64_t m = surv_of(tid, M, C2);
+  const int rem = (int)(tid - m * C2);
+  const int zc = rem >= (int)kd.C ? 1 : 0, c = rem - zc * (int)kd.C;
   const float g = dX0[m * S.L.dx_ld + S.L.off_k0 + c];
   if (g == 0.f) return;
   const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
-  fgs_tri_scatter(k0_grad, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz), g);
+  const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
+  const int z = t.z0 + zc;
+  if (!fgs_in(z, (int)kd.Z)) return;
+  float *base = k0_grad + c * kd.sC + z * kd.sZ;
+#pragma unroll
+  for (int kxy = 0; kxy < 4; ++kxy) {
+    const int x = t.x0 + (kxy >> 1), y = t.y0 + (kxy & 1);
+    const float w = zc ? t.w[2 * kxy + 1] : t.w[2 * kxy];          // (selects, not a run-time index: that would be scratch memory)
+    if (fgs_in(x, (int)kd.X) && fgs_in(y, (int)kd.Y)) atomicAdd(base + x * kd.sX + y * kd.sY, w * g);
+  }
 }
 
 // (Combining the corners of four consecutive survivors in a 4^3-voxel LDS brick first -- the recipe of k_feat_taps_bwd below --
@@ -838,7 +855,7 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   if (int e = fill_layout_coarse(layout_i, &S.L, fgs_dyn_compact(dyn))) return e;
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
-  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
 #define FGS_ENC_BWD(F) hipLaunchKernelGGL(k_feat_enc_bwd<F>, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal, (float *)nullptr, g_gradient)
   switch (S.L.n_reffreq) {      // the shipped configs' frequency counts (config/shiny_blender.py: 3 / 5 / 8) unrolled
@@ -899,7 +916,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   if (k0_grad_grid) {
-    hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+    hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
     FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
   }
   if (!g_gradient) return 0;
