@@ -747,6 +747,8 @@ def main():
             captured.replay(packed[i % N_BATCHES])
         captured.flush()
         captured.clear_counters()
+        if stamp_buf is not None:
+            stamp_buf.zero_()         # (the warm-up replays stamped the slots the timed ones reuse; k_gemm's are atomic min / max)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -40,6 +40,28 @@ for W, K0, M in ((192, 90, 98304), (192, 90, 354000), (128, 66, 98304)):
     g0, g1 = torch.zeros(W, ld0, device=dev), torch.zeros(W, W, device=dev)
     gb0 = torch.zeros(W, device=dev)
     items = [(dY0, X0, g0, gb0, W, K0), (dY1, a0, g1, None, W, W)]
+    bwd2 = [dict(W=W1, mask_bits=m0, out=dY0, n_store=W), dict(W=V0c, out=dX0, n_store=48, side=True)]
+    t_f2 = timed(lambda: fo.rc_chain(False, M, X0, ld0, fwd, form=2))
+    t_b2 = timed(lambda: fo.rc_chain(True, M, dY1, W, bwd2, form=2))
+    print(f"W={W} K0={K0} M={M}: form 2: fwd chain {t_f2:6.1f} us ({2.0 * M * W * (K0 + W) / t_f2 / 1e6:5.1f} TF)  bwd chain + dX0 side layer "
+          f"{t_b2:6.1f} us ({2.0 * M * W * (W + 48) / t_b2 / 1e6:5.1f} TF)", flush=True)
+    if os.environ.get("RC2_PHASES"):
+        import numpy as np
+        for what, backward, layers, in0, cols in (("fwd", False, fwd, X0, ld0), ("bwd", True, bwd2, dY1, W)):
+            buf = torch.zeros(1, fo.STAMP_LAUNCHES, fo.STAMP_WORDS, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                fo.STAMPS.update(buf=buf, counter=None)
+                fo.stamps_begin_step()
+                fo.rc_chain(backward, M, in0, cols, layers, form=2)
+                torch.cuda.synchronize()
+            fo.STAMPS.update(buf=None, counter=None)
+            wds = buf[0, 0].cpu().numpy().astype(np.uint64).reshape(-1, 8)
+            wds = wds[wds[:, 1] > 0]
+            cyc = (wds[:, 2] - wds[:, 0]).astype(np.float64)
+            wall = (wds[:, 3] - wds[:, 1]).astype(np.float64) / 100.0
+            print(f"    {what} form 2: {len(wds)} workgroups, in-kernel {np.median(wall):.1f} us (max {wall.max():.1f}), clock "
+                  f"{np.median(cyc / wall) / 1e3:.2f} GHz; wave 0 cycles: total {np.median(cyc):.0f} = slab input {np.median(wds[:, 7]):.0f} + "
+                  f"init {np.median(wds[:, 4]):.0f} + reductions {np.median(wds[:, 5]):.0f} + epilogues/barriers {np.median(wds[:, 6]):.0f}", flush=True)
     t_f = timed(lambda: fo.rc_chain(False, M, X0, ld0, fwd))
     t_b = timed(lambda: fo.rc_chain(True, M, dY1, W, bwd))
     t_g = timed(lambda: fo.gemm(fo.GEMM_NN, dY0, V0c, dX0, M, 48, W))
