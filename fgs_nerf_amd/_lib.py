@@ -28,6 +28,7 @@ _SIGNATURES = {
     "fgs_infer_ray_start_dir": [P, P, P, I64, P, P, P],
     "fgs_sample_count": [P, P, P, P, F32, F32, F32, I64, P, P, P, P, P],
     "fgs_sample_emit": [P, P, P, P, F32, I64, P, P, I64, P, P, P, P, P],
+    "fgs_copy_f32": [P, P, I64, P],
     "fgs_gather_batch": [P, I64, I64, P, P, P, P, P, P],
     "fgs_sample_ndc_pts": [P, P, P, P, I64, I64, P, P, P],
     "fgs_sample_bg_pts": [P, P, P, F32, I64, I64, P, P],

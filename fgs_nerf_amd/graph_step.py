@@ -362,7 +362,11 @@ class CapturedFineStep:
     def load(self, batch) -> None:
         """batch: (rays_o, rays_d, viewdirs, target), each [n_rays, 3] -- or the four stacked as one [4, n_rays, 3] tensor."""
         if torch.is_tensor(batch):
-            self.inputs.copy_(batch, non_blocking=True)
+            if (batch.is_cuda and batch.dtype == torch.float32 and batch.is_contiguous() and batch.numel() == self.inputs.numel()
+                    and batch.data_ptr() % 16 == 0):
+                call("fgs_copy_f32", ptr(batch), ptr(self.inputs), int(batch.numel()), stream())     # (a launch, not the blit path)
+            else:
+                self.inputs.copy_(batch, non_blocking=True)
             return
         ro, rd, vd, target = batch
         self.rays_o.copy_(ro, non_blocking=True)

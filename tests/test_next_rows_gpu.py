@@ -202,3 +202,15 @@ def test_batch_gather_in_one_launch(dev):
     torch.cuda.synchronize()
     for a in range(4):
         assert torch.equal(out[a], srcs[a][sel])
+
+
+def test_staged_batch_copy_kernel(dev):
+    """fgs_copy_f32 (CapturedFineStep.load of a staged [4, n, 3] batch): a copy, bit-exact, tail elements included."""
+    import torch
+    from fgs_nerf_amd._lib import call, ptr, stream
+    for n in (4 * 4096 * 3, 1027, 3):
+        src = torch.randn(n + 8, device=dev)[:n]
+        dst = torch.full((n + 4,), float('nan'), device=dev)
+        call("fgs_copy_f32", ptr(src), ptr(dst), n, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src) and bool(torch.isnan(dst[n:]).all())
