@@ -51,14 +51,17 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_tv_add_grad(const float *__restri
 // centre row and the four y / x neighbour rows are 16-byte loads, the two z neighbours outside the quad two scalars
 // (7 load instructions per 4 elements instead of 28), 32-bit index arithmetic; the sums are formed element by element in
 // the reference's order, so the result is bit-identical to k_tv_add_grad<false, false>.
+template <bool DENSE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_tv_add_grad_cf4(const float *__restrict__ param, float *__restrict__ grad,
-                                                               float wy, float wz, int dense_mode, int X, int Y, int Z,
-                                                               unsigned n4) {
+                                                               float wy, float wz, int X, int Y, int Z, unsigned n4) {
+  constexpr int dense_mode = DENSE ? 1 : 0;
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n4) return;
   const unsigned idx = 4u * t;
   const float4 g0 = *reinterpret_cast<const float4 *>(grad + idx);
-  if (!(dense_mode || g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f)) return;
+  // (dense mode -- a template parameter -- must not wait for the gradient before it asks for the parameters: the test below made
+  // every thread's seven loads two dependent round trips, 21 us for 48 MB at 160^3)
+  if (!DENSE && !(g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f)) return;
   unsigned r = idx;
   const unsigned z0 = r % (unsigned)Z; r /= (unsigned)Z;
   const unsigned y = r % (unsigned)Y; r /= (unsigned)Y;
@@ -193,8 +196,8 @@ FGS_API int fgs_tv_add_grad(const float *param, float *grad, const float *mask, 
   if (ch_first && !mask && C == 1 && (Z % 4) == 0 && N < ((int64_t)1 << 31) &&
       (reinterpret_cast<uintptr_t>(param) & 15) == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0) {
     const unsigned n4 = (unsigned)(N / 4);
-    hipLaunchKernelGGL(k_tv_add_grad_cf4, dim3(fgs_blocks(n4)), b, 0, st, param, grad, wy, wz, dense_mode, (int)X, (int)Y, (int)Z,
-                       n4);
+    if (dense_mode) hipLaunchKernelGGL(k_tv_add_grad_cf4<true>, dim3(fgs_blocks(n4)), b, 0, st, param, grad, wy, wz, (int)X, (int)Y, (int)Z, n4);
+    else hipLaunchKernelGGL(k_tv_add_grad_cf4<false>, dim3(fgs_blocks(n4)), b, 0, st, param, grad, wy, wz, (int)X, (int)Y, (int)Z, n4);
   } else if (ch_first) {
     if (mask) hipLaunchKernelGGL((k_tv_add_grad<false, true>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
     else      hipLaunchKernelGGL((k_tv_add_grad<false, false>), g, b, 0, st, param, grad, mask, wx, wy, wz, dense_mode, d, N);
