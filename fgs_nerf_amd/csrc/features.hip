@@ -45,6 +45,12 @@ __device__ __forceinline__ int64_t surv_of(int64_t tid, int64_t M, int64_t C) {
   return tid / C;
 }
 
+// consecutive survivors one thread of the k0 scatter walks (FGS_K0_BWD_RUN, default 4; 1 = one survivor per thread)
+static int k0_run() {
+  static const int r = [] { const int v = fgs_env_int("FGS_K0_BWD_RUN", 4); return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------- k0 lookup
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const float *__restrict__ k0, GridDesc kd,
                                                            float *__restrict__ X0) {
@@ -56,34 +62,54 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_fwd(SurvArgs S, const flo
   X0[m * S.L.ldx0 + S.L.off_k0 + c] = fgs_tri_sample(k0, kd, c, fgs_tri_setup(p.fx, p.fy, p.fz));
 }
 
-// One thread per (survivor, z corner, channel), four atomics each -- the (x, y) corners.  Float atomics execute at the memory
-// side and are priced per 64-byte request (MI355X_MICROARCH.md, global float atomics: ~20 G requests/s chip-wide): with the two z
-// corners of an (x, y) pair in ONE wave-instruction their 2 x C contiguous floats (96 bytes at C = 12, channel-last grid) leave as
-// 2.25 requests on average instead of 2 x 1.5 -- the kernel runs at that request rate, nothing else (12 requests per survivor
-// before: 57 K survivors 45 us, 354 K 277 us).
+// One thread per (run of R consecutive survivors, z corner, channel), four accumulators -- the (x, y) corners of the current cell.
+// Float atomics execute at the memory side and are priced per 64-byte request (MI355X_MICROARCH.md, global float atomics: ~20 G
+// requests/s chip-wide); the kernel runs at that request rate, nothing else.  Two things cut the requests:
+// * the two z corners of an (x, y) pair sit in ONE wave-instruction: their 2 x C contiguous floats (96 bytes at C = 12,
+//   channel-last grid) leave as 2.25 requests on average instead of 2 x 1.5 (12 requests per survivor -> 9: 51 -> 41 us at 57 K
+//   survivors beside the weight-gradient launch, 290 -> 231 us at 354 K);
+// * consecutive survivors of a ray sit half a voxel apart, so about every second one falls into the cell of its predecessor: a
+//   thread walks R of them and sends a cell's four sums when the cell changes.
 __global__ __launch_bounds__(FGS_BLOCK) void k_feat_k0_bwd(SurvArgs S, float *__restrict__ k0_grad, GridDesc kd,
-                                                           const float *__restrict__ dX0) {
+                                                           const float *__restrict__ dX0, int R) {
   __builtin_amdgcn_s_setprio(2);     // may run beside k_mlp_wgrad (fused.py _wgrad), whose fp32 matrix instructions occupy
                                      // the vector pipe: this memory-bound kernel's few vector instructions go first
   const int64_t M = fgs_rows(S.M, S.m_dev);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t C2 = 2 * kd.C;
-  if (tid >= M * C2) return;
-  const int64_t m = surv_of(tid, M, C2);
-  const int rem = (int)(tid - m * C2);
+  const int64_t runs = (M + R - 1) / R;
+  if (tid >= runs * C2) return;
+  const int64_t run = surv_of(tid, runs, C2);
+  const int rem = (int)(tid - run * C2);
   const int zc = rem >= (int)kd.C ? 1 : 0, c = rem - zc * (int)kd.C;
-  const float g = dX0[m * S.L.dx_ld + S.L.off_k0 + c];
-  if (g == 0.f) return;
-  const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
-  const TriCorners t = fgs_tri_setup(p.fx, p.fy, p.fz);
-  const int z = t.z0 + zc;
-  if (!fgs_in(z, (int)kd.Z)) return;
-  float *base = k0_grad + c * kd.sC + z * kd.sZ;
+  float *const base = k0_grad + c * kd.sC;
+  int kx = 0, ky = 0, kz = -1;                 // the cell whose sums are held (kz < 0: none)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t m_end = (run + 1) * R < M ? (run + 1) * R : M;
+  for (int64_t m = run * R; m <= m_end; ++m) {
+    float g = 0.f;
+    TriCorners t;
+    t.x0 = 0; t.y0 = 0; t.z0 = -2;            // (the pass behind the last survivor only sends what is held)
+    if (m < m_end) {
+      g = dX0[m * S.L.dx_ld + S.L.off_k0 + c];
+      const PointIdx p = fgs_point_to_index(S.pts[3 * m], S.pts[3 * m + 1], S.pts[3 * m + 2], S.geom.lo, S.geom.hi, kd);
+      t = fgs_tri_setup(p.fx, p.fy, p.fz);
+    }
+    const int z = t.z0 + zc;
+    if (kz >= 0 && (m == m_end || t.x0 != kx || t.y0 != ky || z != kz)) {
 #pragma unroll
-  for (int kxy = 0; kxy < 4; ++kxy) {
-    const int x = t.x0 + (kxy >> 1), y = t.y0 + (kxy & 1);
-    const float w = zc ? t.w[2 * kxy + 1] : t.w[2 * kxy];          // (selects, not a run-time index: that would be scratch memory)
-    if (fgs_in(x, (int)kd.X) && fgs_in(y, (int)kd.Y)) atomicAdd(base + x * kd.sX + y * kd.sY, w * g);
+      for (int kxy = 0; kxy < 4; ++kxy) {
+        const int x = kx + (kxy >> 1), y = ky + (kxy & 1);
+        if (acc[kxy] != 0.f && fgs_in(x, (int)kd.X) && fgs_in(y, (int)kd.Y)) atomicAdd(base + x * kd.sX + y * kd.sY + kz * kd.sZ, acc[kxy]);
+        acc[kxy] = 0.f;
+      }
+      kz = -1;
+    }
+    if (m < m_end && g != 0.f && fgs_in(z, (int)kd.Z)) {
+      kx = t.x0; ky = t.y0; kz = z;
+#pragma unroll
+      for (int kxy = 0; kxy < 4; ++kxy) acc[kxy] += (zc ? t.w[2 * kxy + 1] : t.w[2 * kxy]) * g;      // (selects, not a run-time index)
+    }
   }
 }
 
@@ -855,7 +881,7 @@ FGS_API int fgs_feat_coarse_bwd(int64_t M, const int64_t *ray_id, const float *p
   if (int e = fill_layout_coarse(layout_i, &S.L, fgs_dyn_compact(dyn))) return e;
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
-  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+  hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * ((M + k0_run() - 1) / k0_run()) * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0, k0_run());
   FGS_LAUNCH_OK("fgs_feat_coarse_bwd/k0");
 #define FGS_ENC_BWD(F) hipLaunchKernelGGL(k_feat_enc_bwd<F>, dim3(fgs_blocks(M)), dim3(FGS_BLOCK), 0, st, S, X0, dX0, dX0, g_normal, (float *)nullptr, g_gradient)
   switch (S.L.n_reffreq) {      // the shipped configs' frequency counts (config/shiny_blender.py: 3 / 5 / 8) unrolled
@@ -916,7 +942,7 @@ FGS_API int fgs_feat_fine_bwd(int64_t M, const int64_t *ray_id, const float *pts
   hipStream_t st = fgs_s(stream);
   const GridDesc kd{S.L.k0_dim, X, Y, Z, ksC, ksX, ksY, ksZ};
   if (k0_grad_grid) {
-    hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * M * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0);
+    hipLaunchKernelGGL(k_feat_k0_bwd, dim3(fgs_blocks(2 * ((M + k0_run() - 1) / k0_run()) * S.L.k0_dim)), dim3(FGS_BLOCK), 0, st, S, k0_grad_grid, kd, dX0, k0_run());
     FGS_LAUNCH_OK("fgs_feat_fine_bwd/k0");
   }
   if (!g_gradient) return 0;
