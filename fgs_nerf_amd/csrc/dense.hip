@@ -58,7 +58,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_conv3d_tiled(const float *__restr
   // halo tile -> LDS: z-rows of LZU values, one (lx, ly) row per group of LZU consecutive work items; the fixed trip
   // count lets the compiler keep several global loads in flight per thread
   constexpr int TOTAL = LX * LY * LZU, ITERS = (TOTAL + FGS_BLOCK - 1) / FGS_BLOCK;
-#pragma unroll 6
+  constexpr int UNR = ITERS <= 16 ? ITERS : (ITERS + 1) / 2;       // (the whole halo in one or two batches of loads)
+#pragma unroll UNR
   for (int it = 0; it < ITERS; ++it) {
     const int i = it * FGS_BLOCK + threadIdx.x;
     const int ic = i < TOTAL ? i : TOTAL - 1;

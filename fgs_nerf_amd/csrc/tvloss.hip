@@ -78,17 +78,35 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_tv_loss_value(const float *__rest
   float s[3] = {0.f, 0.f, 0.f}, tot = 0.f;
   unsigned cnt[3] = {0u, 0u, 0u};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // Branch-free per element: the neighbour loads go to clamped (always valid) addresses and predicates select afterwards, so the
+  // loads of the unrolled iterations are all in flight together.  (With `continue` and nested conditions every element was a
+  // chain of three dependent cache round trips and a thread walked its six elements one after the other: 30 us at 114^3 for a
+  // pass that moves 7.5 MB.)
+  const bool has_mask = g.mask != nullptr;
+#pragma unroll 3
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
     int64_t c, x, y, z;
     tv_decode<CH_LAST>(g, i, c, x, y, z);
     const int64_t o = c * g.d.sC + x * g.d.sX + y * g.d.sY + z * g.d.sZ;
-    const float a = v[o];
-    tot += a;
     const int64_t mo = (x * g.d.Y + y) * g.d.Z + z;
-    if (g.mask && !g.mask[mo]) continue;
-    if (x + 1 < g.d.X && (!g.mask || g.mask[mo + g.d.Y * g.d.Z])) { s[0] += fabsf(v[o + g.d.sX] - a); ++cnt[0]; }
-    if (y + 1 < g.d.Y && (!g.mask || g.mask[mo + g.d.Z])) { s[1] += fabsf(v[o + g.d.sY] - a); ++cnt[1]; }
-    if (z + 1 < g.d.Z && (!g.mask || g.mask[mo + 1])) { s[2] += fabsf(v[o + g.d.sZ] - a); ++cnt[2]; }
+    const bool bx = x + 1 < g.d.X, by = y + 1 < g.d.Y, bz = z + 1 < g.d.Z;
+    const float a = v[o];
+    const float ax = v[bx ? o + g.d.sX : o], ay = v[by ? o + g.d.sY : o], az = v[bz ? o + g.d.sZ : o];
+    bool m0 = true, mx = true, my = true, mz = true;
+    if (has_mask) {        // (uniform)
+      m0 = g.mask[mo] != 0;
+      mx = g.mask[bx ? mo + g.d.Y * g.d.Z : mo] != 0;
+      my = g.mask[by ? mo + g.d.Z : mo] != 0;
+      mz = g.mask[bz ? mo + 1 : mo] != 0;
+    }
+    tot += a;
+    const bool px = m0 && bx && mx, py = m0 && by && my, pz = m0 && bz && mz;
+    s[0] += px ? fabsf(ax - a) : 0.f;
+    s[1] += py ? fabsf(ay - a) : 0.f;
+    s[2] += pz ? fabsf(az - a) : 0.f;
+    cnt[0] += px ? 1u : 0u;
+    cnt[1] += py ? 1u : 0u;
+    cnt[2] += pz ? 1u : 0u;
   }
   __shared__ double part[FGS_BLOCK / FGS_WAVE][7];
   __shared__ int is_last;
