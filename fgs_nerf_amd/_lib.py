@@ -19,7 +19,7 @@ P, F32, I64, I32, F64 = c_void_p, c_float, c_int64, c_int, c_double
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {
@@ -102,7 +102,7 @@ _SIGNATURES = {
     "fgs_smooth3d_bwd": [P, I64, I32, I32, I32, I32, P, P, P, P],
     "fgs_smooth_tv_loss": [P, I32, I32, I32, P, P, P, F32, P, P, I64, P, P, P],
     "fgs_sdf_gradvol_fwd": [P, I32, I32, I32, F32, I32, P, P, P, P],
-    "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, I32, P, I32, P],
+    "fgs_sdf_gradvol_bwd": [P, I64, I64, I32, I32, I32, F32, I32, P, I32, P, P],
     "fgs_march_coarse_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, P, P, P, F32, F32, F32,
                              P, P, P, I32, I32, I32, F32, P, I32, I32, I32, P, P, I32,
                              P, P, P, P, P, P, P, P, P, P, P, P, P, P],

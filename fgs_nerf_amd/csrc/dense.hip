@@ -214,32 +214,38 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_fwd(const float *__restri
 // d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v-1 interior] - dg_axis[v+1] * [v+1 interior] ) / 2 / vs          (MODE 0)
 // d_s[v] (+)= sum_axis ( dg_axis[v-1] * [v >= 1] - dg_axis[v] * [v <= n-2] ) / vs                            (MODE 1)
 // dg component c of voxel v lives at dg[c * sC + v * sV] ((XYZ, 1) for the dense [3,X,Y,Z] layout)
+// dg2 (optional): a SECOND upstream gradient of the volume, dense [3,X,Y,Z], added to dg on the fly (the smooth-gradient TV
+// term's: autograd would add the two with a grid-sized launch of its own, one operand strided)
 template <int MODE>
 __global__ __launch_bounds__(FGS_BLOCK) void k_gradvol_bwd(const float *__restrict__ dg, int64_t sC, int64_t sV, int X,
-                                                           int Y, int Z, float vs, float *__restrict__ d_s, int accumulate) {
+                                                           int Y, int Z, float vs, float *__restrict__ d_s, int accumulate,
+                                                           const float *__restrict__ dg2) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t N = (int64_t)X * Y * Z;
   if (idx >= N) return;
   const int z = (int)(idx % Z), y = (int)((idx / Z) % Y), x = (int)(idx / ((int64_t)Z * Y));
   const int64_t sx = (int64_t)Y * Z, sy = Z;
   float acc = 0.f;
+  // component c of voxel w: dg[c sC + w sV] (+ dg2[c N + w])
+#define GV(c, w) (dg[(c) * sC + (w) * sV] + (dg2 ? dg2[(c) * N + (w)] : 0.f))
   if (MODE == 0) {
     // s[v] appears as "+" in g at v-1 (needs 1 <= v-1 <= n-2) and as "-" in g at v+1 (needs 1 <= v+1 <= n-2)
-    if (x - 1 >= 1 && x - 1 <= X - 2) acc += dg[(idx - sx) * sV] / 2.f / vs;
-    if (x + 1 >= 1 && x + 1 <= X - 2) acc -= dg[(idx + sx) * sV] / 2.f / vs;
-    if (y - 1 >= 1 && y - 1 <= Y - 2) acc += dg[sC + (idx - sy) * sV] / 2.f / vs;
-    if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= dg[sC + (idx + sy) * sV] / 2.f / vs;
-    if (z - 1 >= 1 && z - 1 <= Z - 2) acc += dg[2 * sC + (idx - 1) * sV] / 2.f / vs;
-    if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= dg[2 * sC + (idx + 1) * sV] / 2.f / vs;
+    if (x - 1 >= 1 && x - 1 <= X - 2) acc += GV(0, idx - sx) / 2.f / vs;
+    if (x + 1 >= 1 && x + 1 <= X - 2) acc -= GV(0, idx + sx) / 2.f / vs;
+    if (y - 1 >= 1 && y - 1 <= Y - 2) acc += GV(1, idx - sy) / 2.f / vs;
+    if (y + 1 >= 1 && y + 1 <= Y - 2) acc -= GV(1, idx + sy) / 2.f / vs;
+    if (z - 1 >= 1 && z - 1 <= Z - 2) acc += GV(2, idx - 1) / 2.f / vs;
+    if (z + 1 >= 1 && z + 1 <= Z - 2) acc -= GV(2, idx + 1) / 2.f / vs;
   } else {
     // s[v] appears as "+" in g at v-1 (needs v-1 <= n-2, i.e. always, and v >= 1) and as "-" in g at v (needs v <= n-2)
-    if (x >= 1) acc += dg[(idx - sx) * sV] / vs;
-    if (x <= X - 2) acc -= dg[idx * sV] / vs;
-    if (y >= 1) acc += dg[sC + (idx - sy) * sV] / vs;
-    if (y <= Y - 2) acc -= dg[sC + idx * sV] / vs;
-    if (z >= 1) acc += dg[2 * sC + (idx - 1) * sV] / vs;
-    if (z <= Z - 2) acc -= dg[2 * sC + idx * sV] / vs;
+    if (x >= 1) acc += GV(0, idx - sx) / vs;
+    if (x <= X - 2) acc -= GV(0, idx) / vs;
+    if (y >= 1) acc += GV(1, idx - sy) / vs;
+    if (y <= Y - 2) acc -= GV(1, idx) / vs;
+    if (z >= 1) acc += GV(2, idx - 1) / vs;
+    if (z <= Z - 2) acc -= GV(2, idx) / vs;
   }
+#undef GV
   d_s[idx] = accumulate ? d_s[idx] + acc : acc;
 }
 
@@ -302,16 +308,17 @@ FGS_API int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float vox
 }
 
 FGS_API int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
-                                float voxel_size, int mode, float *d_sdf, int accumulate, fgs_stream_t stream) {
+                                float voxel_size, int mode, float *d_sdf, int accumulate, const float *d_grad3_b,
+                                fgs_stream_t stream) {
   FGS_REQUIRE(X > 0 && Y > 0 && Z > 0 && (int64_t)X * Y * Z < ((int64_t)1 << 38), FGS_E_RANGE, "fgs_sdf_gradvol_bwd: size");
   FGS_REQUIRE(mode == 0 || mode == 1, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: mode=%d (0 = interpolate, 1 = raw)", mode);
   FGS_REQUIRE(d_grad3 && d_sdf && chan_stride >= 1 && voxel_stride >= 1, FGS_E_INVALID, "fgs_sdf_gradvol_bwd: bad arguments");
   if (mode == 0)
     hipLaunchKernelGGL(k_gradvol_bwd<0>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
-                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
+                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate, d_grad3_b);
   else
     hipLaunchKernelGGL(k_gradvol_bwd<1>, dim3(fgs_blocks((int64_t)X * Y * Z)), dim3(FGS_BLOCK), 0, fgs_s(stream), d_grad3,
-                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate);
+                       chan_stride, voxel_stride, X, Y, Z, voxel_size, d_sdf, accumulate, d_grad3_b);
   FGS_LAUNCH_OK("fgs_sdf_gradvol_bwd");
   return 0;
 }

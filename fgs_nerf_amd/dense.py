@@ -69,7 +69,11 @@ def smooth3d(grid: torch.Tensor, taps: torch.Tensor, taps_c=None) -> torch.Tenso
 
 class _GradVol(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, grid, voxel_size, pack, mode=0):
+    def forward(ctx, grid, voxel_size, pack, mode=0, side=None):
+        # side: a dict shared with the result's consumers -- a term that would hand autograd a SECOND gradient of the volume
+        # (the smooth-gradient TV term) leaves it there as side['extra'] and the backward pass below adds it on the fly
+        ctx.side = side
+        ctx.set_materialize_grads(False)
         X, Y, Z = _check_grid(grid)
         g = grid.contiguous()
         out = torch.empty(1, 3, X, Y, Z, dtype=torch.float32, device=g.device)
@@ -89,13 +93,18 @@ class _GradVol(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_out):
         X, Y, Z, vs, mode = ctx.meta
+        extra = ctx.side.pop('extra', None) if ctx.side is not None else None
+        if d_out is None:
+            if extra is None:
+                return None, None, None, None, None
+            d_out, extra = extra, None
         sv = _voxel_stride(d_out, X, Y, Z)
         if sv is None:
             d_out, sv = d_out.contiguous(), 1
         sc = d_out.stride(1)
         d_in = torch.empty(1, 1, X, Y, Z, dtype=torch.float32, device=d_out.device)
-        call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, mode, ptr(d_in), 0, stream())
-        return d_in, None, None, None
+        call("fgs_sdf_gradvol_bwd", ptr(d_out), sc, sv, X, Y, Z, vs, mode, ptr(d_in), 0, ptr(extra), stream())
+        return d_in, None, None, None, None
 
 
 GRAD_MODES = {'interpolate': 0, 'raw': 1}
@@ -114,7 +123,10 @@ def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, ho
         w = grad_conv_weight.detach()
         return torch.cat([smooth3d(grid, w[c, 0]) for c in range(3)], dim=1)
     pack = None if pack_sdf is None else (pack_sdf, holder)
-    return _GradVol.apply(grid, float(voxel_size), pack, GRAD_MODES[mode])
+    side = {}
+    out = _GradVol.apply(grid, float(voxel_size), pack, GRAD_MODES[mode], side)
+    out._fgs_side = side             # (read by smooth_tv_loss: see _GradVol.forward)
+    return out
 
 
 _TV_SCRATCH = {}          # (device index, kind) -> scratch of a TV value launch (first word: its arrival counter, left zero)
@@ -138,7 +150,7 @@ class _SmoothTV(torch.autograd.Function):
     one HIP pass per channel (include/fgs_hip.h fgs_smooth_tv_loss); `add_in`: the loss so far (saves an addition launch)."""
 
     @staticmethod
-    def forward(ctx, grad3, taps_c, mask_u8, inv_count, weight, add_in):
+    def forward(ctx, grad3, taps_c, mask_u8, inv_count, weight, add_in, side):
         if not (grad3.is_cuda and grad3.dtype == torch.float32 and grad3.dim() == 5 and grad3.shape[:2] == (1, 3)):
             raise RuntimeError("expected a float32 CUDA gradient volume of shape [1,3,X,Y,Z]")
         g = grad3.contiguous()
@@ -150,7 +162,7 @@ class _SmoothTV(torch.autograd.Function):
         call("fgs_smooth_tv_loss", ptr(g), X, Y, Z, taps_c, ptr(mask_u8), ptr(inv_count), float(weight), ptr(add_in), ptr(scratch),
              scratch.numel(), ptr(loss), ptr(d_g), stream())
         ctx.save_for_backward(d_g)
-        ctx.has_add = add_in is not None
+        ctx.has_add, ctx.side = add_in is not None, side
         return loss
 
     @staticmethod
@@ -159,11 +171,17 @@ class _SmoothTV(torch.autograd.Function):
         (d_g,) = ctx.saved_tensors
         # (a captured step passes a registered unit seed through the additions in front of this node: no grid-sized multiply)
         g = d_g if _is_unit_seed(g_loss) else d_g * g_loss
-        return g, None, None, None, None, (g_loss if ctx.has_add else None)
+        if ctx.side is not None and 'extra' not in ctx.side:
+            # the volume came from _GradVol: its backward pass (which autograd runs after this one) adds this gradient to the
+            # march kernels' while it reads them -- handing it to autograd would cost a grid-sized addition with a strided operand
+            ctx.side['extra'] = g
+            g = None
+        return g, None, None, None, None, (g_loss if ctx.has_add else None), None
 
 
 def smooth_tv_loss(grad3: torch.Tensor, taps_c, mask_u8, inv_count: torch.Tensor, weight: float, add_in=None) -> torch.Tensor:
-    return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight), add_in)
+    side = getattr(grad3, '_fgs_side', None) if grad3.is_contiguous() else None
+    return _SmoothTV.apply(grad3, taps_c, mask_u8, inv_count, float(weight), add_in, side)
 
 
 class _GridTV(torch.autograd.Function):

@@ -38,7 +38,7 @@ typedef void *fgs_stream_t;
  * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
  * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked);
  * 11 = fgs_fine_render_loss. */
-#define FGS_ABI_VERSION 12
+#define FGS_ABI_VERSION 13
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
@@ -601,8 +601,10 @@ int fgs_smooth3d_bwd(const float *d_out, int64_t out_stride, int X, int Y, int Z
  * that fgs_march_coarse_fwd samples with one 16-byte load per trilinear corner (pack_sdf = the smoothed SDF). */
 int fgs_sdf_gradvol_fwd(const float *sdf, int X, int Y, int Z, float voxel_size, int mode, float *grad3,
                         const float *pack_sdf, float *vol4, fgs_stream_t stream);
+/* d_grad3_b (optional): a second upstream gradient of the volume, dense [3,X,Y,Z], added to d_grad3 on the fly (the
+ * smooth-gradient TV term's beside the march kernels': saves autograd's grid-sized addition of the two). */
 int fgs_sdf_gradvol_bwd(const float *d_grad3, int64_t chan_stride, int64_t voxel_stride, int X, int Y, int Z,
-                        float voxel_size, int mode, float *d_sdf, int accumulate, fgs_stream_t stream);
+                        float voxel_size, int mode, float *d_sdf, int accumulate, const float *d_grad3_b, fgs_stream_t stream);
 
 /* Smooth-gradient TV term of nerf.density_total_variation (model/nerf.py:436-446; the shipped fine config adds it every
  * third iteration, the coarse configs every iteration) over the gradient volume g3 [3,X,Y,Z], value and gradient in one
