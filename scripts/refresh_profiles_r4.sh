@@ -44,6 +44,9 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/pmc_sq -- python3
 cd $ROOT
 python3 scripts/pmc_sq_summary.py $OUT/pmc_sq $OUT/fine $OUT/pmc_sq.json > $OUT/pmc_sq.txt 2>&1 || true
 rm -rf $OUT/fine $OUT/forced $OUT/coarse $OUT/g320 $OUT/pmc_sq
+# the real iterations (shipped train bodies through TrainStepper.run_captured) and the coarse one's timeline
+python3 scripts/fine_real_iter.py > $OUT/fine_real_iter.txt 2>&1 || true
+bash scripts/r4_coarse_real.sh r4p > /dev/null 2>&1 || true
 python3 - <<P
 import json, glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
