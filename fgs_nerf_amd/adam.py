@@ -39,6 +39,8 @@ class MaskedAdam(torch.optim.Optimizer):
                 raise ValueError(what)
         self.per_lr = None
         self.before_param = None      # optional callable(param), invoked right before a parameter is updated (dist.py)
+        self.before_small = None      # optional callable(), invoked before the first MLP tensor is updated (graph_step.py: the
+                                      # weight-gradient branch of a captured step is joined there, not inside the backward pass)
         self._early = {}              # id(param) -> event of an update already applied by early_update() in this step
         self._early_stream = None
         self._dev = None              # device-resident schedule (use_device_schedule): {'ss': {group index: ptr}, 'skip': ptr}
@@ -300,7 +302,11 @@ class MaskedAdam(torch.optim.Optimizer):
                     small.setdefault((float(b1), float(b2), float(group['eps']), skip), []).append(
                         (p, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], masked, ss_ptr))
                 else:
+                    if p.dim() <= 2 and self.before_small is not None:    # (an MLP tensor too large for the shared launch)
+                        self.before_small()
                     self._big(p, g, st, group, ss_ptr, skip)
+        if small and self.before_small is not None:     # (graph_step.CapturedFineStep: the deferred join of the weight-gradient branch)
+            self.before_small()
         for (b1, b2, eps, skip), rows in small.items():
             self._flush_small(rows, b1, b2, eps, skip=skip)
         for done in early.values():                     # everything after step() sees the early updates

@@ -314,7 +314,7 @@ class _FusedCoarse(torch.autograd.Function):
              dyn(inv_s=_inv_s(run)), st)
         d_smooth = d4[..., 0][None, None]                       # [1,1,X,Y,Z], element stride 4
         d_gradvol = d4[..., 1:4].permute(3, 0, 1, 2)[None]      # [1,3,X,Y,Z], channel stride 1, voxel stride 4
-        _join_side(dev)
+        _join_side_or_defer(run, dev, allowed=hook is None)
         if hook is not None:
             hook('join', None)
         grads: List[Optional[torch.Tensor]] = [None, d_smooth, d_gradvol, grad_k0]

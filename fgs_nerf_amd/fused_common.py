@@ -293,7 +293,9 @@ def _wgrad(dev, M, items, flop, fork: bool, post=None, rows_dev=None) -> None:
         fo.mlp_wgrad(M, items, flop=flop, rows_dev=rows_dev)
         if post is not None:
             post()                      # (_MLP_COLLAPSE: the original parameters' gradients from the collapsed layer's)
-    keep.append(items)                  # (allocated on the main stream: alive until the join)
+    # allocated on the main stream: alive until the join.  Only the launch's INPUTS: a held gradient view would make autograd's
+    # AccumulateGrad clone the gradient it is handed (16 copy launches) when the join comes after the backward pass (below).
+    keep.append([(it[0], it[1]) for it in items])
     _SIDE_PENDING.add(dev.index)
 
 
@@ -329,6 +331,29 @@ def _flush_tn(dev) -> None:
         side.wait_event(ready)
         for dY, X, dW, n_out, k_in, M in jobs:
             fo.gemm(fo.GEMM_TN, dY, X, dW, n_out, k_in, M)
+
+
+# FGS_DEFER_WGRAD_JOIN=1 (default): a captured single-GPU step (graph_step.CapturedFineStep sets cache['defer_side_join']) joins
+# the weight-gradient branch in front of the MLP's Adam launch instead of at the end of the backward pass.  The scatter branch
+# is the longer one since round 4, so the join is already satisfied there, and sdf's TV + Adam passes follow the scatter kernels
+# on their own queue: the cross-queue wait in front of them cost ~10 us of idle device per step.  0: join inside backward.
+_DEFER_WGRAD_JOIN = os.environ.get("FGS_DEFER_WGRAD_JOIN", "1") == "1"
+
+
+def _join_side_or_defer(run, dev, allowed: bool) -> None:
+    if allowed and _DEFER_WGRAD_JOIN and run.cache.get('defer_side_join') and dev.index in _SIDE_PENDING:
+        run.cache['side_join_pending'] = dev
+        return
+    _join_side(dev)
+
+
+def join_pending_side(model) -> None:
+    """The deferred join of the weight-gradient branch (see _DEFER_WGRAD_JOIN): called by the step that asked for the deferral,
+    in front of the first consumer of the MLP gradients."""
+    cache = model.__dict__.get('_fused_cache', {})
+    dev = cache.pop('side_join_pending', None)
+    if dev is not None:
+        _join_side(dev)
 
 
 def _join_side(dev) -> None:

@@ -680,7 +680,7 @@ class _FusedFine(torch.autograd.Function):
         if hook is None and opt_hook is not None and _K0_ADAM_LATE:
             opt_hook(k0_grid, grad_k0)           # ... as the LAST kernel of this branch (see _K0_ADAM_LATE)
 
-        _join_side(dev)
+        _join_side_or_defer(run, dev, allowed=hook is None)
         if hook is not None:
             hook('join', None)
         grads: List[Optional[torch.Tensor]] = [None, grad_sdf, grad_k0]

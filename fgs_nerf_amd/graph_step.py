@@ -28,7 +28,7 @@ import torch
 from . import fused
 from . import fused_ops as fo
 from ._lib import call, lib, ptr, stream
-from .fused_common import set_loss_spec
+from .fused_common import join_pending_side, set_loss_spec
 from .losses import fused_render_losses, register_unit_seed
 
 
@@ -281,9 +281,14 @@ class CapturedFineStep:
             after, av.after_early = av.after_early, None
         if hasattr(self.opt, '_early'):
             self.opt._early = {}
+        # one GPU: the weight-gradient branch is joined in front of the MLP's Adam launch (fused_common._DEFER_WGRAD_JOIN)
+        defer_join = av is None and update
+        if defer_join:
+            cache['defer_side_join'] = True
         try:
             loss.backward(self._seed)         # (d loss / d loss given: autograd would launch a ones_like fill per step)
         finally:
+            cache.pop('defer_side_join', None)
             if hook is not None:
                 cache['opt_hook'] = hook
             if inline_hook is not None:
@@ -298,7 +303,17 @@ class CapturedFineStep:
         if update:
             if var.get('tv') is not None:
                 self.model.sdf_total_variation_add_grad(var['tv'][0], var['tv'][1])
-            self.opt.step()
+            prev_hook = getattr(self.opt, 'before_small', None)
+            if hasattr(self.opt, 'before_small'):
+                self.opt.before_small = lambda: join_pending_side(self.model)
+            try:
+                self.opt.step()
+            finally:
+                if hasattr(self.opt, 'before_small'):
+                    self.opt.before_small = prev_hook
+                join_pending_side(self.model)     # (nothing of the branch may outlive the body: an optimizer without the hook)
+        else:
+            join_pending_side(self.model)
         return loss
 
     def _drop_autograd_leftovers(self) -> None:
