@@ -418,6 +418,8 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_voxels(float *__restrict__ p
   const bool no_update = skip && *skip;
   if (ss_dev) step_size = *ss_dev;
   const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  __shared__ unsigned char pos[FGS_BLOCK / FGS_WAVE][64];
   const int c4 = g.C / 4;                       // float4s per voxel
   const int vpp = FGS_WAVE / c4;                // voxels per pass of the wave
   const int slot = lane / c4, q = lane - slot * c4;
@@ -449,12 +451,15 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_adam_voxels(float *__restrict__ p
       const int64_t b = base + (int64_t)src * waves + wave_id;
       const int n = __popcll(mask);
       const int bz = (int)(b % g.nbz), by = (int)((b / g.nbz) % g.nby), bx = (int)(b / ((int64_t)g.nbz * g.nby));
+      // positions of the set bits in rank order, through LDS: lane i owns bit i (the wave's own 64 bytes; LDS operations of one
+      // wave execute in order, so neither the reads below nor the next brick's writes need a barrier).  The loop it replaces --
+      // "drop the s lowest set bits" -- ran max(s) iterations for the whole wave: ~120 of the ~250 vector instructions a brick
+      // costs, and beside the weight-gradient launch vector instructions are what this kernel waits for.
+      if ((mask >> lane) & 1ull) pos[threadIdx.x >> 6][__popcll(mask & lt_mask)] = (unsigned char)lane;
       for (int v0 = 0; v0 < n; v0 += vpp) {
         const int s = v0 + slot;
         if (slot < vpp && s < n) {
-          unsigned long long rest = mask;             // drop the s lowest set bits: the next one is this lane's voxel
-          for (int k = 0; k < s; ++k) rest &= rest - 1ull;
-          const int bit = __builtin_ctzll(rest);
+          const int bit = pos[threadIdx.x >> 6][s];
           const int x = bx * 4 + (bit >> 4), y = by * 4 + ((bit >> 2) & 3), z = bz * 4 + (bit & 3);
           const int64_t off = (((int64_t)x * g.Y + y) * g.Z + z) * g.C + 4 * q;
           const float4 gr = *reinterpret_cast<const float4 *>(grad + off);
