@@ -17,7 +17,7 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:45]:
     print(f'{float(r["TotalDurationNs"]) / tot * 100:6.2f} %  {int(r["Calls"]):6d} calls  {float(r["AverageNs"]) / 1e3:8.1f} us  {r["Name"][:90]}')
 PY
-python3 scripts/trace_step.py $OUT/cr 100 > $OUT/coarse_real_timeline.txt
+python3 scripts/trace_step.py $OUT/cr median > $OUT/coarse_real_timeline.txt
 rm -rf $OUT/cr
 cat $OUT/coarse_real.log
 cut -c1-130 $OUT/coarse_real_timeline.txt

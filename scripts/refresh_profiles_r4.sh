@@ -32,8 +32,8 @@ FGS_FORCE_DIST=1 python3 bench.py --grid 320 --no-cpu-baseline > $OUT/bench_forc
 
 for t in fine forced coarse; do python3 scripts/trace_summary.py $OUT/$t 30 graph > $OUT/sum_$t.txt; done
 python3 scripts/trace_summary.py $OUT/g320 20 graph > $OUT/sum_g320.txt
-python3 scripts/trace_step.py $OUT/fine 25 > $OUT/timeline_fine.txt
-python3 scripts/trace_step.py $OUT/forced 25 > $OUT/timeline_forced.txt
+python3 scripts/trace_step.py $OUT/fine median > $OUT/timeline_fine.txt
+python3 scripts/trace_step.py $OUT/forced median > $OUT/timeline_forced.txt
 for t in fine forced coarse g320; do
   cp $(ls $OUT/$t/*/*_kernel_stats.csv | head -1) $OUT/kernel_stats_$t.csv
   cp $(ls $OUT/$t/*/*_memory_copy_stats.csv 2>/dev/null | head -1) $OUT/memory_copy_stats_$t.csv 2>/dev/null || true

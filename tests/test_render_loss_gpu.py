@@ -162,3 +162,46 @@ def test_coarse_step_with_announced_loss_matches_the_separate_launches(dev):
             assert rel_l2(b, a) < 2e-6, (tuple(p.shape), rel_l2(b, a))
             n_cmp += 1
     assert n_cmp >= 4
+
+
+def test_fixed_order_scalars_are_bit_reproducible_over_many_launches(dev):
+    """The "last workgroup to arrive sums the partials" scalars (fgs_common.h fgs_arrive_is_last: agent-scope stores, a wait, the
+    arrival; no agent-scope fence) under repetition: 1500 launches of each kernel on the same inputs, with unrelated traffic on
+    the device in between, must give ONE bit pattern -- a partial that was not yet visible to the last workgroup, or a stale
+    copy of it, would show as a different sum."""
+    import ctypes
+    from fgs_nerf_amd import dense
+    from fgs_nerf_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(9)
+    N = 4096
+    counts = torch.randint(0, 30, (N,), generator=g)
+    off = torch.zeros(N + 1, dtype=torch.int64)
+    off[1:] = counts.cumsum(0)
+    M = int(off[-1])
+    t = dict(off=off, weights=torch.rand(M, generator=g) * 0.2, rgb=torch.rand(M, 3, generator=g),
+             normal=torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1), step_id=torch.randint(0, 500, (M,), generator=g),
+             viewdirs=torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1), target=torch.rand(N, 3, generator=g),
+             last=torch.rand(N, generator=g))
+    t = {k: v.to(dev).contiguous() for k, v in t.items()}
+    W5 = (ctypes.c_float * 5)(1.0, 0.05, 0.001, 1e-4, 0.02)
+    o = {k: torch.empty(N, 3, device=dev) for k in ('rm', 'sr', 'pre', 'pres', 'nm')}
+    dep, gl, grm = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+    d_out, d_w, gn = torch.empty(M, 3, device=dev), torch.empty(M, device=dev), torch.empty(M, 3, device=dev)
+    scratch = torch.zeros(4096, device=dev)
+    reps = 1500
+    losses = torch.empty(reps, device=dev)
+    noise = torch.randn(1 << 22, device=dev)
+    vol = (torch.rand(1, 1, 96, 96, 96, device=dev) + 0.1).requires_grad_(False)
+    tv = torch.empty(reps, device=dev)
+    for i in range(reps):
+        call("fgs_fine_render_loss", N, M, ptr(t['off']), ptr(t['weights']), ptr(t['rgb']), ptr(t['normal']), ptr(t['step_id']), 1.0,
+             0.00625, ptr(t['viewdirs']), ptr(t['target']), ptr(t['last']), W5, None, ptr(o['rm']), ptr(o['sr']), ptr(o['pre']),
+             ptr(o['pres']), ptr(o['nm']), ptr(dep), ptr(losses[i:]), ptr(scratch), scratch.numel(), ptr(d_out), ptr(d_w), ptr(gn),
+             ptr(gl), ptr(grm), None, stream())
+        tv[i] = dense.grid_tv_loss(vol, None, scale=0.3).detach()
+        if i % 3 == 0:
+            noise.mul_(1.0001)                       # dirty lines in every L2 between the launches
+    torch.cuda.synchronize()
+    assert bool((losses.view(torch.int32) == losses.view(torch.int32)[0]).all()), losses.unique()
+    assert bool((tv.view(torch.int32) == tv.view(torch.int32)[0]).all()), tv.unique()
+    assert float(scratch[0]) == 0.0
