@@ -63,6 +63,7 @@ _SIGNATURES = {
     "fgs_mlp_wgrad_debug_stamps": [P],
     "fgs_mlp_rc_debug_stamps": [P],
     "fgs_mlp_wgrad": [I64, I32, P, P, P],
+    "fgs_mlp_wgrad_ws": [I64, I32, P, P, I64, P, P],
     "fgs_exclusive_scan_i64": [P, I64, P, P],
     "fgs_exclusive_scan_guard_i64": [P, I64, P, I64, P, P, P],
     "fgs_march_fine_fwd": [P, P, P, I64, P, P, I32, I32, I32, F32, F32, F32, F32, P, F32, F32, F32,
@@ -170,7 +171,7 @@ def exported_symbols():
     return sorted(list(_SIGNATURES) + ["fgs_last_error", "fgs_version", "fgs_device_info", "fgs_gemm_workspace_bytes",
                                           "fgs_mc_num_blocks", "fgs_head_bwd_scratch_floats", "fgs_mlp_rc_image_floats",
                                           "fgs_mlp_rc2_image_floats", "fgs_adam_step_size", "fgs_smooth_tv_scratch_floats",
-                                          "fgs_tv_loss_scratch_doubles"])
+                                          "fgs_tv_loss_scratch_doubles", "fgs_mlp_wgrad_ws_floats"])
 
 
 def lib() -> ctypes.CDLL:
@@ -207,6 +208,8 @@ def lib() -> ctypes.CDLL:
         handle.fgs_smooth_tv_scratch_floats.argtypes = [c_int, c_int, c_int]
         handle.fgs_tv_loss_scratch_doubles.restype = c_int64
         handle.fgs_tv_loss_scratch_doubles.argtypes = []
+        handle.fgs_mlp_wgrad_ws_floats.restype = c_int64
+        handle.fgs_mlp_wgrad_ws_floats.argtypes = []
         handle.fgs_mc_num_blocks.restype = c_int64
         handle.fgs_mc_num_blocks.argtypes = [c_int, c_int, c_int]
         handle.fgs_device_info.argtypes = [c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),

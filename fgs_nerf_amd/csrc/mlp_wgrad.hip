@@ -57,6 +57,11 @@ struct WgBlock {
   int col0, cols, mode;  // first column and width of the block; wave arrangement (WgMode)
   int wg0, n_wg;         // workgroups [wg0, wg0 + n_wg) split the samples of this block
   float stagger;         // a of the share function (wgrad_block)
+  // store mode (fgs_mlp_wgrad_ws): every (workgroup, k-split wave group) writes its partial block with plain stores into its own
+  // slice [n_out][cols] of `slab`, and k_wgrad_reduce adds the slices in order -- no float atomics (64 MB of them per launch at
+  // the fine stage: ~50 us at the chip's atomic rate), and weight gradients that are bit-reproducible
+  float *slab;           // null: the partials are added to dW with atomics
+  int n_slices;          // n_wg x KS of the block's mode
 };
 
 struct WgArgs {
@@ -171,7 +176,13 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   const double sa = b.stagger;
   const int c0 = __builtin_amdgcn_readfirstlane(j_in_block == 0 ? 0 : (int)((double)NC * ((1.0 - sa) * xa + sa * xa * xa)));
   const int c1 = __builtin_amdgcn_readfirstlane(j_in_block + 1 == b.n_wg ? NC : (int)((double)NC * ((1.0 - sa) * xb + sa * xb * xb)));
-  if (c0 >= c1) return;
+  if (c0 >= c1) {
+    if (b.slab) {        // (store mode: the slices of a workgroup without samples must read as zero)
+      float *sl = b.slab + (int64_t)j_in_block * KS * b.n_out * b.cols;
+      for (int64_t i = tid; i < (int64_t)KS * b.n_out * b.cols; i += WG_THREADS) sl[i] = 0.f;
+    }
+    return;
+  }
   const unsigned ld_a4 = (unsigned)b.ld_dy * 4, ld_b4 = (unsigned)b.ld_x * 4;      // row pitch in bytes
 
   // ---- DMA: per-lane source offsets inside a chunk (bytes)
@@ -294,17 +305,23 @@ __device__ __forceinline__ void wgrad_block(const WgBlock &b, int64_t M, int j_i
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memtime();
-  // ---- flush: dW block and bias sums, fp32 atomics (two 128-byte row segments per instruction)
+  // ---- flush: dW block and bias sums, fp32 atomics (two 128-byte row segments per instruction) -- or, store mode, plain
+  // stores of the same shape into this wave group's slice
+  float *const slice = b.slab ? b.slab + ((int64_t)j_in_block * KS + kg) * b.n_out * b.cols : nullptr;
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta) {
 #pragma unroll
     for (int tb = 0; tb < CT; ++tb) {
-      const int col = b.col0 + colp_base + 32 * tb + l31;
+      const int pc = colp_base + 32 * tb + l31;          // column inside the block
+      const int col = b.col0 + pc;
       if (col < b.n_in) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = row_base + 32 * ta + 8 * (r >> 2) + 4 * h + (r & 3);
-          if (n < b.n_out) atomicAdd(b.dW + (int64_t)n * b.ld_dw + col, acc[ta][tb][r]);
+          if (n < b.n_out) {
+            if (slice) slice[(int64_t)n * b.cols + pc] = acc[ta][tb][r];
+            else atomicAdd(b.dW + (int64_t)n * b.ld_dw + col, acc[ta][tb][r]);
+          }
         }
       }
     }
@@ -342,6 +359,44 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_mlp_wgrad(WgArgs a) {
   }
 }
 
+// Store mode, second launch: dW[n][col0 + c] += slice_0[n][c] + slice_1[n][c] + ... in slice order.  A slice is a flat array of
+// n_out x cols floats (a multiple of 4, 16-byte aligned): one thread per float4 of it, eight 16-byte loads in flight, so that a
+// workgroup reads 4 KB of every slice in one piece (one thread per float measured 40 us beside the scatter kernels; 256-byte pieces
+// per wave 107 us: the slices lie 100..256 KB apart and DRAM pages want longer runs).  blockIdx.y = block.
+__global__ __launch_bounds__(FGS_BLOCK) void k_wgrad_reduce(WgArgs a) {
+  const WgBlock &b = a.B[blockIdx.y];
+  const int per = b.n_out * b.cols, per4 = per >> 2;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x * blockDim.x >= per4 || !b.slab) return;
+  if (q < per4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    const f4 *p = reinterpret_cast<const f4 *>(b.slab) + q;
+    int k = 0;
+    for (; k + 8 <= b.n_slices; k += 8) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)(k + u) * per4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < b.n_slices; ++k) s += __builtin_nontemporal_load(p + (int64_t)k * per4);
+    const float sv[4] = {s[0], s[1], s[2], s[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * q + e, n = i / b.cols, c = i - n * b.cols;
+      b.dW[(int64_t)n * b.ld_dw + b.col0 + c] += sv[e];
+    }
+  }
+  // (measurement: the launch pair counts as ONE weight-gradient launch -- every workgroup of the reduction pushes the end reading of
+  // the first record of fgs_dyn_t.stamps, which bench.py takes the maximum of, to its own end)
+  unsigned long long *st = fgs_stamp_base(a.stamps);
+  if (st && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicMax(st + 5, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+}
+
 // M too small for 1 KB DMA pieces to stay inside the tensors: one thread per dW element
 __global__ __launch_bounds__(FGS_BLOCK) void k_wgrad_small(WgArgs a) {
   const int64_t M = fgs_rows(a.M, a.m_dev);
@@ -375,7 +430,34 @@ FGS_API int fgs_mlp_wgrad_debug_stamps(unsigned long long *stamps) {
   return 0;
 }
 
+namespace {
+int wgrad_launch(int64_t M, int n_items, const fgs_wgrad_item_t *items, float *ws, int64_t ws_floats, const fgs_dyn_t *dyn,
+                 fgs_stream_t stream);
+}
+
 FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, const fgs_dyn_t *dyn, fgs_stream_t stream) {
+  return wgrad_launch(M, n_items, items, nullptr, 0, dyn, stream);
+}
+
+// Upper bound of the workspace fgs_mlp_wgrad_ws needs (floats), whatever the shapes: one 256 x 256 partial per workgroup.
+FGS_API int64_t fgs_mlp_wgrad_ws_floats(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  return (int64_t)(cus + WG_MAXBLK) * 65536;
+}
+
+// The same products with the partials written by plain stores into `ws` and summed in a fixed order by a second launch: no float
+// atomics (weight gradients bit-reproducible; bias sums keep theirs).  ws too small for the shapes at hand, or NULL: the atomic form.
+FGS_API int fgs_mlp_wgrad_ws(int64_t M, int n_items, const fgs_wgrad_item_t *items, float *ws, int64_t ws_floats,
+                             const fgs_dyn_t *dyn, fgs_stream_t stream) {
+  return wgrad_launch(M, n_items, items, ws, ws_floats, dyn, stream);
+}
+
+namespace {
+int wgrad_launch(int64_t M, int n_items, const fgs_wgrad_item_t *items, float *ws, int64_t ws_floats, const fgs_dyn_t *dyn,
+                 fgs_stream_t stream) {
   FGS_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && n_items >= 1 && n_items <= WG_MAXBLK, FGS_E_RANGE,
               "fgs_mlp_wgrad: M=%lld n_items=%d (1..%d)", (long long)M, n_items, WG_MAXBLK);
   if (M == 0) return 0;
@@ -436,7 +518,26 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
     if (n > max_per_block) n = (int)max_per_block;
     given += n;
     a.B[i].wg0 = wg; a.B[i].n_wg = n; a.B[i].stagger = stagger;
+    a.B[i].slab = nullptr; a.B[i].n_slices = 0;
     wg += n;
+  }
+  // store mode: slices of every block, back to back
+  bool store_mode = false;
+  bool rows4 = true;
+  for (int i = 0; i < nb; ++i) rows4 = rows4 && (a.B[i].n_out * a.B[i].cols) % 4 == 0;
+  if (ws && rows4 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && !(M < 64 && !a.m_dev)) {
+    static const int ks_of_mode[7] = {1, 2, 4, 1, 2, 4, 4};
+    int64_t need = 0;
+    for (int i = 0; i < nb; ++i) need += (int64_t)a.B[i].n_wg * ks_of_mode[a.B[i].mode] * a.B[i].n_out * a.B[i].cols;
+    if (need <= ws_floats) {
+      int64_t off = 0;
+      for (int i = 0; i < nb; ++i) {
+        a.B[i].slab = ws + off;
+        a.B[i].n_slices = a.B[i].n_wg * ks_of_mode[a.B[i].mode];
+        off += (int64_t)a.B[i].n_slices * a.B[i].n_out * a.B[i].cols;
+      }
+      store_mode = true;
+    }
   }
   if (M < 64 && !a.m_dev) {      // tiny batches: not worth a 256-register workgroup per block
     hipLaunchKernelGGL(k_wgrad_small, dim3(fgs_blocks(256 * 256), (unsigned)nb), dim3(FGS_BLOCK), 0, fgs_s(stream), a);
@@ -445,5 +546,10 @@ FGS_API int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items,
   }
   hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)wg), dim3(WG_THREADS), 0, fgs_s(stream), a);
   FGS_LAUNCH_OK("fgs_mlp_wgrad");
+  if (store_mode) {
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(256 * 256 / 4 / FGS_BLOCK, (unsigned)nb), dim3(FGS_BLOCK), 0, fgs_s(stream), a);
+    FGS_LAUNCH_OK("fgs_mlp_wgrad (reduce)");
+  }
   return 0;
 }
+}  // namespace

@@ -740,7 +740,8 @@ def roofline_report(pmc=None, flop_scale: float = 1.0, stamped=None):
            "kernel": "MLP matrix-core kernels, fp32 v_mfma_f32_32x32x2_f32: k_mlp_rc2 (forward chain / backward data-gradient "
                      "chain incl. the two narrow first-layer products, one launch each: the waves split the features, a CU is "
                      "dealt whole 32-sample tiles; FGS_MLP_FORM=1 or other widths: k_mlp_rc + k_gemm), k_mlp_wgrad (all weight "
-                     "and bias gradients, one launch)",
+                     "and bias gradients, one launch; its duration here includes k_wgrad_reduce, the launch that adds the "
+                     "per-workgroup partial blocks in a fixed order: FGS_WGRAD_STORE=1)",
            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            "traffic": traffic, "traffic_unit": "HBM bytes per launch, mean over the MLP launches of a step",
            "traffic_detail": detail,

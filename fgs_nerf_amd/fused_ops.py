@@ -5,6 +5,8 @@ HIP stream; argument checking that needs the device happens in the C ABI (negati
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import call, lib, ptr, stream, dyn
@@ -312,4 +314,19 @@ def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:
         arr[i].X, arr[i].ld_x, arr[i].n_in = ptr(X), X.stride(0), int(n_in)
         arr[i].dW, arr[i].ld_dw, arr[i].dbias = ptr(dW), dW.stride(0), ptr(db)
     d = dyn(row_count=rows_dev, stamps=_stamp_arg("k_mlp_wgrad", flop, "wgrad"))
+    if _WGRAD_STORE:
+        dev = items[0][0].device
+        ws = _WGRAD_WS.get(dev.index)
+        if ws is None:
+            ws = _WGRAD_WS[dev.index] = torch.empty(int(lib().fgs_mlp_wgrad_ws_floats()), dtype=torch.float32, device=dev)
+        _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad_ws", M, n, ctypes.cast(arr, ctypes.c_void_p), ptr(ws), ws.numel(), d,
+                                                 stream()))
+        return
     _timed("k_mlp_wgrad", flop, lambda: call("fgs_mlp_wgrad", M, n, ctypes.cast(arr, ctypes.c_void_p), d, stream()))
+
+
+# FGS_WGRAD_STORE=1 (default): the weight-gradient launch writes its partial blocks with plain stores into a workspace (73 MB per
+# device) and a second launch adds them in order (fgs_mlp_wgrad_ws): no float atomics for the weights -- 64 MB of them per launch
+# queued at the memory-side atomic units in front of the scatter kernels' --, bit-reproducible weight gradients.  0: atomics.
+_WGRAD_STORE = os.environ.get("FGS_WGRAD_STORE", "1") == "1"
+_WGRAD_WS = {}

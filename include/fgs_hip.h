@@ -430,6 +430,13 @@ typedef struct fgs_wgrad_item {
   float *dbias;
 } fgs_wgrad_item_t;
 int fgs_mlp_wgrad(int64_t M, int n_items, const fgs_wgrad_item_t *items, const fgs_dyn_t *dyn, fgs_stream_t stream);
+/* The same products without float atomics for the weights: every (workgroup, k-split wave group) stores its partial block into a
+ * slice of `ws` and a second launch adds the slices to dW in slice order -- weight gradients bit-reproducible (bias sums keep
+ * their atomics).  ws: 16-byte aligned, fgs_mlp_wgrad_ws_floats() floats always suffice; NULL or too small for the shapes at
+ * hand: the atomic form. */
+int64_t fgs_mlp_wgrad_ws_floats(void);
+int fgs_mlp_wgrad_ws(int64_t M, int n_items, const fgs_wgrad_item_t *items, float *ws, int64_t ws_floats, const fgs_dyn_t *dyn,
+                     fgs_stream_t stream);
 /* Diagnostics for fgs_mlp_wgrad: while a device buffer of >= 2048 uint64 is set, workgroup w records into stamps[8 w ..]
  * the shader clock at its start [0], after its prologue [2], after its sample loop [3] and after issuing its flush [4], the
  * 100 MHz wall clock at start [1] and end [5], its chunk count [6] and its block index [7].  NULL switches it off. */

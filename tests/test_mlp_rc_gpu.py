@@ -288,3 +288,32 @@ def test_in_kernel_stamps_time_the_launches_and_change_nothing(dev):
         assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
     assert torch.equal(C, C_ref)
     assert rel_l2(dW, dW_ref) < 1e-6 and rel_l2(db, db_ref) < 1e-6    # (atomic flush: order dependent)
+
+
+def test_wgrad_store_mode_is_bit_reproducible_and_matches_the_atomic_form(dev, monkeypatch):
+    """fgs_mlp_wgrad_ws (default, FGS_WGRAD_STORE=1): partial blocks by plain stores, added in slice order by a second launch --
+    the same weight gradients as the atomic form to float32 summation order, and ONE bit pattern over repeated launches (the
+    atomic form's sums depend on arrival order); accumulates into a non-zero dW like the atomic form."""
+    from fgs_nerf_amd import fused_ops as fo
+    M = 20011
+    g = torch.Generator().manual_seed(M)
+    n_in, ld_x = [106, 256, 307], [108, 256, 308]
+    Xs = [torch.randn(M, ld, generator=g).to(dev) for ld in ld_x]
+    dYs = [torch.randn(M, 256, generator=g).to(dev) for _ in range(3)]
+
+    def run(store):
+        monkeypatch.setattr(fo, "_WGRAD_STORE", store)
+        dWs = [torch.full((256, ld), 0.5, device=dev) for ld in ld_x]
+        dbs = [torch.zeros(256, device=dev) for _ in range(3)]
+        fo.mlp_wgrad(M, [(dYs[i], Xs[i], dWs[i], dbs[i], 256, n_in[i]) for i in range(3)])
+        torch.cuda.synchronize()
+        return dWs, dbs
+
+    a, _ = run(True)
+    b, _ = run(True)
+    c, _ = run(False)
+    for i in range(3):
+        assert torch.equal(a[i], b[i]), i
+        ref = 0.5 + dYs[i].double().T @ Xs[i][:, :n_in[i]].double()
+        assert rel_l2(a[i][:, :n_in[i]], ref) < 2e-6 and rel_l2(c[i][:, :n_in[i]], ref) < 2e-6
+        assert float((a[i][:, n_in[i]:] - 0.5).abs().max()) == 0.0 if n_in[i] < ld_x[i] else True
