@@ -380,8 +380,9 @@ __global__ __launch_bounds__(FGS_BLOCK) void k_copy_f32x4(const float4 *__restri
 FGS_API int fgs_copy_f32(const float *src, float *dst, int64_t n, fgs_stream_t stream) {
   FGS_REQUIRE(n >= 0 && n < FGS_MAX_ELEMS, FGS_E_RANGE, "fgs_copy_f32: n=%lld", (long long)n);
   if (n == 0) return 0;
-  FGS_REQUIRE(src && dst && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, FGS_E_INVALID,
-              "fgs_copy_f32: null or unaligned pointer");
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  FGS_REQUIRE(src && dst && (aligned || n < 4) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0,
+              FGS_E_INVALID, "fgs_copy_f32: null or unaligned pointer (16 bytes; 4 for fewer than four floats)");
   const int64_t n4 = n / 4;
   const int tail = (int)(n - 4 * n4);
   hipLaunchKernelGGL(k_copy_f32x4, dim3(fgs_blocks(n4 > 0 ? n4 : 1)), dim3(FGS_BLOCK), 0, fgs_s(stream),

@@ -153,8 +153,9 @@ int fgs_sample_emit(const float *rays_o, const float *rays_d, const float *xyz_m
 /* The batch selection of a training iteration (model/nerf_training.py:256-261: rgb_tr[sel], rays_o_tr[sel], rays_d_tr[sel],
  * viewdirs_tr[sel] -- four advanced-indexing gathers) in one launch: out[a][i][:] = src_a[sel[i]][:], out [4][n][3], src_a
  * [n_src][3], sel device int64 (clamped into range). */
-/* dst[0..n) = src[0..n), float32, both pointers 16-byte aligned: a staged batch into a captured step's static inputs as a kernel
- * launch (the runtime's device-to-device blit costs more per call than it moves). */
+/* dst[0..n) = src[0..n), float32, both pointers 16-byte aligned (4-byte for n < 4): a staged batch into a captured step's static
+ * inputs, an iteration's loss scalar into the window's log -- as a kernel launch (the runtime's device-to-device blit costs more per
+ * call than it moves). */
 int fgs_copy_f32(const float *src, float *dst, int64_t n, fgs_stream_t stream);
 int fgs_gather_batch(const int64_t *sel, int64_t n, int64_t n_src, const float *src0, const float *src1, const float *src2,
                      const float *src3, float *out, fgs_stream_t stream);
