@@ -130,13 +130,16 @@ def sdf_gradient_volume(grid: torch.Tensor, voxel_size: float, pack_sdf=None, ho
 
 
 _TV_SCRATCH = {}          # (device index, kind) -> scratch of a TV value launch (first word: its arrival counter, left zero)
+_TV_SCRATCH_RETIRED = []  # outgrown scratch buffers (a few KB each), kept alive: see _tv_scratch
 
 
 def _tv_scratch(dev, kind: str, n: int, dtype) -> torch.Tensor:
     key = (dev.index, kind)
     t = _TV_SCRATCH.get(key)
     if t is None or t.numel() < n:
-        t = _TV_SCRATCH[key] = torch.zeros(n, dtype=dtype, device=dev)     # (a replaced one stays referenced by its launches' stream order)
+        if t is not None:
+            _TV_SCRATCH_RETIRED.append(t)       # (a captured step may hold its address: never handed back to the allocator)
+        t = _TV_SCRATCH[key] = torch.zeros(n, dtype=dtype, device=dev)
     return t
 
 

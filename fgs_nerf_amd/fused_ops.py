@@ -316,6 +316,8 @@ def mlp_wgrad(M: int, items, flop: float = 0.0, rows_dev=None) -> None:
     d = dyn(row_count=rows_dev, stamps=_stamp_arg("k_mlp_wgrad", flop, "wgrad"))
     if _WGRAD_STORE:
         dev = items[0][0].device
+        # one workspace per device: a device runs ONE weight-gradient launch at a time (the launch pairs of a training step are
+        # ordered on their stream; a caller that overlaps two of them on two streams must set FGS_WGRAD_STORE=0)
         ws = _WGRAD_WS.get(dev.index)
         if ws is None:
             ws = _WGRAD_WS[dev.index] = torch.empty(int(lib().fgs_mlp_wgrad_ws_floats()), dtype=torch.float32, device=dev)
