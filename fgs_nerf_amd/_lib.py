@@ -19,7 +19,7 @@ P, F32, I64, I32, F64 = c_void_p, c_float, c_int64, c_int, c_double
 
 # The ABI this binding was written against (include/fgs_hip.h FGS_ABI_VERSION).  lib() refuses a library built from another
 # header: a stale libfgs_hip.so whose symbol NAMES all exist would otherwise be called with this table's argument lists.
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # name -> argtypes (all functions return int); mirrors include/fgs_hip.h one to one
 _SIGNATURES = {

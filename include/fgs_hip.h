@@ -38,7 +38,7 @@ typedef void *fgs_stream_t;
  * thread-local setters; 5 = fgs_dyn_t carries the in-kernel wall-clock stamps of the matrix-core launches; 6 = fgs_box_mask_fill; 7 = fgs_fine_loss_fwd takes a scratch buffer; 8 = fgs_mlp_rc2_chain;
  * 9 = fgs_step_scalars_tick2; 10 = fgs_mlp_rc2_pack, fgs_mlp_rc2_chain(prepacked);
  * 11 = fgs_fine_render_loss. */
-#define FGS_ABI_VERSION 13
+#define FGS_ABI_VERSION 14
 
 const char *fgs_last_error(void);
 int fgs_version(void);                       /* == FGS_ABI_VERSION of the build */
