@@ -216,6 +216,7 @@ class _FusedCoarse(torch.autograd.Function):
         fl = getattr(run, 'fused_loss', None)
         if fl is not None and fl['used']:
             # (the forward pass ran the loss and the compositing backward already: fused_common._composite)
+            _check_only_announced_loss(fl, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal)
             d_out, d_w, g_normal, g_last = fl['d_out'], fl['d_w'], fl['g_normal'], fl['g_last']
         else:
             d_out = torch.empty(M, 3, dtype=F32, device=dev)

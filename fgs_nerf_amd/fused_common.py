@@ -629,6 +629,16 @@ def _composite(run, needs_grad, N, M, surv_off, weights, rgb, normal, step_id, a
     return None
 
 
+def _check_only_announced_loss(fl, g_rgb_marched, *others) -> None:
+    """The backward pass is about to start from the stash of the one-launch loss: that is only right when the announced loss is the
+    ONLY thing differentiated through this forward pass's outputs -- any other term (a loss on depth, on the weights ...) would hand
+    its gradient to this node and be dropped.  Refuse instead."""
+    if any(t is not None for t in others) or g_rgb_marched is None or g_rgb_marched.data_ptr() != fl['g_rm'].data_ptr():
+        raise RuntimeError("fused.set_loss_spec: another term than the announced loss is differentiated through the render "
+                           "result (only the announced loss may be: call set_loss_spec(model, None, cfg) to switch the "
+                           "one-launch loss off for such a step)")
+
+
 def disable_early_update(model, averager=None) -> None:
     model.__dict__.setdefault('_fused_cache', {}).pop('opt_hook', None)
     if averager is not None:

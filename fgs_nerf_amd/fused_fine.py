@@ -534,6 +534,7 @@ class _FusedFine(torch.autograd.Function):
         if fl is not None and fl['used']:
             # the forward pass already ran the loss and the compositing backward (fgs_fine_render_loss): the gradients that arrive
             # here are the loss node's placeholders; the real ones are in the stash
+            _check_only_announced_loss(fl, g_rgb_marched, g_sigmoid_rgb, g_last, g_weights, g_raw_rgb, g_normal)
             d_out, d_w, g_normal, g_last = fl['d_out'], fl['d_w'], fl['g_normal'], fl['g_last']
         else:
             _seam(run, 'inputs', g_rgb_marched=g_rgb_marched, g_sigmoid_rgb=g_sigmoid_rgb, g_last=g_last, g_weights=g_weights,

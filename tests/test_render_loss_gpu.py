@@ -205,3 +205,20 @@ def test_fixed_order_scalars_are_bit_reproducible_over_many_launches(dev):
     assert bool((losses.view(torch.int32) == losses.view(torch.int32)[0]).all()), losses.unique()
     assert bool((tv.view(torch.int32) == tv.view(torch.int32)[0]).all()), tv.unique()
     assert float(scratch[0]) == 0.0
+
+
+def test_another_term_on_the_render_result_is_refused(dev):
+    """With an announced loss the backward pass starts from the kernel's stash: a second term differentiated through the same
+    render result (here: on the weights) would be dropped silently -- it must raise instead."""
+    from fgs_nerf_amd import synth
+    from fgs_nerf_amd.fused import set_loss_spec
+    from fgs_nerf_amd.losses import fused_render_losses
+    model = synth.build_model(96, synth.FINE_MODEL, device=dev)
+    ro, rd, vd = (t[:512].contiguous().to(dev) for t in synth.random_rays(4096, seed=synth.SEED))
+    target = torch.rand(512, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    set_loss_spec(model, target, synth.FINE_LOSS)
+    res = model(ro, rd, vd, global_step=1000, **synth.RENDER_KWARGS)
+    loss = fused_render_losses(res, target, synth.FINE_LOSS, model) + 0.1 * res['weights'].sum()
+    with pytest.raises(RuntimeError, match="another term"):
+        loss.backward()
+    set_loss_spec(model, None, synth.FINE_LOSS)
